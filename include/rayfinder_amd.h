@@ -1,0 +1,256 @@
+/*
+ * rayfinder_amd.h -- C ABI of the MI355X-native path-tracing core (librayfinder_amd.so).
+ *
+ * This is the drop-in boundary for rayfinder's hot path.  The reference (Nelarius/rayfinder) has
+ * no FFI layer; its path sits behind three C++ seams.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference repo).  Plain pointers and sizes only;
+ * every call returns RF_OK (0) or an error code instead of throwing -- rf_last_error_message()
+ * returns the text the reference would have put into its std::runtime_error.  One handle is used
+ * from one host thread at a time (as in the reference, whose renderer lives on the GLFW thread).
+ *
+ * Record layouts are the reference's, byte for byte:
+ *   BvhNode 48 B (src/common/bvh.hpp:14-21), Positions 36 B (src/common/triangle_attributes.hpp:7-12),
+ *   PositionAttribute 48 B / VertexAttributes 80 B (src/pt-format/vertex_attributes.hpp:7-35),
+ *   texture pixels u32 BGRA (src/common/texture.cpp:46), AlignedSkyState 160 B
+ *   (src/pt/aligned_sky_state.hpp:34-41).
+ */
+#ifndef RAYFINDER_AMD_H
+#define RAYFINDER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_API __attribute__((visibility("default")))
+
+typedef enum rf_status
+{
+    RF_OK = 0,
+    RF_ERROR_INVALID_ARGUMENT = 1,
+    RF_ERROR_RUNTIME = 2,      /* what the reference reports with std::runtime_error */
+    RF_ERROR_NO_DEVICE = 3,    /* no HIP device: this library has NO CPU fallback for rendering */
+    RF_ERROR_OUT_OF_RANGE = 4, /* sky parameters out of range (sky_state_result != success) */
+} rf_status;
+
+/* Text of the last error on the calling thread ("" if none). */
+RF_API const char* rf_last_error_message(void);
+RF_API const char* rf_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Value types
+ * ------------------------------------------------------------------------------------------ */
+/* nlrs::Camera, src/common/camera.hpp:10-21 (19 floats). */
+typedef struct rf_camera
+{
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float up[3];
+    float right[3];
+    float lens_radius;
+} rf_camera;
+
+/* nlrs::Sky, src/pt/aligned_sky_state.hpp:15-23. */
+typedef struct rf_sky
+{
+    float turbidity;          /* [1, 10] */
+    float albedo[3];          /* [0, 1] */
+    float sun_zenith_degrees; /* [0, 90] */
+    float sun_azimuth_degrees;
+} rf_sky;
+
+/* nlrs::RenderParameters + SamplingParams, src/pt/reference_path_tracer.hpp:26-43. */
+typedef struct rf_render_parameters
+{
+    uint32_t  width, height;          /* framebufferSize */
+    rf_camera camera;
+    uint32_t  num_samples_per_pixel;  /* default 128 */
+    uint32_t  num_bounces;            /* default 4 */
+    rf_sky    sky;
+    float     exposure;               /* 1 / 2^stops (src/pt/main.cpp:367) */
+} rf_render_parameters;
+
+/* nlrs::Texture as a view, src/common/texture.hpp:10-47. */
+typedef struct rf_texture
+{
+    const uint32_t* pixels; /* width*height BGRA (b | g<<8 | r<<16 | a<<24) */
+    uint32_t        width, height;
+} rf_texture;
+
+/* nlrs::Scene, src/pt/reference_path_tracer.hpp:45-51: non-owning views; rf_renderer_create
+ * copies everything to device memory and keeps nothing from these pointers. */
+typedef struct rf_scene
+{
+    const void*       bvh_nodes;           /* 48-B BvhNode records */
+    uint64_t          num_bvh_nodes;
+    const void*       position_attributes; /* 48-B PositionAttribute records, BVH leaf order */
+    const void*       vertex_attributes;   /* 80-B VertexAttributes records, same order */
+    uint64_t          num_triangles;
+    const rf_texture* base_color_textures;
+    uint64_t          num_textures;
+} rf_scene;
+
+/* nlrs::RendererDescriptor, src/pt/reference_path_tracer.hpp:53-57, plus device placement. */
+typedef struct rf_renderer_descriptor
+{
+    rf_render_parameters render_params;
+    uint32_t             max_width, max_height; /* maxFramebufferSize; 0 = render_params size */
+    int32_t              device_ordinal;
+    uint64_t             max_paths_in_flight;   /* 0 = default (8 Mi paths per batch) */
+} rf_renderer_descriptor;
+
+typedef struct rf_stats
+{
+    uint64_t primary_rays, closest_rays, shadow_rays;
+    uint64_t closest_node_visits, closest_triangle_tests; /* only while counting is enabled */
+    uint64_t shadow_node_visits, shadow_triangle_tests;
+    uint64_t paths;
+    uint32_t stack_high_water, reserved;
+    double   ms_raygen, ms_closest, ms_shade, ms_shadow, ms_accumulate; /* while timing is enabled */
+    uint32_t launches_raygen, launches_closest, launches_shade, launches_shadow, launches_accumulate, reserved2;
+} rf_stats;
+
+typedef struct rf_renderer rf_renderer;
+
+/* ---------------------------------------------------------------------------------------------
+ * Renderer  (replaces class nlrs::ReferencePathTracer, src/pt/reference_path_tracer.hpp:59-76)
+ * ------------------------------------------------------------------------------------------ */
+/* ReferencePathTracer(const RendererDescriptor&, const GpuContext&, Scene)
+ * (reference_path_tracer.cpp:131-481).  Fails with RF_ERROR_NO_DEVICE when no GPU is present. */
+RF_API int rf_renderer_create(const rf_renderer_descriptor* desc, const rf_scene* scene, rf_renderer** out);
+RF_API void rf_renderer_destroy(rf_renderer* r);
+
+/* void setRenderParameters(const RenderParameters&) (reference_path_tracer.cpp:556-563):
+ * any change resets the accumulation; frameCount keeps counting. */
+RF_API int rf_renderer_set_render_parameters(rf_renderer* r, const rf_render_parameters* params);
+
+/* void render(...) called num_frames times (reference_path_tracer.cpp:565-595 + fsMain
+ * wgsl:34-57): frame f uses sample index frameCount % spp, adds one sample while fewer than spp
+ * are accumulated.  Work is enqueued on the handle's HIP stream; returns without waiting. */
+RF_API int rf_renderer_render(rf_renderer* r, uint32_t num_frames);
+RF_API int rf_renderer_synchronize(rf_renderer* r);
+
+/* float averageRenderpassDurationMs() const (reference_path_tracer.cpp:706-716): mean GPU time per
+ * sample over the last 30 samples. */
+RF_API float rf_renderer_average_renderpass_duration_ms(rf_renderer* r);
+/* float renderProgressPercentage() const (reference_path_tracer.cpp:718-722). */
+RF_API float rf_renderer_render_progress_percentage(const rf_renderer* r);
+
+/* The reference's `imageBuffer` (wgsl:32; never read back there): row-major width*height*4 f32,
+ * SUM of samples, 16-byte stride.  This is the parity surface. */
+RF_API int rf_renderer_read_accumulation(rf_renderer* r, float* dst, uint32_t* accumulated_sample_count);
+/* fsMain's return value (wgsl:59-63) as the BGRA8Unorm swap-chain texel, row-major. */
+RF_API int rf_renderer_read_tonemapped(rf_renderer* r, uint32_t* dst_bgra8);
+
+/* Statistics (replaces the ImGui perf read-out, src/pt/main.cpp:251-257). */
+RF_API int rf_renderer_set_counting(rf_renderer* r, int enabled);
+RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
+RF_API int rf_renderer_reset_stats(rf_renderer* r);
+RF_API int rf_renderer_get_stats(rf_renderer* r, rf_stats* out);
+
+/* Multi-GPU tile sharding (no reference counterpart: the reference is single-device).  The image
+ * is cut into 32x32 tiles dealt to ranks in a scrambled round-robin; each rank renders its tiles
+ * into a compact tile-major float4 buffer that the caller gathers (RCCL) and un-tiles. */
+RF_API int rf_renderer_set_tile_shard(rf_renderer* r, uint32_t rank, uint32_t world_size);
+RF_API int rf_renderer_shard_tiles(rf_renderer* r, uint32_t* tile_ids /* may be NULL */, uint32_t* num_tiles);
+RF_API int rf_renderer_accumulation_device_buffer(rf_renderer* r, void** device_ptr, uint64_t* bytes);
+RF_API int rf_renderer_bind_accumulation_buffer(rf_renderer* r, void* device_ptr, uint64_t bytes);
+/* Host helpers (no GPU needed). */
+RF_API int rf_tiles_for_rank(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, uint32_t* tile_ids, uint32_t* num_tiles);
+RF_API int rf_untile(const float* compact, const uint32_t* tile_ids, uint32_t num_tiles, uint32_t width, uint32_t height, float* image);
+
+/* ---------------------------------------------------------------------------------------------
+ * BVH queries on the GPU
+ * ------------------------------------------------------------------------------------------ */
+/* The bvh-visualizer pixel loop (src/bvh-visualizer/main.cpp:60-78): pinhole camera
+ * (generateCameraRay, src/common/camera.cpp:44-52), u = j/W, v = 1-(i+1)/H, tMax = FLT_MAX.
+ * nodes_visited[W*H] row-major is bit-exact with the CPU reference's BvhStats::nodesVisited. */
+RF_API int rf_renderer_trace_primary_stats(rf_renderer* r, const rf_camera* camera, uint32_t width, uint32_t height,
+                                           uint32_t* nodes_visited, uint8_t* hit /* NULL ok */, float* t /* NULL ok */,
+                                           uint32_t* triangle_tests /* NULL ok */);
+/* bool rayIntersectBvh(const Ray&, span<BvhNode>, span<Positions>, float tMax, Intersection&,
+ * BvhStats*) (src/common/ray_intersection.hpp:43-49) for a batch of rays (6 floats each: origin,
+ * direction).  triangle[i] = 0xFFFFFFFF on a miss. */
+RF_API int rf_renderer_intersect_rays(rf_renderer* r, const float* rays6, uint64_t num_rays, float t_max, uint32_t* triangle,
+                                      float* t, float* uv, float* p, uint32_t* nodes_visited, uint32_t* triangle_tests);
+/* shadowRay (wgsl:321-368): visibility[i] = 1.0 if nothing is hit, else 0.0. */
+RF_API int rf_renderer_occluded_rays(rf_renderer* r, const float* rays6, uint64_t num_rays, float t_max, float* visibility);
+
+/* ---------------------------------------------------------------------------------------------
+ * CPU-side scene preparation (host code, runs without a GPU)
+ * ------------------------------------------------------------------------------------------ */
+/* Bvh buildBvh(std::span<const Positions>) (src/common/bvh.hpp:33, bvh.cpp:263-291).
+ * nodes_out: room for 2*num_triangles 48-B nodes; triangle_indices_out[src] = leaf-order index. */
+RF_API int rf_build_bvh(const float* positions36, uint64_t num_triangles, void* nodes_out, uint64_t* num_nodes_out,
+                        uint64_t* triangle_indices_out, int32_t* depth_out /* NULL ok */);
+
+/* Camera createCamera(origin, lookAt, aperture, focusDistance, vfov, aspectRatio)
+ * (src/common/camera.cpp:7-42); vfov in radians (Angle::asRadians). */
+RF_API int rf_create_camera(const float origin[3], const float look_at[3], float aperture, float focus_distance,
+                            float vfov_radians, float aspect_ratio, rf_camera* out);
+/* FlyCameraController::getCamera (src/pt/fly_camera_controller.cpp:12-22,138-148). */
+RF_API int rf_fly_camera(const float position[3], float yaw_degrees, float pitch_degrees, float vfov_degrees, float aperture,
+                         float focus_distance, float aspect_ratio, rf_camera* out);
+/* The camera lambda of src/bvh-visualizer/main.cpp:36-55 for a 48-B root node. */
+RF_API int rf_bvh_visualizer_camera(const void* root_node48, float aspect_ratio, rf_camera* out);
+
+/* sky_state_new / sky_state_radiance (src/hw-skymodel/hw_skymodel.h:35,44); state33 = params[27],
+ * sky_radiances[3], solar_radiances[3].  Returns the reference's sky_state_result value. */
+RF_API int   rf_sky_state_new(float elevation, float turbidity, const float albedo[3], float state33[33]);
+RF_API float rf_sky_state_radiance(const float state33[33], float theta, float gamma, int channel);
+/* AlignedSkyState(const Sky&) (src/pt/aligned_sky_state.hpp:44-70): 40 floats. */
+RF_API int rf_aligned_sky_state(const rf_sky* sky, float out40[40]);
+
+/* ---------------------------------------------------------------------------------------------
+ * .pt scene files  (replaces nlrs::PtFormat + serialize/deserialize, src/pt-format/pt_format.hpp:18-43)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct rf_pt_format rf_pt_format;
+
+typedef struct rf_pt_format_view
+{
+    const void*     bvh_nodes;                    uint64_t num_bvh_nodes;
+    const void*     bvh_position_attributes;      uint64_t num_bvh_position_attributes;      /* 36 B */
+    const void*     triangle_position_attributes; uint64_t num_triangle_position_attributes; /* 48 B */
+    const void*     triangle_vertex_attributes;   uint64_t num_triangle_vertex_attributes;   /* 80 B */
+    const float*    vertex_positions;             uint64_t num_vertex_positions;             /* vec4 */
+    const float*    vertex_normals;               uint64_t num_vertex_normals;               /* vec4 */
+    const float*    vertex_tex_coords;            uint64_t num_vertex_tex_coords;            /* vec2 */
+    const uint32_t* vertex_indices;               uint64_t num_vertex_indices;
+    const uint64_t* model_vertex_positions;       uint64_t num_model_vertex_positions;       /* {offset,count} pairs */
+    const uint64_t* model_vertex_normals;         uint64_t num_model_vertex_normals;
+    const uint64_t* model_vertex_tex_coords;      uint64_t num_model_vertex_tex_coords;
+    const uint64_t* model_vertex_indices;         uint64_t num_model_vertex_indices;
+    const uint32_t* model_base_color_texture_indices; uint64_t num_model_base_color_texture_indices;
+    uint64_t        num_textures;
+} rf_pt_format_view;
+
+/* PtFormat(std::filesystem::path gltfPath) (pt_format.cpp:20-151): glTF/GLB -> BVH + GPU arrays. */
+RF_API int rf_pt_format_from_gltf(const char* gltf_path, rf_pt_format** out);
+/* deserialize(InputStream&, PtFormat&) (pt_format.cpp:271-321) from a file / from memory.
+ * Wrong magic -> RF_ERROR_RUNTIME with the reference's exact messages (src/tests/pt_format.cpp:192-210). */
+RF_API int rf_pt_format_load(const char* pt_path, rf_pt_format** out);
+RF_API int rf_pt_format_deserialize(const void* data, uint64_t size, rf_pt_format** out);
+/* serialize(OutputStream&, const PtFormat&) (pt_format.cpp:240-269). */
+RF_API int rf_pt_format_save(const rf_pt_format* f, const char* pt_path);
+RF_API int rf_pt_format_serialize(const rf_pt_format* f, void* dst /* NULL = size query */, uint64_t* size);
+/* Build a PtFormat from caller arrays (triangle soup in source order + textures): runs buildBvh +
+ * reorderAttributes + the GPU-layout packing of pt_format.cpp:40-79.  Raster-mesh arrays are left
+ * empty.  Used by the synthetic-scene generator. */
+RF_API int rf_pt_format_from_triangles(const float* positions36, const float* normals36, const float* tex_coords24,
+                                       const uint32_t* texture_indices, uint64_t num_triangles, const rf_texture* textures,
+                                       uint64_t num_textures, rf_pt_format** out);
+RF_API int  rf_pt_format_view_get(const rf_pt_format* f, rf_pt_format_view* out);
+RF_API int  rf_pt_format_texture(const rf_pt_format* f, uint64_t index, rf_texture* out);
+RF_API void rf_pt_format_destroy(rf_pt_format* f);
+/* Fill an rf_scene (the four spans of nlrs::Scene, src/pt/main.cpp:150-157) from a PtFormat.
+ * textures_out must hold num_textures entries. */
+RF_API int rf_pt_format_scene(const rf_pt_format* f, rf_scene* scene_out, rf_texture* textures_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYFINDER_AMD_H */

@@ -1,0 +1,588 @@
+// rf_c_api.cpp -- the extern "C" boundary declared in include/rayfinder_amd.h.
+// Exceptions never cross it: they become status codes + a thread-local message.
+#include "../../include/rayfinder_amd.h"
+
+#include "rf_bvh.hpp"
+#include "rf_camera.hpp"
+#include "rf_gltf.hpp"
+#include "rf_pt_format.hpp"
+#include "rf_renderer.hpp"
+#include "rf_sky.hpp"
+
+#include <cstring>
+#include <exception>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+static_assert(sizeof(rf_camera) == sizeof(rf::Camera));
+
+struct rf_renderer
+{
+    std::unique_ptr<rf::Renderer> impl;
+};
+
+struct rf_pt_format
+{
+    rf::PtFormat format;
+};
+
+namespace
+{
+thread_local std::string gLastError;
+
+struct NoDevice : std::runtime_error
+{
+    using std::runtime_error::runtime_error;
+};
+
+template<typename F>
+int guarded(F&& f)
+{
+    try
+    {
+        gLastError.clear();
+        return f();
+    }
+    catch (const std::invalid_argument& e)
+    {
+        gLastError = e.what();
+        return RF_ERROR_INVALID_ARGUMENT;
+    }
+    catch (const std::bad_alloc&)
+    {
+        gLastError = "out of host memory";
+        return RF_ERROR_RUNTIME;
+    }
+    catch (const std::exception& e)
+    {
+        gLastError = e.what();
+        if (gLastError.find("no HIP device") != std::string::npos) return RF_ERROR_NO_DEVICE;
+        if (gLastError.find("sky parameters out of range") != std::string::npos) return RF_ERROR_OUT_OF_RANGE;
+        return RF_ERROR_RUNTIME;
+    }
+    catch (...)
+    {
+        gLastError = "Unknown exception occurred.";
+        return RF_ERROR_RUNTIME;
+    }
+}
+
+void require(bool cond, const char* what)
+{
+    if (!cond) throw std::invalid_argument(what);
+}
+
+rf::Vec3 v3(const float* p) { return rf::vec3(p[0], p[1], p[2]); }
+
+rf::Camera toCamera(const rf_camera& c)
+{
+    rf::Camera out;
+    std::memcpy(&out, &c, sizeof out);
+    return out;
+}
+
+rf::RenderParameters toParams(const rf_render_parameters& p)
+{
+    rf::RenderParameters out;
+    out.width = p.width;
+    out.height = p.height;
+    out.camera = toCamera(p.camera);
+    out.samplingParams.numSamplesPerPixel = p.num_samples_per_pixel;
+    out.samplingParams.numBounces = p.num_bounces;
+    out.sky.turbidity = p.sky.turbidity;
+    std::memcpy(out.sky.albedo, p.sky.albedo, sizeof out.sky.albedo);
+    out.sky.sunZenithDegrees = p.sky.sun_zenith_degrees;
+    out.sky.sunAzimuthDegrees = p.sky.sun_azimuth_degrees;
+    out.exposure = p.exposure;
+    require(p.width > 0 && p.height > 0, "framebuffer size must be non-zero");
+    require(p.num_samples_per_pixel > 0, "num_samples_per_pixel must be > 0");
+    require(p.num_bounces > 0, "num_bounces must be > 0");
+    return out;
+}
+} // namespace
+
+extern "C" {
+
+const char* rf_last_error_message(void) { return gLastError.c_str(); }
+const char* rf_version(void) { return "rayfinder_amd 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------- renderer
+int rf_renderer_create(const rf_renderer_descriptor* desc, const rf_scene* scene, rf_renderer** out)
+{
+    return guarded([&] {
+        require(desc && scene && out, "null argument");
+        require(scene->bvh_nodes && scene->num_bvh_nodes > 0, "scene has no BVH nodes");
+        require(scene->num_triangles == 0 || (scene->position_attributes && scene->vertex_attributes), "null triangle arrays");
+        rf::RendererDescriptor d;
+        d.renderParams = toParams(desc->render_params);
+        d.maxWidth = desc->max_width;
+        d.maxHeight = desc->max_height;
+        d.deviceOrdinal = desc->device_ordinal;
+        d.maxPathsInFlight = desc->max_paths_in_flight;
+        std::vector<rf::TextureView> textures;
+        for (uint64_t i = 0; i < scene->num_textures; ++i)
+        {
+            const rf_texture& t = scene->base_color_textures[i];
+            require(t.pixels && t.width && t.height, "empty texture");
+            textures.push_back({t.pixels, t.width, t.height});
+        }
+        rf::SceneView view;
+        view.bvhNodes = {static_cast<const rf::BvhNode*>(scene->bvh_nodes), static_cast<size_t>(scene->num_bvh_nodes)};
+        view.positionAttributes = {static_cast<const rf::PositionAttribute*>(scene->position_attributes), static_cast<size_t>(scene->num_triangles)};
+        view.vertexAttributes = {static_cast<const rf::VertexAttributes*>(scene->vertex_attributes), static_cast<size_t>(scene->num_triangles)};
+        view.baseColorTextures = textures;
+        auto handle = std::make_unique<rf_renderer>();
+        handle->impl = std::make_unique<rf::Renderer>(d, view);
+        *out = handle.release();
+        return RF_OK;
+    });
+}
+
+void rf_renderer_destroy(rf_renderer* r) { delete r; }
+
+int rf_renderer_set_render_parameters(rf_renderer* r, const rf_render_parameters* params)
+{
+    return guarded([&] {
+        require(r && params, "null argument");
+        r->impl->setRenderParameters(toParams(*params));
+        return RF_OK;
+    });
+}
+
+int rf_renderer_render(rf_renderer* r, uint32_t num_frames)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->render(num_frames);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_synchronize(rf_renderer* r)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->synchronize();
+        return RF_OK;
+    });
+}
+
+float rf_renderer_average_renderpass_duration_ms(rf_renderer* r)
+{
+    float v = 0.0f;
+    guarded([&] {
+        require(r, "null argument");
+        v = r->impl->averageRenderpassDurationMs();
+        return RF_OK;
+    });
+    return v;
+}
+
+float rf_renderer_render_progress_percentage(const rf_renderer* r) { return r ? r->impl->renderProgressPercentage() : 0.0f; }
+
+int rf_renderer_read_accumulation(rf_renderer* r, float* dst, uint32_t* accumulated)
+{
+    return guarded([&] {
+        require(r && dst, "null argument");
+        r->impl->readAccumulation(dst);
+        if (accumulated) *accumulated = r->impl->accumulatedSampleCount();
+        return RF_OK;
+    });
+}
+
+int rf_renderer_read_tonemapped(rf_renderer* r, uint32_t* dst)
+{
+    return guarded([&] {
+        require(r && dst, "null argument");
+        r->impl->readTonemapped(dst);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_set_counting(rf_renderer* r, int enabled)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->setCounting(enabled != 0);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_set_timing(rf_renderer* r, int enabled)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->setTiming(enabled != 0);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_reset_stats(rf_renderer* r)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->resetStats();
+        return RF_OK;
+    });
+}
+
+int rf_renderer_get_stats(rf_renderer* r, rf_stats* out)
+{
+    return guarded([&] {
+        require(r && out, "null argument");
+        const rf::RenderStats s = r->impl->stats();
+        std::memset(out, 0, sizeof *out);
+        out->primary_rays = s.primaryRays;
+        out->closest_rays = s.closestRays;
+        out->shadow_rays = s.shadowRays;
+        out->closest_node_visits = s.closestNodeVisits;
+        out->closest_triangle_tests = s.closestTriangleTests;
+        out->shadow_node_visits = s.shadowNodeVisits;
+        out->shadow_triangle_tests = s.shadowTriangleTests;
+        out->paths = s.paths;
+        out->stack_high_water = s.stackHighWater;
+        out->ms_raygen = s.msRaygen;
+        out->ms_closest = s.msClosest;
+        out->ms_shade = s.msShade;
+        out->ms_shadow = s.msShadow;
+        out->ms_accumulate = s.msAccumulate;
+        out->launches_raygen = s.launchesRaygen;
+        out->launches_closest = s.launchesClosest;
+        out->launches_shade = s.launchesShade;
+        out->launches_shadow = s.launchesShadow;
+        out->launches_accumulate = s.launchesAccumulate;
+        return RF_OK;
+    });
+}
+
+int rf_renderer_set_tile_shard(rf_renderer* r, uint32_t rank, uint32_t world_size)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        require(world_size > 0 && rank < world_size, "invalid rank / world size");
+        r->impl->setTileShard(rank, world_size);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_shard_tiles(rf_renderer* r, uint32_t* tile_ids, uint32_t* num_tiles)
+{
+    return guarded([&] {
+        require(r && num_tiles, "null argument");
+        const auto tiles = r->impl->shardTiles();
+        *num_tiles = static_cast<uint32_t>(tiles.size());
+        if (tile_ids) std::memcpy(tile_ids, tiles.data(), tiles.size() * sizeof(uint32_t));
+        return RF_OK;
+    });
+}
+
+int rf_renderer_accumulation_device_buffer(rf_renderer* r, void** device_ptr, uint64_t* bytes)
+{
+    return guarded([&] {
+        require(r && device_ptr && bytes, "null argument");
+        *device_ptr = r->impl->accumulationDevicePointer();
+        *bytes = r->impl->accumulationBytes();
+        return RF_OK;
+    });
+}
+
+int rf_renderer_bind_accumulation_buffer(rf_renderer* r, void* device_ptr, uint64_t bytes)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->bindAccumulationBuffer(device_ptr, bytes);
+        return RF_OK;
+    });
+}
+
+int rf_tiles_for_rank(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, uint32_t* tile_ids, uint32_t* num_tiles)
+{
+    return guarded([&] {
+        require(num_tiles, "null argument");
+        require(world_size > 0 && rank < world_size, "invalid rank / world size");
+        const auto tiles = rf::tilesForRank(width, height, rank, world_size);
+        *num_tiles = static_cast<uint32_t>(tiles.size());
+        if (tile_ids) std::memcpy(tile_ids, tiles.data(), tiles.size() * sizeof(uint32_t));
+        return RF_OK;
+    });
+}
+
+int rf_untile(const float* compact, const uint32_t* tile_ids, uint32_t num_tiles, uint32_t width, uint32_t height, float* image)
+{
+    return guarded([&] {
+        require((compact && tile_ids) || num_tiles == 0, "null argument");
+        require(image, "null argument");
+        rf::untileHost(compact, tile_ids, num_tiles, width, height, image);
+        return RF_OK;
+    });
+}
+
+// ---------------------------------------------------------------------------------------- queries
+int rf_renderer_trace_primary_stats(rf_renderer* r, const rf_camera* camera, uint32_t width, uint32_t height, uint32_t* nodes_visited,
+                                    uint8_t* hit, float* t, uint32_t* triangle_tests)
+{
+    return guarded([&] {
+        require(r && camera && nodes_visited, "null argument");
+        require(width > 0 && height > 0, "empty image");
+        r->impl->tracePrimaryStats(toCamera(*camera), width, height, nodes_visited, hit, t, triangle_tests);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_intersect_rays(rf_renderer* r, const float* rays6, uint64_t num_rays, float t_max, uint32_t* triangle, float* t, float* uv,
+                               float* p, uint32_t* nodes_visited, uint32_t* triangle_tests)
+{
+    return guarded([&] {
+        require(r && (num_rays == 0 || (rays6 && triangle)), "null argument");
+        r->impl->intersectRays(rays6, num_rays, t_max, triangle, t, uv, p, nodes_visited, triangle_tests);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_occluded_rays(rf_renderer* r, const float* rays6, uint64_t num_rays, float t_max, float* visibility)
+{
+    return guarded([&] {
+        require(r && (num_rays == 0 || (rays6 && visibility)), "null argument");
+        r->impl->occludedRays(rays6, num_rays, t_max, visibility);
+        return RF_OK;
+    });
+}
+
+// ---------------------------------------------------------------------------------------- CPU side
+int rf_build_bvh(const float* positions36, uint64_t num_triangles, void* nodes_out, uint64_t* num_nodes_out,
+                 uint64_t* triangle_indices_out, int32_t* depth_out)
+{
+    return guarded([&] {
+        require(positions36 && nodes_out && num_nodes_out && triangle_indices_out, "null argument");
+        require(num_triangles > 0, "buildBvh needs at least one triangle"); // bvh.cpp:265 asserts
+        const rf::Bvh bvh = rf::buildBvh({reinterpret_cast<const rf::Positions*>(positions36), static_cast<size_t>(num_triangles)});
+        std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rf::BvhNode));
+        *num_nodes_out = bvh.nodes.size();
+        for (size_t i = 0; i < bvh.triangleIndices.size(); ++i) triangle_indices_out[i] = bvh.triangleIndices[i];
+        if (depth_out) *depth_out = bvh.depth;
+        return RF_OK;
+    });
+}
+
+int rf_create_camera(const float origin[3], const float look_at[3], float aperture, float focus_distance, float vfov_radians,
+                     float aspect_ratio, rf_camera* out)
+{
+    return guarded([&] {
+        require(origin && look_at && out, "null argument");
+        const rf::Camera c = rf::createCamera(v3(origin), v3(look_at), aperture, focus_distance, vfov_radians, aspect_ratio);
+        std::memcpy(out, &c, sizeof c);
+        return RF_OK;
+    });
+}
+
+int rf_fly_camera(const float position[3], float yaw_degrees, float pitch_degrees, float vfov_degrees, float aperture, float focus_distance,
+                  float aspect_ratio, rf_camera* out)
+{
+    return guarded([&] {
+        require(position && out, "null argument");
+        const rf::Camera c = rf::flyCamera(v3(position), yaw_degrees, pitch_degrees, vfov_degrees, aperture, focus_distance, aspect_ratio);
+        std::memcpy(out, &c, sizeof c);
+        return RF_OK;
+    });
+}
+
+int rf_bvh_visualizer_camera(const void* root_node48, float aspect_ratio, rf_camera* out)
+{
+    return guarded([&] {
+        require(root_node48 && out, "null argument");
+        const rf::Camera c = rf::bvhVisualizerCamera(static_cast<const rf::BvhNode*>(root_node48)->aabb, aspect_ratio);
+        std::memcpy(out, &c, sizeof c);
+        return RF_OK;
+    });
+}
+
+int rf_sky_state_new(float elevation, float turbidity, const float albedo[3], float state33[33])
+{
+    if (!albedo || !state33) return -1;
+    return static_cast<int>(rf::skyStateNew(elevation, turbidity, albedo, state33));
+}
+
+float rf_sky_state_radiance(const float state33[33], float theta, float gamma, int channel)
+{
+    return rf::skyStateRadiance(state33, theta, gamma, channel);
+}
+
+int rf_aligned_sky_state(const rf_sky* sky, float out40[40])
+{
+    return guarded([&] {
+        require(sky && out40, "null argument");
+        rf::Sky s;
+        s.turbidity = sky->turbidity;
+        std::memcpy(s.albedo, sky->albedo, sizeof s.albedo);
+        s.sunZenithDegrees = sky->sun_zenith_degrees;
+        s.sunAzimuthDegrees = sky->sun_azimuth_degrees;
+        rf::SkyStateGpu g;
+        const rf::SkyResult rc = rf::alignedSkyState(s, g);
+        std::memcpy(out40, &g, sizeof g);
+        if (rc != rf::SkyResult::Success)
+        {
+            gLastError = "sky parameters out of range";
+            return static_cast<int>(RF_ERROR_OUT_OF_RANGE);
+        }
+        return static_cast<int>(RF_OK);
+    });
+}
+
+// ---------------------------------------------------------------------------------------- .pt files
+int rf_pt_format_from_gltf(const char* gltf_path, rf_pt_format** out)
+{
+    return guarded([&] {
+        require(gltf_path && out, "null argument");
+        auto h = std::make_unique<rf_pt_format>();
+        h->format = rf::ptFormatFromGltf(gltf_path);
+        *out = h.release();
+        return RF_OK;
+    });
+}
+
+int rf_pt_format_load(const char* pt_path, rf_pt_format** out)
+{
+    return guarded([&] {
+        require(pt_path && out, "null argument");
+        auto h = std::make_unique<rf_pt_format>();
+        h->format = rf::readPtFile(pt_path);
+        *out = h.release();
+        return RF_OK;
+    });
+}
+
+int rf_pt_format_deserialize(const void* data, uint64_t size, rf_pt_format** out)
+{
+    return guarded([&] {
+        require(data && out, "null argument");
+        auto h = std::make_unique<rf_pt_format>();
+        rf::deserializePt(static_cast<const uint8_t*>(data), static_cast<size_t>(size), h->format);
+        *out = h.release();
+        return RF_OK;
+    });
+}
+
+int rf_pt_format_save(const rf_pt_format* f, const char* pt_path)
+{
+    return guarded([&] {
+        require(f && pt_path, "null argument");
+        rf::writePtFile(pt_path, f->format);
+        return RF_OK;
+    });
+}
+
+int rf_pt_format_serialize(const rf_pt_format* f, void* dst, uint64_t* size)
+{
+    return guarded([&] {
+        require(f && size, "null argument");
+        const std::vector<uint8_t> bytes = rf::serializePt(f->format);
+        if (dst)
+        {
+            require(*size >= bytes.size(), "destination too small");
+            std::memcpy(dst, bytes.data(), bytes.size());
+        }
+        *size = bytes.size();
+        return RF_OK;
+    });
+}
+
+int rf_pt_format_from_triangles(const float* positions36, const float* normals36, const float* tex_coords24, const uint32_t* texture_indices,
+                                uint64_t num_triangles, const rf_texture* textures, uint64_t num_textures, rf_pt_format** out)
+{
+    return guarded([&] {
+        require(positions36 && normals36 && tex_coords24 && texture_indices && out, "null argument");
+        require(num_triangles > 0, "no triangles");
+        const size_t n = static_cast<size_t>(num_triangles);
+        std::vector<rf::Texture> tex;
+        for (uint64_t i = 0; i < num_textures; ++i)
+        {
+            rf::Texture t;
+            t.width = textures[i].width;
+            t.height = textures[i].height;
+            t.pixels.assign(textures[i].pixels, textures[i].pixels + static_cast<size_t>(t.width) * t.height);
+            tex.push_back(std::move(t));
+        }
+        auto h = std::make_unique<rf_pt_format>();
+        h->format = rf::ptFormatFromTriangles({reinterpret_cast<const rf::Positions*>(positions36), n},
+                                              {reinterpret_cast<const rf::Normals*>(normals36), n},
+                                              {reinterpret_cast<const rf::TexCoords*>(tex_coords24), n}, {texture_indices, n}, std::move(tex));
+        *out = h.release();
+        return RF_OK;
+    });
+}
+
+int rf_pt_format_view_get(const rf_pt_format* f, rf_pt_format_view* v)
+{
+    return guarded([&] {
+        require(f && v, "null argument");
+        const rf::PtFormat& p = f->format;
+        std::memset(v, 0, sizeof *v);
+        v->bvh_nodes = p.bvhNodes.data();
+        v->num_bvh_nodes = p.bvhNodes.size();
+        v->bvh_position_attributes = p.bvhPositionAttributes.data();
+        v->num_bvh_position_attributes = p.bvhPositionAttributes.size();
+        v->triangle_position_attributes = p.trianglePositionAttributes.data();
+        v->num_triangle_position_attributes = p.trianglePositionAttributes.size();
+        v->triangle_vertex_attributes = p.triangleVertexAttributes.data();
+        v->num_triangle_vertex_attributes = p.triangleVertexAttributes.size();
+        v->vertex_positions = reinterpret_cast<const float*>(p.vertexPositions.data());
+        v->num_vertex_positions = p.vertexPositions.size();
+        v->vertex_normals = reinterpret_cast<const float*>(p.vertexNormals.data());
+        v->num_vertex_normals = p.vertexNormals.size();
+        v->vertex_tex_coords = reinterpret_cast<const float*>(p.vertexTexCoords.data());
+        v->num_vertex_tex_coords = p.vertexTexCoords.size();
+        v->vertex_indices = p.vertexIndices.data();
+        v->num_vertex_indices = p.vertexIndices.size();
+        static_assert(sizeof(rf::Slice) == 16);
+        v->model_vertex_positions = reinterpret_cast<const uint64_t*>(p.modelVertexPositions.data());
+        v->num_model_vertex_positions = p.modelVertexPositions.size();
+        v->model_vertex_normals = reinterpret_cast<const uint64_t*>(p.modelVertexNormals.data());
+        v->num_model_vertex_normals = p.modelVertexNormals.size();
+        v->model_vertex_tex_coords = reinterpret_cast<const uint64_t*>(p.modelVertexTexCoords.data());
+        v->num_model_vertex_tex_coords = p.modelVertexTexCoords.size();
+        v->model_vertex_indices = reinterpret_cast<const uint64_t*>(p.modelVertexIndices.data());
+        v->num_model_vertex_indices = p.modelVertexIndices.size();
+        v->model_base_color_texture_indices = p.modelBaseColorTextureIndices.data();
+        v->num_model_base_color_texture_indices = p.modelBaseColorTextureIndices.size();
+        v->num_textures = p.baseColorTextures.size();
+        return RF_OK;
+    });
+}
+
+int rf_pt_format_texture(const rf_pt_format* f, uint64_t index, rf_texture* out)
+{
+    return guarded([&] {
+        require(f && out, "null argument");
+        require(index < f->format.baseColorTextures.size(), "texture index out of range");
+        const rf::Texture& t = f->format.baseColorTextures[static_cast<size_t>(index)];
+        out->pixels = t.pixels.data();
+        out->width = t.width;
+        out->height = t.height;
+        return RF_OK;
+    });
+}
+
+void rf_pt_format_destroy(rf_pt_format* f) { delete f; }
+
+int rf_pt_format_scene(const rf_pt_format* f, rf_scene* scene, rf_texture* textures)
+{
+    return guarded([&] {
+        require(f && scene, "null argument");
+        const rf::PtFormat& p = f->format;
+        require(textures || p.baseColorTextures.empty(), "null texture array");
+        require(p.trianglePositionAttributes.size() == p.triangleVertexAttributes.size(), "attribute arrays differ in length");
+        scene->bvh_nodes = p.bvhNodes.data();
+        scene->num_bvh_nodes = p.bvhNodes.size();
+        scene->position_attributes = p.trianglePositionAttributes.data();
+        scene->vertex_attributes = p.triangleVertexAttributes.data();
+        scene->num_triangles = p.trianglePositionAttributes.size();
+        for (size_t i = 0; i < p.baseColorTextures.size(); ++i)
+            textures[i] = rf_texture{p.baseColorTextures[i].pixels.data(), p.baseColorTextures[i].width, p.baseColorTextures[i].height};
+        scene->base_color_textures = textures;
+        scene->num_textures = p.baseColorTextures.size();
+        return RF_OK;
+    });
+}
+} // extern "C"

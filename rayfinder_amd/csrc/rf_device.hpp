@@ -1,0 +1,323 @@
+// rf_device.hpp -- device-side building blocks of the wavefront path tracer (gfx950).
+//
+// Behavioural reference (what must come out, not how): src/pt/reference_path_tracer.wgsl.
+//   slab test           wgsl:447-475  == src/common/ray_intersection.cpp:101-136
+//   Moller-Trumbore     wgsl:477-521  == ray_intersection.cpp:38-90
+//   offsetRay           wgsl:523-544  == ray_intersection.cpp:17-35
+//   closest-hit order   wgsl:370-429  == ray_intersection.cpp:138-213
+//   any-hit             wgsl:321-368
+//
+// HBM layout (chosen for the hardware, not the reference's):
+//   nodes      32 B each, two float4: {min.xyz, link} {max.xyz, meta}
+//              link = leaf ? trianglesOffset : secondChildOffset (the other one is always 0 in the
+//              reference's 48-B node, bvh.cpp:31-55); meta = triangleCount << 2 | axis (axis 3 =
+//              leaf).  32-B alignment means a node never straddles a 64-B line and one visit is
+//              two dwordx4 loads instead of three; results are bit-identical.
+//   triangles  48 B each, three float4 (the reference's PositionAttribute, unchanged).
+//   traversal stack: per-lane, first RF_LDS_STACK entries in LDS ([depth][lane], conflict free
+//              because lanes l and l+32 sit in different halves), overflow in scratch.
+#pragma once
+
+#include "rf_types.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace rf
+{
+constexpr int      kBlock = 256;          // 4 waves
+constexpr int      kLdsStack = 24;        // entries kept in LDS per lane
+constexpr int      kSpillStack = 72;      // further entries in scratch (total depth 96)
+constexpr uint32_t kMiss = 0xFFFFFFFFu;
+constexpr uint32_t kLeafAxis = 3u;
+
+struct DeviceScene
+{
+    const float4*            nodes;      // 2 per node
+    const float4*            triangles;  // 3 per triangle
+    const VertexAttributes*  attributes; // 80 B each
+    const TextureDescriptor* textureDescriptors;
+    const uint32_t*          texels;
+    uint64_t                 numTexels;
+    const uint8_t*           blueNoise; // 128*128*2
+    const float*             albedoLut; // 256 entries: pow(i/255, 2.2)
+};
+
+struct RayPrep
+{
+    Vec3     origin;
+    Vec3     direction;
+    Vec3     invDir;
+    uint32_t negX, negY, negZ;
+};
+
+__device__ __forceinline__ RayPrep prepareRay(Vec3 o, Vec3 d)
+{
+    RayPrep r;
+    r.origin = o;
+    r.direction = d;
+    r.invDir = vec3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.negX = r.invDir.x < 0.0f;
+    r.negY = r.invDir.y < 0.0f;
+    r.negZ = r.invDir.z < 0.0f;
+    return r;
+}
+
+__device__ __forceinline__ bool slabTest(const RayPrep& r, float4 lo, float4 hi, float rayTMax)
+{
+    float       tmin = ((r.negX ? hi.x : lo.x) - r.origin.x) * r.invDir.x;
+    float       tmax = ((r.negX ? lo.x : hi.x) - r.origin.x) * r.invDir.x;
+    const float tymin = ((r.negY ? hi.y : lo.y) - r.origin.y) * r.invDir.y;
+    const float tymax = ((r.negY ? lo.y : hi.y) - r.origin.y) * r.invDir.y;
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    tmin = maxf(tymin, tmin);
+    tmax = minf(tymax, tmax);
+    const float tzmin = ((r.negZ ? hi.z : lo.z) - r.origin.z) * r.invDir.z;
+    const float tzmax = ((r.negZ ? lo.z : hi.z) - r.origin.z) * r.invDir.z;
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    tmin = maxf(tzmin, tmin);
+    tmax = minf(tzmax, tmax);
+    return (tmin < rayTMax) && (tmax > 0.0f);
+}
+
+__device__ __forceinline__ Vec3 offsetRay(Vec3 p, Vec3 n)
+{
+    constexpr float kOrigin = 1.0f / 32.0f;
+    constexpr float kFloatScale = 1.0f / 65536.0f;
+    constexpr float kIntScale = 256.0f;
+    const int       ox = static_cast<int>(kIntScale * n.x);
+    const int       oy = static_cast<int>(kIntScale * n.y);
+    const int       oz = static_cast<int>(kIntScale * n.z);
+    const Vec3      shifted = vec3(__int_as_float(__float_as_int(p.x) + (p.x < 0 ? -ox : ox)),
+                                   __int_as_float(__float_as_int(p.y) + (p.y < 0 ? -oy : oy)),
+                                   __int_as_float(__float_as_int(p.z) + (p.z < 0 ? -oz : oz)));
+    return vec3(fabsf(p.x) < kOrigin ? p.x + kFloatScale * n.x : shifted.x,
+                fabsf(p.y) < kOrigin ? p.y + kFloatScale * n.y : shifted.y,
+                fabsf(p.z) < kOrigin ? p.z + kFloatScale * n.z : shifted.z);
+}
+
+struct TriangleHit
+{
+    float t, u, v;
+};
+
+// Returns true when the triangle is hit with 1e-5 < t < rayTMax.
+__device__ __forceinline__ bool
+intersectTriangle(const RayPrep& r, Vec3 p0, Vec3 p1, Vec3 p2, float rayTMax, TriangleHit& hit)
+{
+    constexpr float kEpsilon = 0.00001f;
+    const Vec3      e1 = p1 - p0;
+    const Vec3      e2 = p2 - p0;
+    const Vec3      h = cross(r.direction, e2);
+    const float     det = dot(e1, h);
+    if (det > -kEpsilon && det < kEpsilon) return false;
+    const float invDet = 1.0f / det;
+    const Vec3  s = r.origin - p0;
+    const float u = invDet * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const Vec3  q = cross(s, e1);
+    const float v = invDet * dot(r.direction, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = invDet * dot(e2, q);
+    if (t > kEpsilon && t < rayTMax)
+    {
+        hit.t = t;
+        hit.u = u;
+        hit.v = v;
+        return true;
+    }
+    return false;
+}
+
+struct ClosestHit
+{
+    uint32_t triangle; // kMiss when nothing was hit
+    float    t, u, v;
+    Vec3     p; // hit point already pushed off the surface (offsetRay)
+};
+
+struct TraversalCounters
+{
+    uint32_t nodesVisited = 0;
+    uint32_t triangleTests = 0;
+    uint32_t stackHigh = 0;
+};
+
+// Per-lane traversal stack: LDS first, scratch beyond.
+struct LaneStack
+{
+    uint32_t* lds; // &shared[0][threadIdx.x], stride kBlock
+    uint32_t  spill[kSpillStack];
+    int       size = 0;
+
+    // Returns false when the tree is deeper than kLdsStack + kSpillStack (the reference is
+    // undefined past 32 entries); the caller then abandons the ray.
+    __device__ __forceinline__ bool push(uint32_t v)
+    {
+        if (size < kLdsStack) lds[size * kBlock] = v;
+        else if (size - kLdsStack < kSpillStack) spill[size - kLdsStack] = v;
+        else return false;
+        ++size;
+        return true;
+    }
+    __device__ __forceinline__ uint32_t pop()
+    {
+        --size;
+        return size < kLdsStack ? lds[size * kBlock] : spill[size - kLdsStack];
+    }
+};
+
+// One ray, the reference's visit order.  ANY_HIT: return at the first accepted triangle
+// (shadowRay); otherwise keep the closest (rayIntersectBvh).  COUNT: maintain counters.
+template<bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, Vec3 direction, float rayTMax,
+                                         uint32_t* ldsStackLane, ClosestHit& out, TraversalCounters& counters)
+{
+    const RayPrep ray = prepareRay(origin, direction);
+    LaneStack     stack;
+    stack.lds = ldsStackLane;
+    uint32_t current = 0;
+    bool     found = false;
+    out.triangle = kMiss;
+
+    for (;;)
+    {
+        const float4 lo = scene.nodes[2 * current];
+        const float4 hi = scene.nodes[2 * current + 1];
+        if (COUNT) ++counters.nodesVisited;
+        bool advance = false; // true: `current` already holds the next node
+        if (slabTest(ray, lo, hi, rayTMax))
+        {
+            const uint32_t link = __float_as_uint(lo.w);
+            const uint32_t meta = __float_as_uint(hi.w);
+            const uint32_t axis = meta & 3u;
+            if (axis == kLeafAxis)
+            {
+                const uint32_t count = meta >> 2;
+                for (uint32_t i = 0; i < count; ++i)
+                {
+                    const uint32_t tri = link + i;
+                    const float4   a = scene.triangles[3 * tri];
+                    const float4   b = scene.triangles[3 * tri + 1];
+                    const float4   c = scene.triangles[3 * tri + 2];
+                    if (COUNT) ++counters.triangleTests;
+                    TriangleHit th;
+                    const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
+                    if (intersectTriangle(ray, p0, p1, p2, rayTMax, th))
+                    {
+                        if (ANY_HIT) return true;
+                        rayTMax = th.t;
+                        found = true;
+                        const Vec3 e1 = p1 - p0, e2 = p2 - p0;
+                        const Vec3 p = p0 + th.u * e1 + th.v * e2;
+                        const Vec3 n = normalize(cross(e1, e2));
+                        out.p = offsetRay(p, n);
+                        out.t = th.t;
+                        out.u = th.u;
+                        out.v = th.v;
+                        out.triangle = tri;
+                    }
+                }
+            }
+            else
+            {
+                const uint32_t neg = axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ);
+                const uint32_t deferred = neg ? current + 1 : link;
+                current = neg ? link : current + 1;
+                if (!stack.push(deferred)) break;
+                if (COUNT) counters.stackHigh = max(counters.stackHigh, static_cast<uint32_t>(stack.size));
+                advance = true;
+            }
+        }
+        if (!advance)
+        {
+            if (stack.size == 0) break;
+            current = stack.pop();
+        }
+    }
+    return found;
+}
+
+// ---------------------------------------------------------------------------------------------
+// WGSL builtins with implementation-defined precision: documented choice = correctly rounded f32,
+// obtained by evaluating in f64 and rounding once (DESIGN.md "Floating point policy").
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wSin(float x) { return static_cast<float>(sin(static_cast<double>(x))); }
+__device__ __forceinline__ float wCos(float x) { return static_cast<float>(cos(static_cast<double>(x))); }
+__device__ __forceinline__ float wAcos(float x) { return static_cast<float>(acos(static_cast<double>(x))); }
+__device__ __forceinline__ float wExp(float x) { return static_cast<float>(exp(static_cast<double>(x))); }
+__device__ __forceinline__ float wPow(float x, float y)
+{
+    return static_cast<float>(pow(static_cast<double>(x), static_cast<double>(y)));
+}
+__device__ __forceinline__ float wFract(float x) { return x - floorf(x); }
+
+constexpr float kPi = 3.1415927f;       // wgsl:68
+constexpr float kFrac1Pi = 0.31830987f; // wgsl:69
+constexpr float kTMax = 10000.0f;       // wgsl:73
+// wgsl:79-83 evaluated in f32: cos(0.255 deg) and 2*pi*(1-cos); 1 ulp of the cosine is 0.6 % of
+// the direct light, so the bit patterns are fixed here.
+constexpr uint32_t kSolarCosThetaMaxBits = 0x3F7FFF5Au;
+constexpr uint32_t kSolarInvPdfBits = 0x38826048u;
+
+// Duff et al. orthonormal basis, wgsl:309-319.  Returns columns u, v (third column is n).
+__device__ __forceinline__ void pixarOnb(Vec3 n, Vec3& u, Vec3& v)
+{
+    const float s = (n.z >= 0.0f) ? 1.0f : -1.0f;
+    const float a = -1.0f / (s + n.z);
+    const float b = n.x * n.y * a;
+    u = vec3(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
+    v = vec3(b, s + n.y * n.y * a, -n.y);
+}
+
+__device__ __forceinline__ Vec3 basisTimes(Vec3 c0, Vec3 c1, Vec3 c2, Vec3 v)
+{
+    return (v.x * c0 + v.y * c1) + v.z * c2;
+}
+
+// wgsl:247-275 (sky dome only; the solar disk is reached through next-event estimation)
+__device__ __forceinline__ float skyRadiance(const SkyStateGpu& sky, float theta, float gamma, int channel)
+{
+    const float  r = sky.skyRadiances[channel];
+    const float* p = sky.params + 9 * channel;
+    const float  cosGamma = wCos(gamma);
+    const float  cosGamma2 = cosGamma * cosGamma;
+    const float  cosTheta = fabsf(wCos(theta));
+    const float  expM = wExp(p[4] * gamma);
+    const float  mieLhs = 1.0f + cosGamma2;
+    const float  mieRhs = wPow(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma, 1.5f);
+    const float  mie = mieLhs / mieRhs;
+    const float  zenith = rf_sqrt(cosTheta);
+    const float  lhs = 1.0f + p[0] * wExp(p[1] / (cosTheta + 0.01f));
+    const float  rhs = p[2] + p[3] * expM + p[5] * cosGamma2 + p[6] * mie + p[7] * zenith;
+    return r * (lhs * rhs);
+}
+
+// wgsl:303-307,552-565.  An index past the end of the texel array (fract()*w rounding up on the
+// last row of the last texture) is clamped into the array, as WGSL robust buffer access does.
+__device__ __forceinline__ Vec3 evalTexture(const DeviceScene& scene, uint32_t descriptorIdx, float uvx, float uvy)
+{
+    const TextureDescriptor d = scene.textureDescriptors[descriptorIdx];
+    const float             u = wFract(uvx);
+    const float             v = wFract(uvy);
+    const uint32_t          j = static_cast<uint32_t>(u * static_cast<float>(d.width));
+    const uint32_t          i = static_cast<uint32_t>(v * static_cast<float>(d.height));
+    uint64_t                idx = static_cast<uint64_t>(d.offset) + static_cast<uint64_t>(i * d.width + j);
+    if (idx >= scene.numTexels) idx = scene.numTexels - 1;
+    const uint32_t bgra = scene.texels[idx];
+    return vec3(scene.albedoLut[(bgra >> 16) & 0xffu], scene.albedoLut[(bgra >> 8) & 0xffu], scene.albedoLut[bgra & 0xffu]);
+}
+
+// wgsl:602-616; table texel = u8 / 255.0f (reference_path_tracer.cpp:174-178)
+__device__ __forceinline__ void animatedBlueNoise(const uint8_t* table, uint32_t x, uint32_t y, uint32_t frameIdx,
+                                                  uint32_t totalSampleCount, float& nx, float& ny)
+{
+    const uint32_t idx = (y % 128u) * 128u + (x % 128u);
+    const float    bx = static_cast<float>(table[2 * idx]) / 255.0f;
+    const float    by = static_cast<float>(table[2 * idx + 1]) / 255.0f;
+    const uint32_t n = frameIdx % totalSampleCount;
+    const float    a1 = 0.7548776662466927f;
+    const float    a2 = 0.5698402909980532f;
+    nx = wFract(bx + wFract(a1 * static_cast<float>(n)));
+    ny = wFract(by + wFract(a2 * static_cast<float>(n)));
+}
+} // namespace rf

@@ -1,0 +1,1050 @@
+// rf_renderer.hip -- wavefront path tracer for MI355X (gfx950): kernels + host driver.
+//
+// The reference traces one full path per fragment-shader invocation
+// (src/pt/reference_path_tracer.wgsl:34-64,180-234).  Here the same per-path arithmetic is cut
+// into a wavefront pipeline so that every stage runs with full, coherent waves:
+//
+//   raygen            wgsl:42-54,236-245,594-616   S samples x all pixels of this rank's tiles
+//   for bounce = 1..numBounces
+//     traceClosest    wgsl:370-521                 queue of live paths -> hit record, origin <- p
+//     shade           wgsl:189-228,247-319,546-592 miss: += throughput*sky, path ends
+//                                                  hit : albedo, pending NEE term, next direction,
+//                                                        throughput *= albedo; ballot-compacted queue
+//     traceShadow     wgsl:321-368                 radiance += pending * visibility * invPdf
+//   accumulate        wgsl:47-57                   image += radiance, samples in index order (f32)
+//
+// Path state lives in HBM as six float4 streams indexed by path slot (slot = sample*pixels +
+// pixel, fixed for the life of the path); queues hold slot ids.  Because the reference reuses ONE
+// blue-noise pair for lens, sun cone and every bounce (wgsl:52-55,194,209), cos/sin of 2*pi*u.y
+// are evaluated once per path in raygen and carried in the .w lanes.
+//
+// Kernel grids are sized for the worst case (all paths alive) and read the live count from
+// device memory, so a whole batch is enqueued without any host round trip.
+#include "rf_renderer.hpp"
+
+#include "rf_camera.hpp"
+#include "rf_data.hpp"
+#include "rf_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace rf
+{
+bool operator==(const RenderParameters& a, const RenderParameters& b)
+{
+    return a.width == b.width && a.height == b.height && std::memcmp(&a.camera, &b.camera, sizeof(Camera)) == 0 &&
+           a.samplingParams == b.samplingParams && a.sky == b.sky && a.exposure == b.exposure;
+}
+
+namespace
+{
+#define RF_HIP(expr)                                                                                          \
+    do                                                                                                        \
+    {                                                                                                         \
+        const hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                                 \
+            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " in " #expr);      \
+    } while (0)
+
+struct PathStreams
+{
+    float4* rayO;    // origin.xyz (hit point after traceClosest), w = noise.x
+    float4* rayD;    // direction.xyz, w = cos(2 pi noise.y)
+    float4* thr;     // throughput.rgb, w = sin(2 pi noise.y)
+    float4* rad;     // radiance.rgb
+    float4* hit;     // {triangle bits, u, v, -}
+    float4* pending; // (throughput * solar radiance) * reflectance, waiting for visibility
+};
+
+struct DeviceCounters
+{
+    unsigned long long primaryRays, closestRays, shadowRays;
+    unsigned long long closestNodeVisits, closestTriangleTests, shadowNodeVisits, shadowTriangleTests;
+    unsigned int       stackHigh;
+    unsigned int       pad;
+};
+
+struct FrameParams
+{
+    uint32_t width, height;
+    Camera   camera;
+    uint32_t samplesPerPixel, numBounces;
+    uint32_t firstFrame; // frameCount of sample 0 of this batch
+    uint32_t numSamples; // samples traced in this batch
+    uint32_t numTiles;
+    uint32_t pixelsPadded; // numTiles * 1024
+    uint32_t tilesX;
+};
+
+// local pixel index (tile-major, 8x8 pixel blocks = one wave) -> image coordinates
+__device__ __forceinline__ bool localPixelToXY(const FrameParams& fp, const uint32_t* tileIds, uint32_t lp, uint32_t& x, uint32_t& y)
+{
+    const uint32_t tile = tileIds[lp >> 10];
+    const uint32_t w = lp & 1023u;
+    const uint32_t block = w >> 6, lane = w & 63u;
+    x = (tile % fp.tilesX) * kTileSize + (block & 3u) * 8u + (lane & 7u);
+    y = (tile / fp.tilesX) * kTileSize + (block >> 2) * 8u + (lane >> 3);
+    return x < fp.width && y < fp.height;
+}
+
+// Append `slot` to `queue` for every lane with `keep`: one atomic per wave.
+__device__ __forceinline__ void waveAppend(bool keep, uint32_t slot, uint32_t* queue, uint32_t* count)
+{
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    const int      leader = __ffsll(static_cast<long long>(mask)) - 1;
+    uint32_t       base = 0;
+    if (static_cast<int>(lane) == leader) base = atomicAdd(count, static_cast<uint32_t>(__popcll(mask)));
+    base = __shfl(base, leader);
+    if (keep) queue[base + prefix] = slot;
+}
+
+__device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+__device__ __forceinline__ uint32_t waveMax(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, static_cast<uint32_t>(__shfl_down(v, off)));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene scene, const uint32_t* tileIds, PathStreams ps,
+                                                   uint32_t* queue, uint32_t* queueCount, DeviceCounters* counters)
+{
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t total = fp.numSamples * fp.pixelsPadded;
+    bool           valid = slot < total;
+    uint32_t       x = 0, y = 0;
+    if (valid)
+    {
+        const uint32_t lp = slot % fp.pixelsPadded;
+        valid = localPixelToXY(fp, tileIds, lp, x, y);
+    }
+    if (valid)
+    {
+        const uint32_t k = slot / fp.pixelsPadded;
+        const uint32_t frame = fp.firstFrame + k;
+        float          nx, ny;
+        animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
+
+        // fragment centre (wgsl:36-43); v runs down the image
+        const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(fp.width);
+        const float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(fp.height);
+        const float s = u + nx / static_cast<float>(fp.width);
+        const float t = (1.0f - v) + ny / static_cast<float>(fp.height);
+
+        const float phi = 2.0f * kPi * ny;
+        const float cosPhi = wCos(phi), sinPhi = wSin(phi);
+        const float r = rf_sqrt(nx);
+        const float lensX = fp.camera.lensRadius * (r * cosPhi);
+        const float lensY = fp.camera.lensRadius * (r * sinPhi);
+        const Vec3  origin = fp.camera.origin + (lensX * fp.camera.right + lensY * fp.camera.up);
+        const Vec3  dir = normalize(fp.camera.lowerLeftCorner + s * fp.camera.horizontal + t * fp.camera.vertical - origin);
+
+        ps.rayO[slot] = make_float4(origin.x, origin.y, origin.z, nx);
+        ps.rayD[slot] = make_float4(dir.x, dir.y, dir.z, cosPhi);
+        ps.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, sinPhi);
+        ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    waveAppend(valid, slot, queue, queueCount);
+    const unsigned long long n = waveSum(valid ? 1ull : 0ull);
+    if (__lane_id() == 0 && n) atomicAdd(&counters->primaryRays, n);
+}
+
+template<bool COUNT>
+__global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathStreams ps, const uint32_t* queue,
+                                                         const uint32_t* queueCount, DeviceCounters* counters)
+{
+    __shared__ uint32_t sStack[kLdsStack * kBlock];
+    const uint32_t      i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t      count = *queueCount;
+    if (blockIdx.x * kBlock >= count) return;
+    TraversalCounters tc;
+    if (i < count)
+    {
+        const uint32_t slot = queue[i];
+        const float4   o = ps.rayO[slot];
+        const float4   d = ps.rayD[slot];
+        ClosestHit     h;
+        traverse<false, COUNT>(scene, vec3(o.x, o.y, o.z), vec3(d.x, d.y, d.z), kTMax, &sStack[threadIdx.x], h, tc);
+        ps.hit[slot] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f);
+        if (h.triangle != kMiss) ps.rayO[slot] = make_float4(h.p.x, h.p.y, h.p.z, o.w);
+    }
+    if (COUNT)
+    {
+        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
+        const uint32_t           sh = waveMax(tc.stackHigh);
+        if (__lane_id() == 0)
+        {
+            atomicAdd(&counters->closestNodeVisits, nv);
+            atomicAdd(&counters->closestTriangleTests, tt);
+            atomicMax(&counters->stackHigh, sh);
+        }
+    }
+    if (i == 0) atomicAdd(&counters->closestRays, static_cast<unsigned long long>(count));
+}
+
+// Sun direction sample for this path (wgsl:194,287-292,568-579): cone about sunDirection.
+__device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, float nx, float cosPhi, float sinPhi)
+{
+    const float cosThetaMax = __uint_as_float(kSolarCosThetaMaxBits);
+    const float cosTheta = 1.0f - nx * (1.0f - cosThetaMax);
+    const float sinTheta = rf_sqrt(1.0f - cosTheta * cosTheta);
+    const Vec3  local = vec3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+    const Vec3  sun = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
+    Vec3        bu, bv;
+    pixarOnb(sun, bu, bv);
+    return basisTimes(bu, bv, sun, local);
+}
+
+__global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
+                                                  const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t isLastBounce)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t count = *queueCount;
+    if (blockIdx.x * kBlock >= count) return;
+    bool     isHit = false;
+    uint32_t slot = 0;
+    if (i < count)
+    {
+        slot = queue[i];
+        const float4   h = ps.hit[slot];
+        const uint32_t tri = __float_as_uint(h.x);
+        const float4   thr4 = ps.thr[slot];
+        const float4   d4 = ps.rayD[slot];
+        const Vec3     throughput = vec3(thr4.x, thr4.y, thr4.z);
+        if (tri == kMiss)
+        {
+            // wgsl:212-228
+            const Vec3  v = vec3(d4.x, d4.y, d4.z);
+            const Vec3  s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
+            const float theta = wAcos(v.y);
+            const float gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
+            const Vec3  dome = vec3(skyRadiance(sky, theta, gamma, 0), skyRadiance(sky, theta, gamma, 1), skyRadiance(sky, theta, gamma, 2));
+            float4      rad4 = ps.rad[slot];
+            const Vec3  radiance = vec3(rad4.x, rad4.y, rad4.z) + throughput * dome;
+            ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        }
+        else
+        {
+            isHit = true;
+            const float             nx = ps.rayO[slot].w;
+            const float             cosPhi = d4.w, sinPhi = thr4.w;
+            const VertexAttributes& va = scene.attributes[tri];
+            const float             b0 = 1.0f - h.y - h.z, b1 = h.y, b2 = h.z; // wgsl:515
+            const Vec3              n = (b0 * va.n0 + b1 * va.n1) + b2 * va.n2; // not normalised, wgsl:396
+            const float             uvx = (b0 * va.uv0.x + b1 * va.uv1.x) + b2 * va.uv2.x;
+            const float             uvy = (b0 * va.uv0.y + b1 * va.uv1.y) + b2 * va.uv2.y;
+            const Vec3              albedo = evalTexture(scene, va.textureIdx, uvx, uvy);
+
+            // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
+            const Vec3 lightDirection = sunSample(sky, nx, cosPhi, sinPhi);
+            const Vec3 lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
+            const Vec3 brdf = albedo * kFrac1Pi;
+            const Vec3 reflectance = brdf * dot(n, lightDirection);
+            const Vec3 pend = (throughput * lightIntensity) * reflectance;
+            ps.pending[slot] = make_float4(pend.x, pend.y, pend.z, 0.0f);
+
+            if (!isLastBounce)
+            {
+                // cosine-weighted bounce about the interpolated normal, wgsl:209-211,294-301,582-592
+                const float sinTheta = rf_sqrt(1.0f - nx);
+                const Vec3  local = vec3(cosPhi * sinTheta, sinPhi * sinTheta, rf_sqrt(nx));
+                Vec3        bu, bv;
+                pixarOnb(n, bu, bv);
+                const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
+                const Vec3 t2 = throughput * albedo;
+                ps.rayD[slot] = make_float4(wi.x, wi.y, wi.z, cosPhi);
+                ps.thr[slot] = make_float4(t2.x, t2.y, t2.z, sinPhi);
+            }
+        }
+    }
+    waveAppend(isHit, slot, hitQueue, hitCount);
+}
+
+template<bool COUNT>
+__global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
+                                                        const uint32_t* queueCount, DeviceCounters* counters)
+{
+    __shared__ uint32_t sStack[kLdsStack * kBlock];
+    const uint32_t      i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t      count = *queueCount;
+    if (blockIdx.x * kBlock >= count) return;
+    TraversalCounters tc;
+    if (i < count)
+    {
+        const uint32_t slot = queue[i];
+        const float4   o = ps.rayO[slot];
+        const float    cosPhi = ps.rayD[slot].w, sinPhi = ps.thr[slot].w;
+        const Vec3     l = sunSample(sky, o.w, cosPhi, sinPhi);
+        ClosestHit     h;
+        const bool     occluded = traverse<true, COUNT>(scene, vec3(o.x, o.y, o.z), l, kTMax, &sStack[threadIdx.x], h, tc);
+        const float    visibility = occluded ? 0.0f : 1.0f;
+        const float4   pend = ps.pending[slot];
+        const float4   rad4 = ps.rad[slot];
+        // wgsl:203  radiance += ((throughput*L)*reflectance) * visibility * SOLAR_INV_PDF
+        const Vec3 add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
+        const Vec3 radiance = vec3(rad4.x, rad4.y, rad4.z) + add;
+        ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    }
+    if (COUNT)
+    {
+        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
+        if (__lane_id() == 0)
+        {
+            atomicAdd(&counters->shadowNodeVisits, nv);
+            atomicAdd(&counters->shadowTriangleTests, tt);
+        }
+    }
+    if (i == 0) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
+}
+
+// image[lp] += radiance of samples 0..numSamples-1 in order (f32, wgsl:55); image is the compact
+// tile-major float4 buffer.
+__global__ __launch_bounds__(kBlock) void kAccumulate(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image)
+{
+    const uint32_t lp = blockIdx.x * kBlock + threadIdx.x;
+    if (lp >= fp.pixelsPadded) return;
+    uint32_t x, y;
+    if (!localPixelToXY(fp, tileIds, lp, x, y)) return;
+    float4 acc = image[lp];
+    for (uint32_t k = 0; k < fp.numSamples; ++k)
+    {
+        const float4 r = ps.rad[static_cast<size_t>(k) * fp.pixelsPadded + lp];
+        acc.x += r.x;
+        acc.y += r.y;
+        acc.z += r.z;
+    }
+    image[lp] = acc;
+}
+
+// wgsl:59-63,277-285 -> BGRA8Unorm texel
+__global__ void kTonemap(const float4* image, uint32_t n, uint32_t accumulatedSamples, float exposure, uint32_t* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 px = image[i];
+    const float  in[3] = {px.x, px.y, px.z};
+    uint32_t     q[3];
+    for (int c = 0; c < 3; ++c)
+    {
+        const float est = in[c] / static_cast<float>(accumulatedSamples);
+        const float x = exposure * est;
+        const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
+        float       y = (x * (a * x + b)) / (x * (cc * x + d) + e);
+        y = minf(maxf(y, 0.0f), 1.0f);
+        const float srgb = wPow(y, 1.0f / 2.2f);
+        q[c] = static_cast<uint32_t>(floorf(srgb * 255.0f + 0.5f));
+    }
+    out[i] = q[2] | (q[1] << 8) | (q[0] << 16) | (255u << 24);
+}
+
+// bvh-visualizer pass (src/bvh-visualizer/main.cpp:60-78): pinhole camera.cpp:44-52 rays.
+__global__ __launch_bounds__(kBlock) void kPrimaryStats(DeviceScene scene, Camera cam, uint32_t width, uint32_t height,
+                                                         uint32_t* nodesVisited, uint8_t* hitOut, float* tOut, uint32_t* triTests)
+{
+    __shared__ uint32_t sStack[kLdsStack * kBlock];
+    // 8x8 pixel blocks per wave for coherence; output is row-major
+    const uint32_t blocksX = (width + 7u) / 8u;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t j = (wave % blocksX) * 8u + (lane & 7u);
+    const uint32_t i = (wave / blocksX) * 8u + (lane >> 3);
+    if (j >= width || i >= height) return;
+    const float u = static_cast<float>(j) / static_cast<float>(width);
+    const float v = 1.0f - static_cast<float>(i + 1) / static_cast<float>(height);
+    const Vec3  dir = normalize(cam.lowerLeftCorner + cam.horizontal * u + cam.vertical * v - cam.origin);
+    ClosestHit        h;
+    TraversalCounters tc;
+    const bool        found = traverse<false, true>(scene, cam.origin, dir, FLT_MAX, &sStack[threadIdx.x], h, tc);
+    const size_t      k = static_cast<size_t>(i) * width + j;
+    nodesVisited[k] = tc.nodesVisited;
+    if (hitOut) hitOut[k] = found ? 1 : 0;
+    if (tOut) tOut[k] = found ? h.t : 0.0f;
+    if (triTests) triTests[k] = tc.triangleTests;
+}
+
+__global__ __launch_bounds__(kBlock) void kIntersectRays(DeviceScene scene, const float* rays, uint64_t n, float tMax, uint32_t* triOut,
+                                                          float* tOut, float* uvOut, float* pOut, uint32_t* nvOut, uint32_t* ttOut)
+{
+    __shared__ uint32_t sStack[kLdsStack * kBlock];
+    const uint64_t      i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float*      r = rays + 6 * i;
+    ClosestHit        h;
+    TraversalCounters tc;
+    const bool        found = traverse<false, true>(scene, vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), tMax, &sStack[threadIdx.x], h, tc);
+    triOut[i] = h.triangle;
+    if (tOut) tOut[i] = found ? h.t : 0.0f;
+    if (uvOut)
+    {
+        uvOut[2 * i] = found ? h.u : 0.0f;
+        uvOut[2 * i + 1] = found ? h.v : 0.0f;
+    }
+    if (pOut)
+    {
+        pOut[3 * i] = found ? h.p.x : 0.0f;
+        pOut[3 * i + 1] = found ? h.p.y : 0.0f;
+        pOut[3 * i + 2] = found ? h.p.z : 0.0f;
+    }
+    if (nvOut) nvOut[i] = tc.nodesVisited;
+    if (ttOut) ttOut[i] = tc.triangleTests;
+}
+
+__global__ __launch_bounds__(kBlock) void kOccludedRays(DeviceScene scene, const float* rays, uint64_t n, float tMax, float* visOut)
+{
+    __shared__ uint32_t sStack[kLdsStack * kBlock];
+    const uint64_t      i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float*      r = rays + 6 * i;
+    ClosestHit        h;
+    TraversalCounters tc;
+    const bool        occluded = traverse<true, false>(scene, vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), tMax, &sStack[threadIdx.x], h, tc);
+    visOut[i] = occluded ? 0.0f : 1.0f;
+}
+
+template<typename T>
+struct DeviceBuffer
+{
+    T*     ptr = nullptr;
+    size_t count = 0;
+    void   alloc(size_t n)
+    {
+        release();
+        count = n;
+        if (n) RF_HIP(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+    }
+    void upload(const T* src, size_t n)
+    {
+        alloc(n);
+        if (n) RF_HIP(hipMemcpy(ptr, src, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+    ~DeviceBuffer() { release(); }
+};
+
+uint32_t scramble(uint32_t v)
+{
+    v ^= v >> 16;
+    v *= 0x7feb352du;
+    v ^= v >> 15;
+    v *= 0x846ca68bu;
+    v ^= v >> 16;
+    return v;
+}
+} // namespace
+
+std::vector<uint32_t> tilesForRank(uint32_t width, uint32_t height, uint32_t rank, uint32_t worldSize)
+{
+    const uint32_t tilesX = (width + kTileSize - 1) / kTileSize, tilesY = (height + kTileSize - 1) / kTileSize;
+    const uint32_t n = tilesX * tilesY;
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    if (worldSize > 1)
+    {
+        // scrambled order dealt round-robin: neighbouring tiles (similar cost: sky vs interior)
+        // land on different ranks, and every rank gets n/world +-1 tiles
+        std::stable_sort(order.begin(), order.end(), [](uint32_t a, uint32_t b) { return scramble(a) < scramble(b); });
+    }
+    std::vector<uint32_t> mine;
+    for (uint32_t i = rank; i < n; i += worldSize) mine.push_back(order[i]);
+    std::sort(mine.begin(), mine.end());
+    return mine;
+}
+
+void untileHost(const float* compact, const uint32_t* tileIds, uint32_t numTiles, uint32_t width, uint32_t height, float* image)
+{
+    const uint32_t tilesX = (width + kTileSize - 1) / kTileSize;
+    for (uint32_t t = 0; t < numTiles; ++t)
+    {
+        const uint32_t tx = tileIds[t] % tilesX, ty = tileIds[t] / tilesX;
+        for (uint32_t w = 0; w < kTileSize * kTileSize; ++w)
+        {
+            const uint32_t block = w >> 6, lane = w & 63u;
+            const uint32_t x = tx * kTileSize + (block & 3u) * 8u + (lane & 7u);
+            const uint32_t y = ty * kTileSize + (block >> 2) * 8u + (lane >> 3);
+            if (x >= width || y >= height) continue;
+            std::memcpy(image + 4 * (static_cast<size_t>(y) * width + x), compact + 4 * (static_cast<size_t>(t) * 1024 + w), 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Renderer::Impl
+{
+    int         device = 0;
+    hipStream_t stream = nullptr;
+
+    DeviceBuffer<float4>            nodes, triangles;
+    DeviceBuffer<VertexAttributes>  attributes;
+    DeviceBuffer<TextureDescriptor> textureDescriptors;
+    DeviceBuffer<uint32_t>          texels;
+    DeviceBuffer<uint8_t>           blueNoise;
+    DeviceBuffer<float>             albedoLut;
+    DeviceScene                     scene{};
+
+    RenderParameters params;
+    SkyStateGpu      sky{};
+    uint32_t         maxWidth = 0, maxHeight = 0;
+    uint32_t         frameCount = 0, accumulated = 0;
+    uint32_t         rank = 0, worldSize = 1;
+
+    std::vector<uint32_t>   tiles;
+    DeviceBuffer<uint32_t>  tileIds;
+    DeviceBuffer<float4>    ownedImage;
+    float4*                 image = nullptr; // compact tile-major accumulation buffer
+    uint64_t                imageBytes = 0;
+    bool                    imageDirty = true; // needs zeroing before the next sample
+
+    uint64_t                maxPaths = 0;
+    DeviceBuffer<float4>    sRayO, sRayD, sThr, sRad, sHit, sPending;
+    DeviceBuffer<uint32_t>  queueA, queueB, queueCounts;
+    DeviceBuffer<DeviceCounters> counters;
+
+    bool counting = false, timing = false;
+    RenderStats hostStats;
+
+    struct TimedLaunch
+    {
+        hipEvent_t start, stop;
+        int        kind;
+    };
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t>  eventPool;
+
+    struct BatchTiming
+    {
+        hipEvent_t start, stop;
+        uint32_t   samples;
+    };
+    std::vector<BatchTiming> pendingBatches;
+    std::deque<float>        passDurationsMs;
+
+    hipEvent_t getEvent()
+    {
+        if (!eventPool.empty())
+        {
+            hipEvent_t e = eventPool.back();
+            eventPool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        RF_HIP(hipEventCreate(&e));
+        return e;
+    }
+
+    void allocatePathState(uint64_t paths)
+    {
+        maxPaths = paths;
+        sRayO.alloc(paths);
+        sRayD.alloc(paths);
+        sThr.alloc(paths);
+        sRad.alloc(paths);
+        sHit.alloc(paths);
+        sPending.alloc(paths);
+        queueA.alloc(paths);
+        queueB.alloc(paths);
+    }
+
+    void configureShard()
+    {
+        tiles = tilesForRank(params.width, params.height, rank, worldSize);
+        tileIds.upload(tiles.data(), tiles.size());
+        const uint64_t pixelsPadded = static_cast<uint64_t>(tiles.size()) * 1024;
+        if (image == nullptr || image == ownedImage.ptr)
+        {
+            ownedImage.alloc(std::max<uint64_t>(pixelsPadded, 1));
+            image = ownedImage.ptr;
+        }
+        else if (imageBytes < pixelsPadded * sizeof(float4))
+        {
+            throw std::runtime_error("bound accumulation buffer is too small for this shard");
+        }
+        if (image == ownedImage.ptr) imageBytes = pixelsPadded * sizeof(float4);
+        accumulated = 0;
+        imageDirty = true;
+    }
+
+    template<typename F>
+    void launchTimed(int kind, F&& launch)
+    {
+        if (timing)
+        {
+            TimedLaunch t{getEvent(), getEvent(), kind};
+            RF_HIP(hipEventRecord(t.start, stream));
+            launch();
+            RF_HIP(hipEventRecord(t.stop, stream));
+            timed.push_back(t);
+        }
+        else
+        {
+            launch();
+        }
+    }
+
+    void collectTimings()
+    {
+        if (timed.empty()) return;
+        RF_HIP(hipStreamSynchronize(stream));
+        for (const TimedLaunch& t : timed)
+        {
+            float ms = 0.0f;
+            RF_HIP(hipEventElapsedTime(&ms, t.start, t.stop));
+            switch (t.kind)
+            {
+            case 0: hostStats.msRaygen += ms; hostStats.launchesRaygen++; break;
+            case 1: hostStats.msClosest += ms; hostStats.launchesClosest++; break;
+            case 2: hostStats.msShade += ms; hostStats.launchesShade++; break;
+            case 3: hostStats.msShadow += ms; hostStats.launchesShadow++; break;
+            default: hostStats.msAccumulate += ms; hostStats.launchesAccumulate++; break;
+            }
+            eventPool.push_back(t.start);
+            eventPool.push_back(t.stop);
+        }
+        timed.clear();
+    }
+
+    void collectBatchTimings()
+    {
+        for (const BatchTiming& b : pendingBatches)
+        {
+            RF_HIP(hipEventSynchronize(b.stop));
+            float ms = 0.0f;
+            RF_HIP(hipEventElapsedTime(&ms, b.start, b.stop));
+            for (uint32_t i = 0; i < b.samples; ++i)
+            {
+                passDurationsMs.push_back(ms / static_cast<float>(b.samples));
+                if (passDurationsMs.size() > 30) passDurationsMs.pop_front();
+            }
+            eventPool.push_back(b.start);
+            eventPool.push_back(b.stop);
+        }
+        pendingBatches.clear();
+    }
+
+    // Trace `numSamples` consecutive samples (sample indices start at frame `firstFrame`).
+    void traceBatch(uint32_t firstFrame, uint32_t numSamples)
+    {
+        FrameParams fp{};
+        fp.width = params.width;
+        fp.height = params.height;
+        fp.camera = params.camera;
+        fp.samplesPerPixel = params.samplingParams.numSamplesPerPixel;
+        fp.numBounces = params.samplingParams.numBounces;
+        fp.firstFrame = firstFrame;
+        fp.numSamples = numSamples;
+        fp.numTiles = static_cast<uint32_t>(tiles.size());
+        fp.pixelsPadded = fp.numTiles * 1024u;
+        fp.tilesX = (params.width + kTileSize - 1) / kTileSize;
+        if (fp.numTiles == 0) return;
+
+        const uint64_t paths = static_cast<uint64_t>(numSamples) * fp.pixelsPadded;
+        const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
+        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr};
+        const uint32_t numBounces = fp.numBounces;
+
+        BatchTiming bt{getEvent(), getEvent(), numSamples};
+        RF_HIP(hipEventRecord(bt.start, stream));
+
+        if (queueCounts.count < numBounces + 2) queueCounts.alloc(numBounces + 2);
+        RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
+
+        uint32_t* qIn = queueA.ptr;
+        uint32_t* qOut = queueB.ptr;
+        launchTimed(0, [&] {
+            hipLaunchKernelGGL(kRaygen, dim3(blocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
+        });
+        for (uint32_t bounce = 1; bounce <= numBounces; ++bounce)
+        {
+            uint32_t* countIn = queueCounts.ptr + (bounce - 1);
+            uint32_t* countOut = queueCounts.ptr + bounce;
+            launchTimed(1, [&] {
+                if (counting)
+                    hipLaunchKernelGGL(kTraceClosest<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+                else
+                    hipLaunchKernelGGL(kTraceClosest<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+            });
+            launchTimed(2, [&] {
+                hipLaunchKernelGGL(kShade, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, qOut, countOut,
+                                   bounce == numBounces ? 1u : 0u);
+            });
+            launchTimed(3, [&] {
+                if (counting)
+                    hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                else
+                    hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+            });
+            std::swap(qIn, qOut);
+        }
+        launchTimed(4, [&] {
+            hipLaunchKernelGGL(kAccumulate, dim3((fp.pixelsPadded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, fp, tileIds.ptr, ps, image);
+        });
+        RF_HIP(hipGetLastError());
+        RF_HIP(hipEventRecord(bt.stop, stream));
+        pendingBatches.push_back(bt);
+        if (timing) collectTimings();
+        if (pendingBatches.size() > 64) collectBatchTimings();
+    }
+};
+
+Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) : mImpl(std::make_unique<Impl>())
+{
+    Impl& m = *mImpl;
+    int   deviceCount = 0;
+    if (hipGetDeviceCount(&deviceCount) != hipSuccess || deviceCount == 0)
+        throw std::runtime_error("rayfinder_amd: no HIP device available (this library has no CPU fallback)");
+    m.device = desc.deviceOrdinal;
+    RF_HIP(hipSetDevice(m.device));
+    RF_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+
+    if (sceneView.bvhNodes.empty()) throw std::runtime_error("scene has no BVH nodes");
+    if (sceneView.positionAttributes.size() != sceneView.vertexAttributes.size())
+        throw std::runtime_error("position and vertex attribute counts differ");
+
+    // 48-B reference nodes -> 32-B device nodes
+    {
+        std::vector<float4> packed(2 * sceneView.bvhNodes.size());
+        for (size_t i = 0; i < sceneView.bvhNodes.size(); ++i)
+        {
+            const BvhNode& n = sceneView.bvhNodes[i];
+            const bool     leaf = n.triangleCount > 0;
+            if (n.triangleCount >= (1u << 30)) throw std::runtime_error("BVH leaf too large");
+            const uint32_t link = leaf ? n.trianglesOffset : n.secondChildOffset;
+            const uint32_t meta = leaf ? ((n.triangleCount << 2) | kLeafAxis) : (n.splitAxis & 3u);
+            if (!leaf && n.splitAxis > 2) throw std::runtime_error("interior BVH node with invalid split axis");
+            packed[2 * i] = make_float4(n.aabb.min.x, n.aabb.min.y, n.aabb.min.z, bitsFloat(link));
+            packed[2 * i + 1] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, bitsFloat(meta));
+        }
+        m.nodes.upload(packed.data(), packed.size());
+    }
+    m.triangles.upload(reinterpret_cast<const float4*>(sceneView.positionAttributes.data()), 3 * sceneView.positionAttributes.size());
+    m.attributes.upload(sceneView.vertexAttributes.data(), sceneView.vertexAttributes.size());
+
+    // texture blob + descriptors in the order of the model's textures (reference_path_tracer.cpp:210-270)
+    {
+        std::vector<TextureDescriptor> descs;
+        std::vector<uint32_t>          blob;
+        for (const TextureView& t : sceneView.baseColorTextures)
+        {
+            const uint32_t offset = static_cast<uint32_t>(blob.size());
+            const size_t   n = static_cast<size_t>(t.width) * t.height;
+            blob.insert(blob.end(), t.pixels, t.pixels + n);
+            descs.push_back({t.width, t.height, offset});
+        }
+        // the reference refuses texture blobs above its 1 GiB binding limit (reference_path_tracer.cpp:254-263,
+        // gpu_limits.hpp); HBM has room, but u32 texel offsets cap the blob at 2^32 texels
+        if (blob.size() > 0xFFFFFFFFull) throw std::runtime_error("Texture buffer size exceeds the 32-bit texel offset range.");
+        if (blob.empty()) blob.push_back(0xFFFFFFFFu);
+        if (descs.empty()) descs.push_back({1, 1, 0});
+        m.textureDescriptors.upload(descs.data(), descs.size());
+        m.texels.upload(blob.data(), blob.size());
+    }
+    {
+        m.blueNoise.upload(blueNoiseTable(), 128 * 128 * 2);
+        float lut[256];
+        for (int i = 0; i < 256; ++i)
+            lut[i] = static_cast<float>(std::pow(static_cast<double>(static_cast<float>(i) / 255.0f), static_cast<double>(2.2f)));
+        m.albedoLut.upload(lut, 256);
+    }
+    m.scene.nodes = m.nodes.ptr;
+    m.scene.triangles = m.triangles.ptr;
+    m.scene.attributes = m.attributes.ptr;
+    m.scene.textureDescriptors = m.textureDescriptors.ptr;
+    m.scene.texels = m.texels.ptr;
+    m.scene.numTexels = m.texels.count;
+    m.scene.blueNoise = m.blueNoise.ptr;
+    m.scene.albedoLut = m.albedoLut.ptr;
+
+    DeviceCounters zero{};
+    m.counters.upload(&zero, 1);
+
+    m.maxWidth = desc.maxWidth ? desc.maxWidth : desc.renderParams.width;
+    m.maxHeight = desc.maxHeight ? desc.maxHeight : desc.renderParams.height;
+    const uint64_t maxTiles = static_cast<uint64_t>((m.maxWidth + kTileSize - 1) / kTileSize) * ((m.maxHeight + kTileSize - 1) / kTileSize);
+    const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (8ull << 20);
+    m.allocatePathState(std::max<uint64_t>(want, maxTiles * 1024));
+
+    m.params = desc.renderParams;
+    if (alignedSkyState(m.params.sky, m.sky) != SkyResult::Success) throw std::runtime_error("sky parameters out of range");
+    m.configureShard();
+}
+
+Renderer::~Renderer()
+{
+    if (!mImpl) return;
+    (void)hipSetDevice(mImpl->device);
+    (void)hipStreamSynchronize(mImpl->stream);
+    for (auto& t : mImpl->timed)
+    {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    for (auto& b : mImpl->pendingBatches)
+    {
+        (void)hipEventDestroy(b.start);
+        (void)hipEventDestroy(b.stop);
+    }
+    for (auto e : mImpl->eventPool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(mImpl->stream);
+}
+
+void Renderer::setRenderParameters(const RenderParameters& p)
+{
+    Impl& m = *mImpl;
+    if (m.params == p) return; // reference_path_tracer.cpp:556-563
+    if (p.width > m.maxWidth || p.height > m.maxHeight) throw std::runtime_error("framebuffer size exceeds maxFramebufferSize");
+    SkyStateGpu sky;
+    if (alignedSkyState(p.sky, sky) != SkyResult::Success) throw std::runtime_error("sky parameters out of range");
+    RF_HIP(hipSetDevice(m.device));
+    RF_HIP(hipStreamSynchronize(m.stream));
+    const bool resized = p.width != m.params.width || p.height != m.params.height;
+    m.params = p;
+    m.sky = sky;
+    m.accumulated = 0;
+    m.imageDirty = true;
+    if (resized) m.configureShard();
+}
+
+void Renderer::setTileShard(uint32_t rank, uint32_t worldSize)
+{
+    Impl& m = *mImpl;
+    if (worldSize == 0 || rank >= worldSize) throw std::runtime_error("invalid tile shard");
+    RF_HIP(hipSetDevice(m.device));
+    RF_HIP(hipStreamSynchronize(m.stream));
+    m.rank = rank;
+    m.worldSize = worldSize;
+    m.configureShard();
+}
+
+std::span<const uint32_t> Renderer::shardTiles() const { return mImpl->tiles; }
+
+void Renderer::render(uint32_t numFrames)
+{
+    Impl& m = *mImpl;
+    RF_HIP(hipSetDevice(m.device));
+    const uint32_t spp = m.params.samplingParams.numSamplesPerPixel;
+    const uint64_t pixelsPadded = static_cast<uint64_t>(m.tiles.size()) * 1024;
+    // Each reference render() call: frame = frameCount++, then one sample if accumulated < spp
+    // (reference_path_tracer.cpp:577-591, wgsl:47-57).  Calls past spp only advance frameCount.
+    uint32_t remaining = numFrames;
+    while (remaining > 0)
+    {
+        if (m.accumulated >= spp || pixelsPadded == 0)
+        {
+            m.frameCount += remaining;
+            break;
+        }
+        if (m.imageDirty)
+        {
+            RF_HIP(hipMemsetAsync(m.image, 0, pixelsPadded * sizeof(float4), m.stream)); // wgsl:47-49
+            m.imageDirty = false;
+        }
+        const uint32_t perBatch = static_cast<uint32_t>(std::max<uint64_t>(1, m.maxPaths / pixelsPadded));
+        const uint32_t n = std::min({remaining, spp - m.accumulated, perBatch});
+        m.traceBatch(m.frameCount, n);
+        m.frameCount += n;
+        m.accumulated += n;
+        remaining -= n;
+    }
+}
+
+float Renderer::averageRenderpassDurationMs() const
+{
+    Impl& m = *mImpl;
+    (void)hipSetDevice(m.device);
+    m.collectBatchTimings();
+    if (m.passDurationsMs.empty()) return 0.0f;
+    float sum = 0.0f;
+    for (float v : m.passDurationsMs) sum += v;
+    return sum / static_cast<float>(m.passDurationsMs.size());
+}
+
+float Renderer::renderProgressPercentage() const
+{
+    return 100.0f * static_cast<float>(mImpl->accumulated) / static_cast<float>(mImpl->params.samplingParams.numSamplesPerPixel);
+}
+
+uint32_t Renderer::accumulatedSampleCount() const { return mImpl->accumulated; }
+
+void Renderer::synchronize()
+{
+    RF_HIP(hipSetDevice(mImpl->device));
+    RF_HIP(hipStreamSynchronize(mImpl->stream));
+}
+
+void Renderer::readAccumulation(float* dst)
+{
+    Impl& m = *mImpl;
+    synchronize();
+    const size_t       pixelsPadded = m.tiles.size() * 1024;
+    std::vector<float> compact(pixelsPadded * 4);
+    if (m.imageDirty) std::fill(compact.begin(), compact.end(), 0.0f);
+    else if (pixelsPadded) RF_HIP(hipMemcpy(compact.data(), m.image, pixelsPadded * sizeof(float4), hipMemcpyDeviceToHost));
+    std::memset(dst, 0, static_cast<size_t>(m.params.width) * m.params.height * 4 * sizeof(float));
+    untileHost(compact.data(), m.tiles.data(), static_cast<uint32_t>(m.tiles.size()), m.params.width, m.params.height, dst);
+}
+
+void*    Renderer::accumulationDevicePointer() const { return mImpl->image; }
+uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }
+
+void Renderer::bindAccumulationBuffer(void* devicePtr, uint64_t bytes)
+{
+    Impl& m = *mImpl;
+    synchronize();
+    if (devicePtr == nullptr)
+    {
+        m.image = nullptr;
+        m.configureShard();
+        return;
+    }
+    if (bytes < accumulationBytes()) throw std::runtime_error("accumulation buffer too small");
+    m.image = static_cast<float4*>(devicePtr);
+    m.imageBytes = bytes;
+    m.accumulated = 0;
+    m.imageDirty = true;
+}
+
+void Renderer::readTonemapped(uint32_t* dst)
+{
+    Impl& m = *mImpl;
+    synchronize();
+    const uint32_t         n = static_cast<uint32_t>(m.tiles.size() * 1024);
+    DeviceBuffer<uint32_t> out;
+    out.alloc(std::max<uint32_t>(n, 1));
+    if (m.imageDirty)
+    {
+        RF_HIP(hipMemsetAsync(m.image, 0, static_cast<size_t>(n) * sizeof(float4), m.stream));
+        m.imageDirty = false;
+    }
+    if (n) hipLaunchKernelGGL(kTonemap, dim3((n + 255) / 256), dim3(256), 0, m.stream, m.image, n, m.accumulated, m.params.exposure, out.ptr);
+    RF_HIP(hipStreamSynchronize(m.stream));
+    std::vector<uint32_t> compact(n);
+    if (n) RF_HIP(hipMemcpy(compact.data(), out.ptr, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+    std::memset(dst, 0, static_cast<size_t>(m.params.width) * m.params.height * 4);
+    const uint32_t tilesX = (m.params.width + kTileSize - 1) / kTileSize;
+    for (size_t t = 0; t < m.tiles.size(); ++t)
+        for (uint32_t w = 0; w < 1024; ++w)
+        {
+            const uint32_t block = w >> 6, lane = w & 63u;
+            const uint32_t x = (m.tiles[t] % tilesX) * kTileSize + (block & 3u) * 8u + (lane & 7u);
+            const uint32_t y = (m.tiles[t] / tilesX) * kTileSize + (block >> 2) * 8u + (lane >> 3);
+            if (x < m.params.width && y < m.params.height) dst[static_cast<size_t>(y) * m.params.width + x] = compact[t * 1024 + w];
+        }
+}
+
+void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
+void Renderer::setTiming(bool enabled) { mImpl->timing = enabled; }
+
+void Renderer::resetStats()
+{
+    Impl& m = *mImpl;
+    synchronize();
+    m.collectTimings();
+    DeviceCounters zero{};
+    RF_HIP(hipMemcpy(m.counters.ptr, &zero, sizeof zero, hipMemcpyHostToDevice));
+    m.hostStats = RenderStats{};
+}
+
+RenderStats Renderer::stats()
+{
+    Impl& m = *mImpl;
+    synchronize();
+    m.collectTimings();
+    DeviceCounters c{};
+    RF_HIP(hipMemcpy(&c, m.counters.ptr, sizeof c, hipMemcpyDeviceToHost));
+    RenderStats s = m.hostStats;
+    s.primaryRays = c.primaryRays;
+    s.closestRays = c.closestRays;
+    s.shadowRays = c.shadowRays;
+    s.closestNodeVisits = c.closestNodeVisits;
+    s.closestTriangleTests = c.closestTriangleTests;
+    s.shadowNodeVisits = c.shadowNodeVisits;
+    s.shadowTriangleTests = c.shadowTriangleTests;
+    s.stackHighWater = c.stackHigh;
+    s.paths = c.primaryRays;
+    return s;
+}
+
+void Renderer::tracePrimaryStats(const Camera& camera, uint32_t width, uint32_t height, uint32_t* nodesVisitedOut, uint8_t* hitOut,
+                                 float* tOut, uint32_t* triangleTestsOut)
+{
+    Impl& m = *mImpl;
+    synchronize();
+    const size_t           n = static_cast<size_t>(width) * height;
+    DeviceBuffer<uint32_t> nv, tt;
+    DeviceBuffer<uint8_t>  hit;
+    DeviceBuffer<float>    t;
+    nv.alloc(n);
+    tt.alloc(n);
+    hit.alloc(n);
+    t.alloc(n);
+    const uint32_t waves = ((width + 7) / 8) * ((height + 7) / 8);
+    hipLaunchKernelGGL(kPrimaryStats, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, m.stream, m.scene, camera, width, height,
+                       nv.ptr, hit.ptr, t.ptr, tt.ptr);
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipStreamSynchronize(m.stream));
+    RF_HIP(hipMemcpy(nodesVisitedOut, nv.ptr, n * 4, hipMemcpyDeviceToHost));
+    if (hitOut) RF_HIP(hipMemcpy(hitOut, hit.ptr, n, hipMemcpyDeviceToHost));
+    if (tOut) RF_HIP(hipMemcpy(tOut, t.ptr, n * 4, hipMemcpyDeviceToHost));
+    if (triangleTestsOut) RF_HIP(hipMemcpy(triangleTestsOut, tt.ptr, n * 4, hipMemcpyDeviceToHost));
+}
+
+void Renderer::intersectRays(const float* rays6, uint64_t numRays, float tMax, uint32_t* triangleOut, float* tOut, float* uvOut, float* pOut,
+                             uint32_t* nodesVisitedOut, uint32_t* triangleTestsOut)
+{
+    Impl& m = *mImpl;
+    synchronize();
+    if (numRays == 0) return;
+    DeviceBuffer<float>    rays, t, uv, p;
+    DeviceBuffer<uint32_t> tri, nv, tt;
+    rays.upload(rays6, 6 * numRays);
+    tri.alloc(numRays);
+    t.alloc(numRays);
+    uv.alloc(2 * numRays);
+    p.alloc(3 * numRays);
+    nv.alloc(numRays);
+    tt.alloc(numRays);
+    hipLaunchKernelGGL(kIntersectRays, dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
+                       numRays, tMax, tri.ptr, t.ptr, uv.ptr, p.ptr, nv.ptr, tt.ptr);
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipStreamSynchronize(m.stream));
+    RF_HIP(hipMemcpy(triangleOut, tri.ptr, numRays * 4, hipMemcpyDeviceToHost));
+    if (tOut) RF_HIP(hipMemcpy(tOut, t.ptr, numRays * 4, hipMemcpyDeviceToHost));
+    if (uvOut) RF_HIP(hipMemcpy(uvOut, uv.ptr, numRays * 8, hipMemcpyDeviceToHost));
+    if (pOut) RF_HIP(hipMemcpy(pOut, p.ptr, numRays * 12, hipMemcpyDeviceToHost));
+    if (nodesVisitedOut) RF_HIP(hipMemcpy(nodesVisitedOut, nv.ptr, numRays * 4, hipMemcpyDeviceToHost));
+    if (triangleTestsOut) RF_HIP(hipMemcpy(triangleTestsOut, tt.ptr, numRays * 4, hipMemcpyDeviceToHost));
+}
+
+void Renderer::occludedRays(const float* rays6, uint64_t numRays, float tMax, float* visibilityOut)
+{
+    Impl& m = *mImpl;
+    synchronize();
+    if (numRays == 0) return;
+    DeviceBuffer<float> rays, vis;
+    rays.upload(rays6, 6 * numRays);
+    vis.alloc(numRays);
+    hipLaunchKernelGGL(kOccludedRays, dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
+                       numRays, tMax, vis.ptr);
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipStreamSynchronize(m.stream));
+    RF_HIP(hipMemcpy(visibilityOut, vis.ptr, numRays * 4, hipMemcpyDeviceToHost));
+}
+} // namespace rf

@@ -1,0 +1,136 @@
+// rf_renderer.hpp -- host interface of the MI355X wavefront path tracer.
+//
+// Mirrors the reference's renderer seam (src/pt/reference_path_tracer.hpp:26-76):
+//   ReferencePathTracer(desc, gpu, scene)  -> Renderer(desc, scene)      copies the scene to HBM
+//   setRenderParameters(params)            -> setRenderParameters        resets accumulation on change
+//   render(...)  (one sample per call)     -> render(numFrames)          n calls without host sync
+//   averageRenderpassDurationMs()          -> averageRenderpassDurationMs (30-deep moving average)
+//   renderProgressPercentage()             -> renderProgressPercentage
+// plus what an offline renderer needs and the reference never exposed: read-back of the float
+// accumulation buffer, the tonemapped image, per-kernel statistics, tile sharding for multi-GPU,
+// and the bvh-visualizer node-visit pass (src/bvh-visualizer/main.cpp:60-78) on the GPU.
+#pragma once
+
+#include "rf_sky.hpp"
+#include "rf_types.hpp"
+
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <span>
+#include <string>
+#include <vector>
+
+namespace rf
+{
+struct SamplingParams
+{
+    uint32_t numSamplesPerPixel = 128;
+    uint32_t numBounces = 4;
+    bool     operator==(const SamplingParams&) const = default;
+};
+
+struct RenderParameters
+{
+    uint32_t       width = 0, height = 0;
+    Camera         camera{};
+    SamplingParams samplingParams;
+    Sky            sky;
+    float          exposure = 1.0f;
+};
+bool operator==(const RenderParameters& a, const RenderParameters& b);
+
+struct TextureView
+{
+    const uint32_t* pixels;
+    uint32_t        width, height;
+};
+
+struct SceneView
+{
+    std::span<const BvhNode>           bvhNodes;
+    std::span<const PositionAttribute> positionAttributes;
+    std::span<const VertexAttributes>  vertexAttributes;
+    std::span<const TextureView>       baseColorTextures;
+};
+
+struct RendererDescriptor
+{
+    RenderParameters renderParams;
+    uint32_t         maxWidth = 0, maxHeight = 0;
+    int              deviceOrdinal = 0;
+    // Paths kept in flight per batch (several samples of every pixel are traced together so that
+    // deep bounces still fill the chip). 0 = default (about 8M).
+    uint64_t maxPathsInFlight = 0;
+};
+
+// Ray/traversal statistics since the last resetStats().  Node visits and triangle tests are only
+// counted while counting is enabled (it selects the counting build of the traversal kernels).
+struct RenderStats
+{
+    uint64_t primaryRays = 0, closestRays = 0, shadowRays = 0;
+    uint64_t closestNodeVisits = 0, closestTriangleTests = 0;
+    uint64_t shadowNodeVisits = 0, shadowTriangleTests = 0;
+    uint64_t paths = 0;
+    uint32_t stackHighWater = 0;
+    // hipEvent-timed kernel time (ms) and launch counts, per kernel class, while timing is enabled
+    double   msRaygen = 0, msClosest = 0, msShade = 0, msShadow = 0, msAccumulate = 0;
+    uint32_t launchesRaygen = 0, launchesClosest = 0, launchesShade = 0, launchesShadow = 0, launchesAccumulate = 0;
+};
+
+constexpr uint32_t kTileSize = 32; // shard tile edge in pixels (32x32 = 16 waves of 8x8 pixels)
+
+// Deterministic tile -> rank assignment (scrambled round-robin, equal counts +-1).
+std::vector<uint32_t> tilesForRank(uint32_t width, uint32_t height, uint32_t rank, uint32_t worldSize);
+// compact tile-major float4 buffer -> row-major width*height*4 image (pixels of other ranks' tiles untouched)
+void untileHost(const float* compact, const uint32_t* tileIds, uint32_t numTiles, uint32_t width, uint32_t height, float* image);
+
+class Renderer
+{
+public:
+    Renderer(const RendererDescriptor& desc, const SceneView& scene);
+    ~Renderer();
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+
+    void  setRenderParameters(const RenderParameters& params);
+    void  render(uint32_t numFrames);
+    float averageRenderpassDurationMs() const;
+    float renderProgressPercentage() const;
+
+    // Multi-GPU: render only this rank's tiles. Resets accumulation.
+    void setTileShard(uint32_t rank, uint32_t worldSize);
+    std::span<const uint32_t> shardTiles() const;
+
+    uint32_t accumulatedSampleCount() const;
+    // Row-major width*height*4 floats (sum of samples, 16-B stride as the reference's
+    // array<vec3f>); pixels outside this rank's tiles are zero.
+    void readAccumulation(float* dst);
+    // Device pointer of the compact tile-major accumulation buffer (numTiles*1024 float4) and a
+    // way to render into caller-owned device memory (e.g. a torch tensor used for the RCCL gather).
+    void*    accumulationDevicePointer() const;
+    uint64_t accumulationBytes() const;
+    void     bindAccumulationBuffer(void* devicePtr, uint64_t bytes);
+    // BGRA8 swap-chain image (wgsl:59-63), row-major.
+    void readTonemapped(uint32_t* dstBgra8);
+
+    void        setCounting(bool enabled);
+    void        setTiming(bool enabled);
+    void        resetStats();
+    RenderStats stats();
+    void        synchronize();
+
+    // bvh-visualizer pass: pinhole camera, u = j/W, v = 1-(i+1)/H, tMax = FLT_MAX.
+    void tracePrimaryStats(const Camera& camera, uint32_t width, uint32_t height, uint32_t* nodesVisitedOut,
+                           uint8_t* hitOut, float* tOut, uint32_t* triangleTestsOut);
+    // Batch closest-hit / any-hit of caller rays (6 floats each) -- the GPU twin of the
+    // reference's CPU query rayIntersectBvh (src/common/ray_intersection.hpp:43-49).
+    void intersectRays(const float* rays6, uint64_t numRays, float tMax, uint32_t* triangleOut, float* tOut, float* uvOut,
+                       float* pOut, uint32_t* nodesVisitedOut, uint32_t* triangleTestsOut);
+    void occludedRays(const float* rays6, uint64_t numRays, float tMax, float* visibilityOut);
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> mImpl;
+};
+} // namespace rf
