@@ -1,0 +1,360 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+the same inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties (shard-union == whole, batching invariance, idempotence,
+ray-count conservation).
+
+Bars:  traversal outputs (hit, t, triangle, u, v, p, nodesVisited, triangle tests) BIT-EXACT.
+       Radiance sums: per channel |gpu - oracle| <= 1e-3*|oracle| + 1e-4*spp on >= 99.5 % of
+       pixels; in practice the f64-evaluated transcendental policy makes the
+       images bit-identical, which the tests also report/assert at >= 99.9 %.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import rayfinder_amd as rf
+from conftest import GOLDEN, bits, oracle_scene_from_pt
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _renderer(pt, w, h, spp, bounces, cam=None, sky=None, exposure=0.25, **kw):
+    cam = cam if cam is not None else rf.fly_camera(w, h)
+    params = rf.make_render_parameters(w, h, cam, spp, bounces, sky if sky is not None else rf.make_sky(), exposure)
+    return rf.ReferencePathTracer(params, pt.scene(), **kw), params
+
+
+def _compare(gpu_sum, ref_sum, spp, min_ok=0.995, min_exact=0.999):
+    g, c = gpu_sum[..., :3], ref_sum[..., :3]
+    nan = np.isnan(g) | np.isnan(c)
+    assert np.array_equal(np.isnan(g), np.isnan(c)), "NaN pixels differ"
+    diff = np.abs(np.where(nan, 0, g - c))
+    tol = 1e-3 * np.abs(np.where(nan, 0, c)) + 1e-4 * spp
+    ok = float((diff <= tol).mean())
+    exact = float(((g == c) | nan).mean())
+    assert ok >= min_ok, (ok, exact, float(diff.max()))
+    assert exact >= min_exact, (ok, exact, float(diff.max()))
+    return ok, exact
+
+
+# ------------------------------------------------------------------ config 1: node-visit parity
+def test_primary_node_visits_bit_exact_vs_golden_256(duck_pt):
+    g = np.load(os.path.join(GOLDEN, "duck_golden.npz"))
+    r, _ = _renderer(duck_pt, 256, 256, 1, 1)
+    nodes = duck_pt.arrays()["bvhNodes"]
+    out = r.trace_primary_stats(rf.bvh_visualizer_camera(nodes, 1.0), 256, 256)
+    assert np.array_equal(out["nodesVisited"], g["viz256_nodes_visited"].astype(np.uint32))
+    assert np.array_equal(np.packbits(out["hit"]), g["viz256_hit"])
+    assert int(out["nodesVisited"].sum()) == 1209382 and int(out["hit"].sum()) == 19462
+    assert int(out["triTests"].sum()) == int(g["viz256_tri_tests"]) == 69097
+
+
+def test_primary_node_visits_bit_exact_1280x720(duck_pt, duck_oracle):
+    r, _ = _renderer(duck_pt, 64, 64, 1, 1)
+    aspect = np.float32(np.float32(1280) / np.float32(720))
+    cam = rf.bvh_visualizer_camera(duck_oracle.nodes, aspect)
+    out = r.trace_primary_stats(cam, 1280, 720)
+    cpu = orc.bvh_visualize(duck_oracle.nodes, duck_oracle.tris36, rf.camera_to_array(cam), 1280, 720)
+    assert np.array_equal(out["nodesVisited"], cpu["nodesVisited"])
+    assert np.array_equal(out["hit"], cpu["hit"]) and np.array_equal(bits(out["t"]), bits(cpu["t"]))
+    assert np.array_equal(out["triTests"], cpu["triTests"])
+    assert int(out["nodesVisited"].sum()) == 9979946
+
+
+def test_reference_bvh_test_grid_on_gpu(duck_pt):
+    """src/tests/bvh.cpp:76-101 rays: GPU hit/t/triangle == oracle == brute force."""
+    g = np.load(os.path.join(GOLDEN, "duck_golden.npz"))
+    r, _ = _renderer(duck_pt, 64, 64, 1, 1)
+    out = r.intersect_rays(g["grid_rays"], 1000.0)
+    assert np.array_equal(out["hit"], g["grid_hit"]) and int(out["hit"].sum()) == 1216
+    assert np.array_equal(bits(out["t"]), bits(g["grid_t"]))
+    assert np.array_equal(out["tri"][out["hit"] == 1], g["grid_tri"][g["grid_hit"] == 1])
+
+
+def _random_rays(rng, n, lo, hi):
+    o = rng.uniform(lo - 0.5 * (hi - lo), hi + 0.5 * (hi - lo), (n, 3))
+    target = rng.uniform(lo, hi, (n, 3))
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    # edge cases the reference tests exercise: axis-parallel directions (inf invDir, 0*inf NaN
+    # slabs), non-unit directions, rays starting inside the model, zero components
+    k = n // 10
+    rays[:k, 3:] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], (k, 1)).astype(np.float32)
+    rays[k:2 * k, 3:] *= rng.uniform(0.1, 5.0, (k, 1)).astype(np.float32)
+    rays[2 * k:3 * k, :3] = rng.uniform(lo, hi, (k, 3)).astype(np.float32)
+    rays[3 * k:4 * k, 4] = 0.0
+    return rays
+
+
+@pytest.mark.parametrize("tmax", [10000.0, 1.5, float(np.finfo(np.float32).max)])
+def test_closest_hit_random_rays_bit_exact(duck_pt, duck_oracle, tmax):
+    rng = np.random.default_rng(42)
+    lo, hi = duck_oracle.nodes[0]["min"].astype(np.float64), duck_oracle.nodes[0]["max"].astype(np.float64)
+    rays = _random_rays(rng, 20000, lo, hi)
+    r, _ = _renderer(duck_pt, 64, 64, 1, 1)
+    with np.errstate(all="ignore"):
+        cpu = orc.intersect_bvh_batch(duck_oracle.nodes, duck_oracle.pos48, rays, tmax)
+    gpu = r.intersect_rays(rays, tmax)
+    assert np.array_equal(gpu["hit"], cpu["hit"])
+    assert np.array_equal(gpu["tri"], cpu["tri"])
+    for k in ("t", "uv", "p"):
+        assert np.array_equal(bits(gpu[k]), bits(cpu[k])), k
+    assert np.array_equal(gpu["nodesVisited"], cpu["nodesVisited"])
+    assert np.array_equal(gpu["triTests"], cpu["triTests"])
+    assert 0.05 < cpu["hit"].mean() < 0.95
+
+
+def test_any_hit_random_rays_bit_exact(duck_pt, duck_oracle):
+    rng = np.random.default_rng(43)
+    lo, hi = duck_oracle.nodes[0]["min"].astype(np.float64), duck_oracle.nodes[0]["max"].astype(np.float64)
+    rays = _random_rays(rng, 20000, lo, hi)
+    r, _ = _renderer(duck_pt, 64, 64, 1, 1)
+    with np.errstate(all="ignore"):
+        cpu = orc.shadow_batch(duck_oracle.nodes, duck_oracle.pos48, rays, 10000.0)
+        closest = orc.intersect_bvh_batch(duck_oracle.nodes, duck_oracle.pos48, rays, 10000.0)
+    gpu = r.occluded_rays(rays, 10000.0)
+    assert np.array_equal(gpu, cpu)
+    assert np.array_equal(gpu == 0.0, closest["hit"] == 1)   # any-hit agrees with closest-hit on occlusion
+    assert r.intersect_rays(np.zeros((0, 6), np.float32), 1.0)["tri"].size == 0   # empty input
+
+
+# ------------------------------------------------------------------ config 2: radiance parity
+def test_duck_render_matches_golden_crops(duck_pt):
+    g = np.load(os.path.join(GOLDEN, "duck_render_golden.npz"))
+    W, H, spp, bounces = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["bounces"])
+    r, _ = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    assert acc == spp and r.render_progress_percentage() == 100.0
+    for (x0, y0), want in zip(g["crops"], g["sums"]):
+        _compare(img[y0:y0 + 16, x0:x0 + 16], want, spp)
+    assert (img[..., 3] == 0).all()       # 16-byte stride, w unused (array<vec3f>)
+
+
+def test_duck_render_vs_oracle_full_frame(duck_pt, duck_oracle):
+    W, H, spp, bounces = 200, 150, 16, 4
+    r, params = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    ref, st = orc.render(duck_oracle.scene, rp, 0, spp)
+    ok, exact = _compare(img, ref, spp)
+    s = r.stats()
+    assert s["closest_rays"] == st.closestRays and s["shadow_rays"] == st.shadowRays
+    # tonemapped swap-chain image (wgsl:59-63): within 1 LSB of the oracle's float result
+    bgra = r.read_tonemapped()
+    srgb = orc.tonemap(ref, spp, 0.25).reshape(H, W, 3)
+    want = np.floor(srgb * 255.0 + 0.5).astype(np.int64)
+    got = np.stack([(bgra >> 16) & 255, (bgra >> 8) & 255, bgra & 255], axis=-1).astype(np.int64)
+    assert np.abs(got - want).max() <= 1 and ((bgra >> 24) == 255).all()
+
+
+def test_lens_sampling_and_other_sky_parameters(duck_pt, duck_oracle):
+    """Thin-lens camera (aperture > 0), low sun, turbid sky, odd frame size (edge tiles)."""
+    W, H, spp, bounces = 150, 90, 8, 3
+    cam = rf.fly_camera(W, H, aperture=0.2, focus_distance=2.0, vfov_degrees=50.0)
+    sky = rf.make_sky(4.5, (0.3, 0.5, 0.2), 75.0, 200.0)
+    r, params = _renderer(duck_pt, W, H, spp, bounces, cam=cam, sky=sky)
+    r.render(spp)
+    img, _ = r.read_accumulation()
+    rp = orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.25, rf.aligned_sky_state(sky))
+    ref, _ = orc.render(duck_oracle.scene, rp, 0, spp)
+    _compare(img, ref, spp)
+
+
+def test_counting_build_matches_oracle_counts(duck_pt, duck_oracle):
+    W, H, spp, bounces = 128, 96, 4, 4
+    r, params = _renderer(duck_pt, W, H, spp, bounces)
+    r.set_counting(True)
+    r.render(spp)
+    s = r.stats()
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    _, st = orc.render(duck_oracle.scene, rp, 0, spp)
+    assert s["closest_node_visits"] == st.closestNodeVisits and s["closest_triangle_tests"] == st.closestTriTests
+    assert s["shadow_node_visits"] == st.shadowNodeVisits and s["shadow_triangle_tests"] == st.shadowTriTests
+    assert s["stack_high_water"] == st.stackHigh
+    assert s["primary_rays"] == W * H * spp
+
+
+# ------------------------------------------------------------------ renderer state machine
+def test_frame_and_sample_bookkeeping(duck_pt, duck_oracle):
+    """reference_path_tracer.cpp:556-595: one sample per render() until spp, frameCount never
+    resets, setRenderParameters resets accumulation only on a change."""
+    W, H, spp, bounces = 96, 64, 6, 2
+    r, params = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(2); r.render(1)
+    img3, acc = r.read_accumulation()
+    assert acc == 3 and r.render_progress_percentage() == pytest.approx(50.0)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    ref3, _ = orc.render(duck_oracle.scene, rp, 0, 3)
+    _compare(img3, ref3, 3)
+    r.set_render_parameters(params)            # identical -> no reset
+    assert r.read_accumulation()[1] == 3
+    r.render(10)                               # clamps at spp; frameCount advances to 13
+    img6, acc = r.read_accumulation()
+    assert acc == spp
+    ref6, _ = orc.render(duck_oracle.scene, rp, 0, spp)
+    _compare(img6, ref6, spp)
+    # change exposure -> accumulation restarts, sample indices continue from frameCount = 13
+    p2 = rf.make_render_parameters(W, H, params.camera, spp, bounces, params.sky, 0.5)
+    r.set_render_parameters(p2)
+    assert r.read_accumulation()[1] == 0 and (r.read_accumulation()[0] == 0).all()
+    r.render(2)
+    img, acc = r.read_accumulation()
+    assert acc == 2
+    ref = np.zeros((H, W, 4), np.float32)
+    for f in (13, 14):                         # oracle: two single-frame calls with acc = 0, 1
+        for y in range(H):
+            for x in range(0, W, 7):           # subsample columns to keep the CPU work small
+                rgb, _ = orc.pixel_sample(duck_oracle.scene, rp, x, y, f)
+                ref[y, x, :3] += rgb
+    _compare(img[:, ::7], ref[:, ::7], 2)
+    assert r.average_renderpass_duration_ms() > 0.0
+
+
+def test_batching_is_invisible(duck_pt):
+    """Samples traced 1 / 3 / all per batch give the same image bit for bit (f32 accumulation in
+    sample order, wgsl:55)."""
+    W, H, spp, bounces = 160, 96, 9, 4
+    tiles = ((W + 31) // 32) * ((H + 31) // 32)
+    imgs = []
+    for per_batch in (1, 3, 9):
+        r, _ = _renderer(duck_pt, W, H, spp, bounces, max_paths_in_flight=per_batch * tiles * 1024)
+        r.render(spp)
+        imgs.append(r.read_accumulation()[0])
+        r.close()
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1])) and np.array_equal(bits(imgs[0]), bits(imgs[2]))
+    r, _ = _renderer(duck_pt, W, H, spp, bounces)
+    for _ in range(spp):
+        r.render(1)
+    assert np.array_equal(bits(r.read_accumulation()[0]), bits(imgs[0]))
+
+
+def test_tile_shards_union_equals_whole(duck_pt):
+    W, H, spp, bounces = 200, 150, 4, 4
+    whole, _ = _renderer(duck_pt, W, H, spp, bounces)
+    whole.render(spp)
+    want = whole.read_accumulation()[0]
+    union = np.zeros_like(want)
+    seen = np.zeros((H, W), bool)
+    for world in (3,):
+        for rank in range(world):
+            r, _ = _renderer(duck_pt, W, H, spp, bounces)
+            r.set_tile_shard(rank, world)
+            assert np.array_equal(r.shard_tiles(), rf.tiles_for_rank(W, H, rank, world))
+            r.render(spp)
+            part = r.read_accumulation()[0]
+            mask = np.zeros((H, W), bool)
+            tx = (W + 31) // 32
+            for t in r.shard_tiles():
+                mask[(t // tx) * 32:(t // tx) * 32 + 32, (t % tx) * 32:(t % tx) * 32 + 32] = True
+            assert (part[~mask] == 0).all() and not (seen & mask).any()
+            seen |= mask
+            union[mask] = part[mask]
+            r.close()
+    assert seen.all() and np.array_equal(bits(union), bits(want))
+
+
+def test_render_into_torch_tensor(duck_pt):
+    torch = pytest.importorskip("torch")
+    W, H, spp, bounces = 96, 64, 3, 2
+    r, _ = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(spp)
+    want = r.read_accumulation()[0]
+    ptr, nbytes = r.accumulation_device_buffer()
+    assert nbytes == len(r.shard_tiles()) * 1024 * 16
+    buf = torch.full((nbytes // 4,), 7.0, dtype=torch.float32, device="cuda:0")
+    r.bind_accumulation_buffer(buf.data_ptr(), buf.numel() * 4)
+    assert r.read_accumulation()[1] == 0
+    r.render(spp)
+    r.synchronize()
+    img = rf.untile(buf.cpu().numpy(), r.shard_tiles(), W, H)
+    assert np.array_equal(bits(img), bits(want))
+    with pytest.raises(rf.RayfinderError):
+        r.bind_accumulation_buffer(buf.data_ptr(), 16)
+
+
+def test_set_render_parameters_resize_and_limits(duck_pt):
+    r, params = _renderer(duck_pt, 64, 64, 2, 2, max_width=128, max_height=128)
+    p2 = rf.make_render_parameters(128, 96, rf.fly_camera(128, 96), 2, 2, params.sky, 0.25)
+    r.set_render_parameters(p2)
+    r.render(2)
+    img, acc = r.read_accumulation()
+    assert img.shape == (96, 128, 4) and acc == 2 and np.isfinite(img).all() and img[..., :3].max() > 0
+    with pytest.raises(rf.RayfinderError):
+        r.set_render_parameters(rf.make_render_parameters(256, 256, rf.fly_camera(256, 256), 2, 2, params.sky, 0.25))
+    with pytest.raises(rf.RayfinderError):
+        r.set_render_parameters(rf.make_render_parameters(64, 64, rf.fly_camera(64, 64), 2, 2, rf.make_sky(turbidity=0.5), 0.25))
+
+
+# ------------------------------------------------------------------ configs 3-5: the atrium
+@pytest.fixture(scope="module")
+def atrium():
+    from rayfinder_amd import scenes
+    pt, info = scenes.atrium()
+    assert 255000 < info["triangles"] < 270000 and info["textures"] == 25
+    return pt
+
+
+def test_atrium_crops_vs_oracle_1080p_8_bounces(atrium):
+    W, H, spp, bounces = 1920, 1080, 4, 8
+    r, params = _renderer(atrium, W, H, spp, bounces)
+    r.set_counting(True)
+    r.render(spp)
+    img, _ = r.read_accumulation()
+    s = r.stats()
+    sc, _ = oracle_scene_from_pt(atrium)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    for (x0, y0) in [(928, 508), (64, 64), (1500, 300), (1888, 1048), (700, 900)]:
+        ref, st = orc.render(sc, rp, 0, spp, x0, y0, x0 + 32, y0 + 32)
+        _compare(img[y0:y0 + 32, x0:x0 + 32], ref[y0:y0 + 32, x0:x0 + 32], spp)
+        assert st.stackHigh < 32          # the reference's fixed stack would also suffice here
+    # full-size properties
+    assert not np.isnan(img).any()
+    assert s["primary_rays"] == W * H * spp
+    assert s["shadow_rays"] <= s["closest_rays"] <= W * H * spp * bounces
+    assert s["stack_high_water"] < 32
+    assert s["closest_node_visits"] > 30 * s["closest_rays"]
+
+
+def test_atrium_idempotent_and_shard_union_at_full_size(atrium):
+    W, H, spp, bounces = 1920, 1080, 2, 8
+    a, params = _renderer(atrium, W, H, spp, bounces)
+    a.render(spp)
+    img_a = a.read_accumulation()[0]
+    a.set_render_parameters(rf.make_render_parameters(W, H, params.camera, spp, bounces, params.sky, 0.125))  # reset
+    a.render(spp)
+    img_b = a.read_accumulation()[0]
+    # frameCount moved on by 2, and 2 % 2 == 0: same sample indices -> same image, bit for bit
+    assert np.array_equal(bits(img_a), bits(img_b))
+    union = np.zeros_like(img_a)
+    tx = (W + 31) // 32
+    for rank in range(2):
+        a.set_tile_shard(rank, 2)
+        a.render(spp)                      # frameCount 4, 5 -> sample indices 0, 1 again
+        part = a.read_accumulation()[0]
+        for t in a.shard_tiles():
+            ys, xs = (t // tx) * 32, (t % tx) * 32
+            union[ys:ys + 32, xs:xs + 32] = part[ys:ys + 32, xs:xs + 32]
+    assert np.array_equal(bits(union), bits(img_a))
+
+
+def test_known_answer_quad_scene_on_gpu():
+    """The analytic NEE case of tests/test_oracle_pins.py, on the GPU."""
+    import math
+    from rayfinder_amd import scenes
+    pt = scenes.quad_scene()
+    cam = rf.create_camera([0, 3, 0.001], [0, 0, 0], 0.0, 1.0, orc.degrees_to_radians(40.0), 1.0)
+    r, params = _renderer(pt, 16, 16, 4, 1, cam=cam, exposure=1.0)
+    r.render(1)
+    img, _ = r.read_accumulation()
+    sky = rf.aligned_sky_state(params.sky)
+    expected = sky[30:33] * (1.0 / math.pi) * math.cos(math.radians(30.0)) * 6.216817e-05
+    assert np.allclose(img[8, 8, :3], expected, rtol=5e-3)
+    sc, _ = oracle_scene_from_pt(pt)
+    rp = orc.make_render_params(16, 16, rf.camera_to_array(cam), 4, 1, 1.0, sky)
+    ref, _ = orc.render(sc, rp, 0, 1)
+    assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))

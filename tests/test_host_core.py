@@ -1,0 +1,401 @@
+"""CPU tests of the product's host core through the C ABI (no GPU needed): every declared symbol
+is exported; BVH builder, glTF/PNG ingest, .pt reader/writer, camera and sky agree bit for bit
+with the oracle / the reference's golden vectors; error behaviour matches the reference."""
+import ctypes as C
+import hashlib
+import io
+import json
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import rayfinder_amd as rf
+from conftest import DUCK, GOLDEN, ROOT, bits
+from oracle import gltf_ref, orc
+
+
+# ---------------------------------------------------------------- the C ABI itself
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rayfinder_amd.h")).read()
+    declared = set(re.findall(r"RF_API\s+[\w\s\*]+?\b(rf_\w+)\s*\(", header))
+    assert len(declared) >= 40
+    assert declared == set(rf._ffi.SIGNATURES), declared ^ set(rf._ffi.SIGNATURES)
+    lib = C.CDLL(rf._ffi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", rf._ffi.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (rf_\w+)", out))
+    assert declared <= exported
+    assert rf.version().startswith("rayfinder_amd")
+
+
+def test_no_oracle_in_product():
+    # the product must not link, include or import anything under oracle/
+    out = subprocess.check_output(["ldd", rf._ffi.LIB_PATH]).decode()
+    assert "oracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rayfinder_amd")):
+        if "build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("test oracle", ""), os.path.join(dirpath, f)
+
+
+def test_renderer_create_fails_loudly_without_gpu(duck_pt):
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    params = rf.make_render_parameters(64, 64, rf.fly_camera(64, 64), 4, 2)
+    with pytest.raises(rf.RayfinderError) as e:
+        rf.ReferencePathTracer(params, duck_pt.scene())
+    assert e.value.status == rf._ffi.RF_ERROR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_invalid_arguments_are_reported():
+    assert rf.lib.rf_renderer_create(None, None, None) == rf._ffi.RF_ERROR_INVALID_ARGUMENT
+    assert rf.lib.rf_pt_format_load(None, None) == rf._ffi.RF_ERROR_INVALID_ARGUMENT
+    with pytest.raises(rf.RayfinderError):
+        rf.build_bvh(np.zeros((0, 9), np.float32))      # the reference asserts !triangles.empty()
+    with pytest.raises(rf.RayfinderError):
+        rf.tiles_for_rank(64, 64, 2, 2)
+
+
+# ---------------------------------------------------------------- BVH builder
+def test_build_bvh_matches_oracle_on_duck(duck_oracle):
+    nodes, idx, depth = rf.build_bvh(duck_oracle.P)
+    assert nodes.tobytes() == duck_oracle.nodes.tobytes()
+    assert np.array_equal(idx, duck_oracle.idx) and depth == duck_oracle.depth
+    g = np.load(os.path.join(GOLDEN, "duck_golden.npz"))
+    assert hashlib.sha256(nodes.tobytes()).hexdigest() == str(g["nodes_sha256"])
+
+
+@pytest.mark.parametrize("seed,n", [(1, 1), (2, 2), (3, 3), (4, 17), (5, 300), (6, 5000)])
+def test_build_bvh_matches_oracle_on_random_soups(seed, n):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-10, 10, (n, 1, 3))
+    P = (c + rng.normal(0, 0.3, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+    a, ai, ad = rf.build_bvh(P)
+    b, bi, bd = orc.build_bvh(P)
+    assert a.tobytes() == b.tobytes() and np.array_equal(ai, bi) and ad == bd
+    assert sorted(ai.tolist()) == list(range(n))          # a permutation
+    leaves = a[a["triangleCount"] > 0]
+    assert int(leaves["triangleCount"].sum()) == n
+
+
+def test_build_bvh_degenerate_inputs():
+    # 300 identical triangles: centroid extent is degenerate -> ONE leaf of 300 (bvh.cpp:111-121),
+    # even though 300 > maxTrianglesInNode
+    tri = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0], np.float32)
+    P = np.tile(tri, (300, 1))
+    a, ai, _ = rf.build_bvh(P)
+    b, bi, _ = orc.build_bvh(P)
+    assert len(a) == 1 and a[0]["triangleCount"] == 300 and a.tobytes() == b.tobytes()
+    # zero-area node box (all vertices on one point)
+    P = np.zeros((5, 9), np.float32)
+    a, _, _ = rf.build_bvh(P)
+    assert len(a) == 1 and a[0]["triangleCount"] == 5
+    # 400 triangles on a line: forced splits above 255 primitives
+    P = np.zeros((400, 9), np.float32)
+    P[:, 0] = P[:, 3] = P[:, 6] = np.arange(400)
+    P[:, 4] = 1; P[:, 8] = 1
+    a, ai, _ = rf.build_bvh(P)
+    b, bi, _ = orc.build_bvh(P)
+    assert a.tobytes() == b.tobytes() and np.array_equal(ai, bi)
+    assert a[a["triangleCount"] > 0]["triangleCount"].max() <= 255
+
+
+# ---------------------------------------------------------------- glTF ingest + .pt
+def test_duck_pt_matches_oracle_ingest(duck_pt, duck_oracle):
+    a = duck_pt.arrays()
+    d = duck_oracle
+    assert a["bvhNodes"].tobytes() == d.nodes.tobytes()
+    assert np.array_equal(bits(a["bvhPositionAttributes"]), bits(d.tris36))
+    assert np.array_equal(bits(a["trianglePositionAttributes"]), bits(d.pos48))
+    assert np.array_equal(bits(a["triangleVertexAttributes"]), bits(d.attr80))
+    px, w, h = a["baseColorTextures"][0]
+    assert (w, h) == (512, 512) and np.array_equal(px, d.texels)      # own PNG decoder == PIL
+    g = np.load(os.path.join(GOLDEN, "duck_golden.npz"))
+    assert hashlib.sha256(px.tobytes()).hexdigest() == str(g["tex_sha256"])
+    # raster-mesh arrays (pt_format.cpp:85-148)
+    m = d.model["meshes"][0]
+    assert np.array_equal(bits(a["vertexPositions"][:, :3]), bits(m["positions"])) and (a["vertexPositions"][:, 3] == 1).all()
+    assert np.array_equal(bits(a["vertexNormals"][:, :3]), bits(m["normals"])) and (a["vertexNormals"][:, 3] == 0).all()
+    assert np.array_equal(a["vertexIndices"], m["indices"])
+    assert a["modelVertexPositions"].tolist() == [[0, 2399]] and a["modelVertexIndices"].tolist() == [[0, 12636]]
+    assert a["modelBaseColorTextureIndices"].tolist() == [0]
+    # substitute pins from SURVEY 8(c): accessor min/max * 0.01 == root AABB
+    js, _ = gltf_ref.load_container(DUCK)
+    acc = js["accessors"][2]
+    assert np.allclose(a["bvhNodes"][0]["min"], np.float32(0.01) * np.array(acc["min"], np.float32), rtol=1e-6)
+    assert np.allclose(a["bvhNodes"][0]["max"], np.float32(0.01) * np.array(acc["max"], np.float32), rtol=1e-6)
+
+
+def test_pt_format_round_trip_and_size(duck_pt, tmp_path):
+    data = duck_pt.serialize()
+    assert len(data) == 2288437 and data[:9] == b"PTFORMAT3"
+    again = rf.PtFormat.deserialize(data)
+    assert again.serialize() == data
+    a, b = duck_pt.arrays(), again.arrays()
+    for k in a:
+        if k == "baseColorTextures":
+            assert all(np.array_equal(x[0], y[0]) and x[1:] == y[1:] for x, y in zip(a[k], b[k]))
+        else:
+            assert a[k].tobytes() == b[k].tobytes(), k       # memcmp-equal, as tests/pt_format.cpp:18-176
+    p = tmp_path / "Duck.pt"
+    duck_pt.save(p)
+    assert open(p, "rb").read() == data
+    assert rf.PtFormat.load(p).serialize() == data
+
+
+def test_pt_format_layout_is_the_documented_one(duck_pt):
+    """Independent parse of the byte stream per pt_format.cpp:238-321."""
+    data = duck_pt.serialize()
+    off = 9
+    sizes = [48, 36, 48, 80, 16, 16, 8, 4]
+    counts = []
+    for s in sizes:
+        n = struct.unpack_from("<Q", data, off)[0]; off += 8 + n * s; counts.append(n)
+    assert counts == [8383, 4212, 4212, 4212, 2399, 2399, 2399, 12636]
+    for _ in range(4):
+        n = struct.unpack_from("<Q", data, off)[0]; off += 8 + 16 * n
+    n = struct.unpack_from("<Q", data, off)[0]; off += 8 + 4 * n
+    ntex = struct.unpack_from("<Q", data, off)[0]; off += 8
+    assert ntex == 1
+    w, h, npx = struct.unpack_from("<IIQ", data, off); off += 16 + 4 * npx
+    assert (w, h, npx) == (512, 512, 512 * 512) and off == len(data)
+
+
+def test_pt_format_magic_errors_match_reference():
+    with pytest.raises(rf.RayfinderError) as e:
+        rf.PtFormat.deserialize(b"PTFORMAT0")
+    assert str(e.value) == ("Mismatching PtFormat file version. Invalid version in magic bytes: expected "
+                            "'PTFORMAT3', got 'PTFORMAT0'.")
+    with pytest.raises(rf.RayfinderError) as e:
+        rf.PtFormat.deserialize(b"INVALID  ")
+    assert str(e.value) == "Invalid file format: expected PtFormat file."
+    with pytest.raises(rf.RayfinderError):
+        rf.PtFormat.deserialize(b"PTFORMAT3" + b"\x05\x00\x00\x00\x00\x00\x00\x00")   # truncated
+    with pytest.raises(rf.RayfinderError):
+        rf.PtFormat.load("/nonexistent/file.pt")
+    with pytest.raises(rf.RayfinderError) as e:
+        rf.PtFormat.from_gltf("/nonexistent/file.glb")
+    assert "does not exist" in str(e.value)
+
+
+def _make_glb(path, nodes, meshes_prims, materials, images=(), textures=(), samplers=()):
+    """Tiny GLB writer for ingest tests. meshes_prims: list of lists of (pos, nrm, uv, idx, material)."""
+    blob = bytearray()
+    views, accessors, meshes = [], [], []
+
+    def add(data, target=None):
+        while len(blob) % 4:
+            blob.append(0)
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)})
+        blob.extend(data)
+        return len(views) - 1
+
+    for prims in meshes_prims:
+        plist = []
+        for (pos, nrm, uv, idx, mat) in prims:
+            accs = {}
+            for name, arr, typ in (("POSITION", pos, "VEC3"), ("NORMAL", nrm, "VEC3"), ("TEXCOORD_0", uv, "VEC2")):
+                v = add(np.asarray(arr, "<f4").tobytes())
+                accessors.append({"bufferView": v, "componentType": 5126, "count": len(arr), "type": typ})
+                accs[name] = len(accessors) - 1
+            idx = np.asarray(idx)
+            ct = {np.dtype("uint8"): 5121, np.dtype("uint16"): 5123, np.dtype("uint32"): 5125}[idx.dtype]
+            v = add(idx.tobytes())
+            accessors.append({"bufferView": v, "componentType": ct, "count": idx.size, "type": "SCALAR"})
+            plist.append({"attributes": accs, "indices": len(accessors) - 1, "material": mat, "mode": 4})
+        meshes.append({"primitives": plist})
+    imgs = []
+    for png in images:
+        v = add(png)
+        imgs.append({"bufferView": v, "mimeType": "image/png"})
+    js = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": nodes, "meshes": meshes,
+          "materials": materials, "accessors": accessors, "bufferViews": views, "buffers": [{"byteLength": len(blob)}]}
+    if imgs:
+        js.update(images=imgs, textures=list(textures), samplers=list(samplers))
+    jb = json.dumps(js).encode()
+    jb += b" " * (-len(jb) % 4)
+    while len(blob) % 4:
+        blob.append(0)
+    total = 12 + 8 + len(jb) + 8 + len(blob)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<III", 0x46546C67, 2, total))
+        f.write(struct.pack("<II", len(jb), 0x4E4F534A)); f.write(jb)
+        f.write(struct.pack("<II", len(blob), 0x004E4942)); f.write(bytes(blob))
+
+
+def _png(arr, mode, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr, mode).save(buf, "PNG", **kw)
+    return buf.getvalue()
+
+
+def test_gltf_ingest_transforms_materials_and_png_variants(tmp_path):
+    rng = np.random.default_rng(11)
+
+    def prim(nv, mat, dtype):
+        pos = rng.uniform(-1, 1, (nv, 3)); nrm = rng.normal(size=(nv, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        uv = rng.uniform(-2, 2, (nv, 2)); idx = rng.integers(0, nv, 3 * 7).astype(dtype)
+        return (pos, nrm, uv, idx, mat)
+
+    rgb = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    rgba = rng.integers(0, 256, (4, 6, 4), dtype=np.uint8)
+    gray = rng.integers(0, 256, (5, 3), dtype=np.uint8)
+    pal = rng.integers(0, 256, (16, 16), dtype=np.uint8)
+    from PIL import Image
+    pim = Image.fromarray(pal, "P"); pim.putpalette([int(x) for x in rng.integers(0, 256, 768)])
+    buf = io.BytesIO(); pim.save(buf, "PNG"); pal_png = buf.getvalue()
+    images = [_png(rgb, "RGB"), _png(rgba, "RGBA"), _png(gray, "L"), pal_png]
+    q = np.array([0.1, 0.7, -0.2, 0.67]); q /= np.linalg.norm(q)
+    nodes = [
+        {"children": [1, 2, 3], "translation": [1.0, 2.0, 3.0], "rotation": q.tolist(), "scale": [2.0, 0.5, 1.5]},
+        {"mesh": 0, "matrix": [0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 2, 0, 0.5, 0.25, -4, 1]},
+        {"mesh": 1, "scale": [0.01, 0.01, 0.01]},
+        {"mesh": 2, "children": [4], "translation": [0, -1, 0]},
+        {"mesh": 3, "rotation": [0.5, 0.5, 0.5, 0.5]},
+    ]
+    materials = [
+        {"pbrMetallicRoughness": {"baseColorTexture": {"index": 3}}},     # palette
+        {"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1.0]}},
+        {"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}},
+        {"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1.0]}},  # same factor -> dedup
+        {"pbrMetallicRoughness": {"baseColorTexture": {"index": 1}}},
+        {"pbrMetallicRoughness": {"baseColorTexture": {"index": 2}}},
+        {"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}},     # same image -> dedup
+    ]
+    meshes = [[prim(9, 0, np.uint16), prim(5, 1, np.uint8)], [prim(12, 2, np.uint32)], [prim(6, 3, np.uint16), prim(7, 4, np.uint16)],
+              [prim(8, 5, np.uint16), prim(4, 6, np.uint8)]]
+    textures = [{"source": i, "sampler": 0} for i in range(4)]
+    p = tmp_path / "multi.glb"
+    _make_glb(p, nodes, meshes, materials, images, textures, [{"wrapS": 10497, "wrapT": 10497}])
+
+    pt = rf.PtFormat.from_gltf(p)
+    a = pt.arrays()
+    m = gltf_ref.load_model(str(p))
+    P, N, T, I = gltf_ref.flatten(m)
+    onodes, oidx, _ = orc.build_bvh(P)
+    assert a["bvhNodes"].tobytes() == onodes.tobytes()
+    pa, va = gltf_ref.gpu_layout(orc.reorder(P, oidx), orc.reorder(N, oidx), orc.reorder(T, oidx), orc.reorder(I, oidx))
+    assert np.array_equal(bits(a["trianglePositionAttributes"]), bits(pa))
+    assert np.array_equal(bits(a["triangleVertexAttributes"]), bits(va))
+    assert len(a["baseColorTextures"]) == len(m["textures"]) == 5         # 4 images + 1 factor colour
+    for (px, w, h), (opx, ow, oh) in zip(a["baseColorTextures"], m["textures"]):
+        assert (w, h) == (ow, oh) and np.array_equal(px, opx)
+    assert a["modelBaseColorTextureIndices"].tolist() == sorted(a["modelBaseColorTextureIndices"].tolist())  # sorted by texture
+    # fromPixel truncation (texture.cpp:56-65): 0.2*255 = 51, 0.4*255 = 102, 0.6*255 = 153
+    factor = [t for t in a["baseColorTextures"] if t[1:] == (1, 1)][0][0][0]
+    assert factor == (153 | (102 << 8) | (51 << 16) | (255 << 24))
+
+
+def test_png_decoder_interlaced_16bit_and_low_depth():
+    rng = np.random.default_rng(5)
+    from PIL import Image
+    cases = []
+    rgb = rng.integers(0, 256, (13, 11, 3), dtype=np.uint8)
+    buf = io.BytesIO(); Image.fromarray(rgb, "RGB").save(buf, "PNG", interlace=1) if False else None
+    cases.append((_png(rgb, "RGB"), rgb))
+    g16 = rng.integers(0, 65536, (7, 9), dtype=np.uint16)
+    b = io.BytesIO(); Image.fromarray(g16, "I;16").save(b, "PNG"); cases.append((b.getvalue(), None))
+    bw = (rng.integers(0, 2, (10, 10)) * 255).astype(np.uint8)
+    b = io.BytesIO(); Image.fromarray(bw, "L").convert("1").save(b, "PNG"); cases.append((b.getvalue(), None))
+    la = rng.integers(0, 256, (6, 6, 2), dtype=np.uint8)
+    cases.append((_png(la, "LA"), None))
+    for png, _ in cases:
+        # go through a GLB so the product decodes it
+        want = gltf_ref.decode_image_bgra(png)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            tri = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], float), np.array([[0, 0, 1]] * 3, float), np.zeros((3, 2)), np.array([0, 1, 2], np.uint8), 0)
+            path = os.path.join(td, "t.glb")
+            _make_glb(path, [{"mesh": 0}], [[tri]], [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}], [png], [{"source": 0}], [])
+            px, w, h = rf.PtFormat.from_gltf(path).texture(0)
+        if w * h and want is not None:
+            opx, ow, oh = want
+            assert (w, h) == (ow, oh)
+            if png is cases[1][0]:
+                # 16-bit: stb keeps the high byte; PIL's I;16 -> RGBA conversion clips instead.  Check against the spec'd rule.
+                hi = (g16 >> 8).astype(np.uint32).reshape(-1)
+                assert np.array_equal(px, hi | (hi << 8) | (hi << 16) | np.uint32(255 << 24))
+            else:
+                assert np.array_equal(px, opx)
+
+
+def test_cli_pt_format_tool_writes_identical_bytes(duck_pt, tmp_path):
+    import shutil
+    tool = os.path.join(ROOT, "rayfinder_amd", "bin", "rf-pt-format-tool")
+    src = tmp_path / "Duck.glb"
+    shutil.copy(DUCK, src)
+    out = subprocess.check_output([tool, str(src)]).decode()
+    assert "8383 nodes" in out
+    assert open(tmp_path / "Duck.pt", "rb").read() == duck_pt.serialize()
+    assert subprocess.call([tool, str(tmp_path / "missing.glb")], stderr=subprocess.DEVNULL) == 1
+    assert b"Usage" in subprocess.check_output([tool])
+
+
+# ---------------------------------------------------------------- camera / sky
+def test_cameras_match_oracle(duck_oracle):
+    for (w, h) in [(800, 600), (1920, 1080), (256, 256)]:
+        assert np.array_equal(bits(rf.camera_to_array(rf.fly_camera(w, h))), bits(orc.default_pt_camera(w, h)))
+        aspect = np.float32(np.float32(w) / np.float32(h))
+        assert np.array_equal(bits(rf.camera_to_array(rf.bvh_visualizer_camera(duck_oracle.nodes, aspect))),
+                              bits(orc.bvh_visualizer_camera(duck_oracle.nodes, aspect)))
+    a = rf.camera_to_array(rf.create_camera([1, 2, 3], [0, 0.5, -1], 0.3, 4.0, orc.degrees_to_radians(55.0), 1.5))
+    b = orc.create_camera([1, 2, 3], [0, 0.5, -1], 0.3, 4.0, orc.degrees_to_radians(55.0), 1.5)
+    assert np.array_equal(bits(a), bits(b)) and a[18] == np.float32(0.15)
+
+
+def test_sky_matches_reference_vectors():
+    from test_oracle_pins import _check_sky
+    _check_sky(rf.sky_state_new, rf.sky_state_radiance)
+    assert np.array_equal(bits(rf.aligned_sky_state(rf.make_sky())), bits(orc.aligned_sky_state()))
+    s = rf.make_sky(3.5, (0.2, 0.5, 0.9), 71.0, 213.0)
+    assert np.array_equal(bits(rf.aligned_sky_state(s)), bits(orc.aligned_sky_state(3.5, (0.2, 0.5, 0.9), 71.0, 213.0)))
+    with pytest.raises(rf.RayfinderError) as e:
+        rf.aligned_sky_state(rf.make_sky(turbidity=11.0))
+    assert e.value.status == rf._ffi.RF_ERROR_OUT_OF_RANGE
+
+
+# ---------------------------------------------------------------- tiles
+@pytest.mark.parametrize("w,h,world", [(1920, 1080, 1), (1920, 1080, 8), (800, 600, 2), (100, 70, 3), (31, 33, 4)])
+def test_tile_assignment_is_a_balanced_partition(w, h, world):
+    tx, ty = (w + 31) // 32, (h + 31) // 32
+    all_tiles = [rf.tiles_for_rank(w, h, r, world) for r in range(world)]
+    flat = np.concatenate(all_tiles)
+    assert sorted(flat.tolist()) == list(range(tx * ty))
+    sizes = [len(t) for t in all_tiles]
+    assert max(sizes) - min(sizes) <= 1
+    for t in all_tiles:
+        assert (np.diff(t.astype(np.int64)) > 0).all()
+    if world == 1:
+        assert all_tiles[0].tolist() == list(range(tx * ty))
+
+
+def test_untile_inverts_the_tile_major_layout():
+    w, h = 100, 70
+    tiles = rf.tiles_for_rank(w, h, 1, 3)
+    compact = np.zeros((len(tiles) * 1024, 4), np.float32)
+    tx = (w + 31) // 32
+    expect = np.zeros((h, w, 4), np.float32)
+    for t, tid in enumerate(tiles):
+        for k in range(1024):
+            block, lane = k >> 6, k & 63
+            x = (tid % tx) * 32 + (block & 3) * 8 + (lane & 7)
+            y = (tid // tx) * 32 + (block >> 2) * 8 + (lane >> 3)
+            compact[t * 1024 + k] = (x, y, tid, 1)
+            if x < w and y < h:
+                expect[y, x] = (x, y, tid, 1)
+    img = rf.untile(compact, tiles, w, h)
+    assert np.array_equal(img, expect)
