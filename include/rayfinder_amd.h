@@ -149,6 +149,8 @@ RF_API int rf_renderer_read_tonemapped(rf_renderer* r, uint32_t* dst_bgra8);
 /* Statistics (replaces the ImGui perf read-out, src/pt/main.cpp:251-257). */
 RF_API int rf_renderer_set_counting(rf_renderer* r, int enabled);
 RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
+/* Tuning knobs for A/B measurements ("traversal_variant": 0 | 1); never change results. */
+RF_API int rf_renderer_set_option(rf_renderer* r, const char* name, int64_t value);
 RF_API int rf_renderer_reset_stats(rf_renderer* r);
 RF_API int rf_renderer_get_stats(rf_renderer* r, rf_stats* out);
 

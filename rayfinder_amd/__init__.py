@@ -295,6 +295,9 @@ class ReferencePathTracer:
     def set_timing(self, enabled):
         check(lib.rf_renderer_set_timing(self._h, int(enabled)))
 
+    def set_option(self, name, value):
+        check(lib.rf_renderer_set_option(self._h, name.encode(), int(value)))
+
     def reset_stats(self):
         check(lib.rf_renderer_reset_stats(self._h))
 

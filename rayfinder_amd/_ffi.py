@@ -100,6 +100,7 @@ SIGNATURES = {
     "rf_renderer_read_tonemapped": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rf_renderer_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "rf_renderer_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rf_renderer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "rf_renderer_reset_stats": (C.c_int, [C.c_void_p]),
     "rf_renderer_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rf_renderer_set_tile_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -210,6 +210,15 @@ int rf_renderer_set_counting(rf_renderer* r, int enabled)
     });
 }
 
+int rf_renderer_set_option(rf_renderer* r, const char* name, int64_t value)
+{
+    return guarded([&] {
+        require(r && name, "null argument");
+        r->impl->setOption(name, value);
+        return RF_OK;
+    });
+}
+
 int rf_renderer_set_timing(rf_renderer* r, int enabled)
 {
     return guarded([&] {

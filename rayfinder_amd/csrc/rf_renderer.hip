@@ -25,12 +25,14 @@
 #include "rf_camera.hpp"
 #include "rf_data.hpp"
 #include "rf_device.hpp"
+#include "rf_wide.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -311,6 +313,481 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
     if (i == 0) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent traversal: the production form of kTraceClosest / kTraceShadow.
+//
+// A wave is 64 independent rays whose trip counts differ by an order of magnitude (atrium: mean 62
+// node visits, tail > 300), and 19 visits in 20 are interior nodes.  Two things keep the lanes
+// busy without changing any ray's visit order (results and counters stay bit-identical):
+//   * lane refill -- a lane whose ray has finished takes the next ray of the wave's current chunk
+//     (chunks of kChunk queue entries are claimed with one atomic per chunk), so waves stay full
+//     until the queue is dry instead of idling behind their longest ray;
+//   * deferred leaves -- a lane that reaches a leaf parks on it; the wave keeps visiting interior
+//     nodes with the other lanes until fewer than kLeafVote of them are still descending, then all
+//     parked lanes run the Moller-Trumbore code together (instead of every step paying for both
+//     the interior and the leaf path).
+// Grid = resident blocks only (CUs x blocks/CU); each wave loops until the queue is exhausted.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kChunk = 256;   // queue entries claimed per atomic
+constexpr uint32_t kRefillMin = 8; // refill once this many lanes are idle (or the wave is empty)
+constexpr uint32_t kLeafVote = 40; // leave the descent loop when fewer lanes than this are descending
+
+enum LaneState : uint32_t
+{
+    kIdle = 0,    // no ray
+    kDescend = 1, // `current` is the next node to visit
+    kAtLeaf = 2,  // parked on a leaf (leafLink, leafCount)
+    kDone = 3,    // ray finished, result not yet written
+};
+
+template<bool ANY_HIT, bool COUNT>
+__global__ __launch_bounds__(kBlock) void kTracePersistent(DeviceScene scene, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
+                                                            const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote)
+{
+    __shared__ uint32_t sStack[kLdsStack * kBlock];
+    const uint32_t      count = *queueCount;
+    const uint32_t      lane = __lane_id();
+
+    // wave-uniform work cursor
+    uint32_t chunkPos = 0, chunkEnd = 0;
+    bool     exhausted = count == 0;
+
+    // per-lane ray state
+    uint32_t  state = kIdle;
+    uint32_t  slot = 0, current = 0, leafLink = 0, leafCount = 0;
+    float     noiseX = 0.0f;
+    RayPrep   ray{};
+    float     rayTMax = kTMax;
+    LaneStack stack;
+    stack.lds = &sStack[threadIdx.x];
+    ClosestHit        best{};
+    bool              occluded = false;
+    TraversalCounters tc;
+
+    for (;;)
+    {
+        // ---- refill idle lanes
+        const unsigned long long idleMask = __ballot(state == kIdle);
+        const uint32_t           idleCount = __popcll(idleMask);
+        if (!exhausted && idleCount >= refillMin)
+        {
+            if (chunkPos == chunkEnd)
+            {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, kChunk);
+                base = __shfl(base, 0);
+                if (base >= count)
+                {
+                    exhausted = true;
+                    chunkPos = chunkEnd = 0;
+                }
+                else
+                {
+                    chunkPos = base;
+                    chunkEnd = min(base + kChunk, count);
+                }
+            }
+            const uint32_t take = min(idleCount, chunkEnd - chunkPos);
+            const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
+            if (state == kIdle && rankInIdle < take)
+            {
+                slot = queue[chunkPos + rankInIdle];
+                const float4 o = ps.rayO[slot];
+                Vec3         dir;
+                if (ANY_HIT)
+                {
+                    dir = sunSample(sky, o.w, ps.rayD[slot].w, ps.thr[slot].w);
+                }
+                else
+                {
+                    const float4 d = ps.rayD[slot];
+                    dir = vec3(d.x, d.y, d.z);
+                }
+                ray = prepareRay(vec3(o.x, o.y, o.z), dir);
+                noiseX = o.w;
+                rayTMax = kTMax;
+                current = 0;
+                stack.size = 0;
+                best.triangle = kMiss;
+                occluded = false;
+                state = kDescend;
+            }
+            chunkPos += take;
+        }
+        if (__ballot(state != kIdle) == 0ull)
+        {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- descend: interior-node visits only, until too few lanes are still descending
+        do
+        {
+            if (state == kDescend)
+            {
+                const float4 lo = scene.nodes[2 * current];
+                const float4 hi = scene.nodes[2 * current + 1];
+                if (COUNT) ++tc.nodesVisited;
+                bool needPop = true;
+                if (slabTest(ray, lo, hi, rayTMax))
+                {
+                    const uint32_t link = __float_as_uint(lo.w);
+                    const uint32_t meta = __float_as_uint(hi.w);
+                    const uint32_t axis = meta & 3u;
+                    if (axis == kLeafAxis)
+                    {
+                        leafLink = link;
+                        leafCount = meta >> 2;
+                        state = kAtLeaf;
+                        needPop = false;
+                    }
+                    else
+                    {
+                        const uint32_t neg = axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ);
+                        const uint32_t deferred = neg ? current + 1 : link;
+                        current = neg ? link : current + 1;
+                        needPop = !stack.push(deferred); // overflow: abandon the ray
+                        if (COUNT) tc.stackHigh = max(tc.stackHigh, static_cast<uint32_t>(stack.size));
+                        if (needPop) stack.size = 0;
+                    }
+                }
+                if (needPop)
+                {
+                    if (stack.size == 0) state = kDone;
+                    else current = stack.pop();
+                }
+            }
+        } while (__popcll(__ballot(state == kDescend)) >= leafVote);
+
+        // ---- leaves: all parked lanes intersect their triangles together
+        if (state == kAtLeaf)
+        {
+            bool finished = false;
+            for (uint32_t i = 0; i < leafCount; ++i)
+            {
+                const uint32_t tri = leafLink + i;
+                const float4   a = scene.triangles[3 * tri];
+                const float4   b = scene.triangles[3 * tri + 1];
+                const float4   c = scene.triangles[3 * tri + 2];
+                if (COUNT) ++tc.triangleTests;
+                TriangleHit th;
+                const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
+                if (intersectTriangle(ray, p0, p1, p2, rayTMax, th))
+                {
+                    if (ANY_HIT)
+                    {
+                        occluded = true;
+                        finished = true;
+                        break;
+                    }
+                    rayTMax = th.t;
+                    const Vec3 e1 = p1 - p0, e2 = p2 - p0;
+                    const Vec3 p = p0 + th.u * e1 + th.v * e2;
+                    const Vec3 n = normalize(cross(e1, e2));
+                    best.p = offsetRay(p, n);
+                    best.t = th.t;
+                    best.u = th.u;
+                    best.v = th.v;
+                    best.triangle = tri;
+                }
+            }
+            if (finished || stack.size == 0) state = kDone;
+            else
+            {
+                current = stack.pop();
+                state = kDescend;
+            }
+        }
+
+        // ---- write back finished rays
+        if (state == (kDone))
+        {
+            if (ANY_HIT)
+            {
+                const float  visibility = occluded ? 0.0f : 1.0f;
+                const float4 pend = ps.pending[slot];
+                const float4 rad4 = ps.rad[slot];
+                const Vec3   add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3   radiance = vec3(rad4.x, rad4.y, rad4.z) + add;
+                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            }
+            else
+            {
+                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, 0.0f);
+                if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, noiseX);
+            }
+            state = kIdle;
+        }
+    }
+
+    if (COUNT)
+    {
+        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
+        const uint32_t           sh = waveMax(tc.stackHigh);
+        if (lane == 0)
+        {
+            atomicAdd(ANY_HIT ? &counters->shadowNodeVisits : &counters->closestNodeVisits, nv);
+            atomicAdd(ANY_HIT ? &counters->shadowTriangleTests : &counters->closestTriangleTests, tt);
+            if (!ANY_HIT) atomicMax(&counters->stackHigh, sh);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
+}
+
+// ------------------------------------------------------------------------------------------------
+// kTraceWide: persistent traversal over the 64-byte children-in-parent layout (rf_wide.hpp).
+// Same scheduling as kTracePersistent (chunked queue claims, lane refill, deferred leaves); one
+// dependent fetch now tests two boxes and leaf nodes are never fetched.
+// ------------------------------------------------------------------------------------------------
+template<bool ANY_HIT, bool COUNT>
+__global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
+                                                      const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin,
+                                                      uint32_t leafVote)
+{
+    __shared__ uint2 sStack[kWideLdsStack * kBlock];
+    const uint32_t   count = *queueCount;
+    const uint32_t   lane = __lane_id();
+
+    uint32_t chunkPos = 0, chunkEnd = 0;
+    bool     exhausted = count == 0;
+
+    uint32_t  state = kIdle;
+    uint32_t  slot = 0, current = 0, leafWord = 0;
+    float     noiseX = 0.0f;
+    RayPrep   ray{};
+    float     rayTMax = kTMax;
+    WideStack stack;
+    stack.lds = &sStack[threadIdx.x];
+    ClosestHit        best{};
+    bool              occluded = false;
+    TraversalCounters tc;
+
+    // Pop entries until one passes `tmin < rayTMax` (the reference's box test at pop time).
+    auto popNext = [&]() {
+        for (;;)
+        {
+            if (stack.size == 0)
+            {
+                state = kDone;
+                return;
+            }
+            const uint2 e = stack.pop();
+            if (COUNT) ++tc.nodesVisited;
+            if (__uint_as_float(e.y) < rayTMax)
+            {
+                if (e.x & kWideLeafBit)
+                {
+                    leafWord = e.x;
+                    state = kAtLeaf;
+                }
+                else
+                {
+                    current = e.x;
+                    state = kDescend;
+                }
+                return;
+            }
+        }
+    };
+
+    for (;;)
+    {
+        // ---- refill idle lanes from the wave's chunk
+        const unsigned long long idleMask = __ballot(state == kIdle);
+        const uint32_t           idleCount = __popcll(idleMask);
+        if (!exhausted && idleCount >= refillMin)
+        {
+            if (chunkPos == chunkEnd)
+            {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, kChunk);
+                base = __shfl(base, 0);
+                if (base >= count)
+                {
+                    exhausted = true;
+                    chunkPos = chunkEnd = 0;
+                }
+                else
+                {
+                    chunkPos = base;
+                    chunkEnd = min(base + kChunk, count);
+                }
+            }
+            const uint32_t take = min(idleCount, chunkEnd - chunkPos);
+            const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
+            if (state == kIdle && rankInIdle < take)
+            {
+                slot = queue[chunkPos + rankInIdle];
+                const float4 o = ps.rayO[slot];
+                Vec3         dir;
+                if (ANY_HIT)
+                {
+                    dir = sunSample(sky, o.w, ps.rayD[slot].w, ps.thr[slot].w);
+                }
+                else
+                {
+                    const float4 d = ps.rayD[slot];
+                    dir = vec3(d.x, d.y, d.z);
+                }
+                ray = prepareRay(vec3(o.x, o.y, o.z), dir);
+                noiseX = o.w;
+                rayTMax = kTMax;
+                stack.size = 0;
+                best.triangle = kMiss;
+                occluded = false;
+                // the root visit (wgsl:379-382)
+                if (COUNT) ++tc.nodesVisited;
+                float      rootTMin;
+                const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
+                if (!rootOk) state = kDone;
+                else if (wide.rootLeaf != kWideNone)
+                {
+                    leafWord = wide.rootLeaf;
+                    state = kAtLeaf;
+                }
+                else
+                {
+                    current = 0;
+                    state = kDescend;
+                }
+            }
+            chunkPos += take;
+        }
+        if (__ballot(state != kIdle) == 0ull)
+        {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- descend: one 64-byte record = both children of an accepted interior node
+        do
+        {
+            if (state == kDescend)
+            {
+                const float4*  n = wide.nodes + 4 * static_cast<size_t>(current);
+                const float4   a0 = n[0], a1 = n[1], b0 = n[2], b1 = n[3];
+                const uint32_t axis = __float_as_uint(a1.w) & 3u;
+                const uint32_t neg = axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ);
+                float          t0, t1;
+                const bool     ok0 = slabBounds(ray, a0, a1, t0);
+                const bool     ok1 = slabBounds(ray, b0, b1, t1);
+                // reference order: dirNeg[axis] ? second child first : first child first
+                const uint32_t nearWord = __float_as_uint(neg ? b0.w : a0.w), farWord = __float_as_uint(neg ? a0.w : b0.w);
+                const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
+                const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
+                bool           overflow = false;
+                if (COUNT)
+                {
+                    overflow = !stack.push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
+                    tc.stackHigh = max(tc.stackHigh, static_cast<uint32_t>(stack.size));
+                    ++tc.nodesVisited; // the near child
+                }
+                else if (okFar)
+                {
+                    overflow = !stack.push(farWord, tFar);
+                }
+                if (overflow)
+                {
+                    stack.size = 0; // deeper than 96: abandon the ray
+                    state = kDone;
+                }
+                else if (okNear && tNear < rayTMax)
+                {
+                    if (nearWord & kWideLeafBit)
+                    {
+                        leafWord = nearWord;
+                        state = kAtLeaf;
+                    }
+                    else
+                    {
+                        current = nearWord;
+                    }
+                }
+                else
+                {
+                    popNext();
+                }
+            }
+        } while (__popcll(__ballot(state == kDescend)) >= leafVote);
+
+        // ---- leaves
+        if (state == kAtLeaf)
+        {
+            uint32_t first = leafWord & 0x0FFFFFFFu, n = ((leafWord >> 28) & 7u) + 1u;
+            if (n == 8u)
+            {
+                const uint2 big = wide.bigLeaves[first];
+                first = big.x;
+                n = big.y;
+            }
+            bool finished = false;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                const uint32_t tri = first + i;
+                const float4   a = scene.triangles[3 * tri];
+                const float4   b = scene.triangles[3 * tri + 1];
+                const float4   c = scene.triangles[3 * tri + 2];
+                if (COUNT) ++tc.triangleTests;
+                TriangleHit th;
+                const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
+                if (intersectTriangle(ray, p0, p1, p2, rayTMax, th))
+                {
+                    if (ANY_HIT)
+                    {
+                        occluded = true;
+                        finished = true;
+                        break;
+                    }
+                    rayTMax = th.t;
+                    const Vec3 e1 = p1 - p0, e2 = p2 - p0;
+                    const Vec3 p = p0 + th.u * e1 + th.v * e2;
+                    const Vec3 nrm = normalize(cross(e1, e2));
+                    best.p = offsetRay(p, nrm);
+                    best.t = th.t;
+                    best.u = th.u;
+                    best.v = th.v;
+                    best.triangle = tri;
+                }
+            }
+            if (finished) state = kDone;
+            else popNext();
+        }
+
+        // ---- write back finished rays
+        if (state == kDone)
+        {
+            if (ANY_HIT)
+            {
+                const float  visibility = occluded ? 0.0f : 1.0f;
+                const float4 pend = ps.pending[slot];
+                const float4 rad4 = ps.rad[slot];
+                const Vec3   add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3   radiance = vec3(rad4.x, rad4.y, rad4.z) + add;
+                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            }
+            else
+            {
+                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, 0.0f);
+                if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, noiseX);
+            }
+            state = kIdle;
+        }
+    }
+
+    if (COUNT)
+    {
+        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
+        const uint32_t           sh = waveMax(tc.stackHigh);
+        if (lane == 0)
+        {
+            atomicAdd(ANY_HIT ? &counters->shadowNodeVisits : &counters->closestNodeVisits, nv);
+            atomicAdd(ANY_HIT ? &counters->shadowTriangleTests : &counters->closestTriangleTests, tt);
+            if (!ANY_HIT) atomicMax(&counters->stackHigh, sh);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
+}
+
 // image[lp] += radiance of samples 0..numSamples-1 in order (f32, wgsl:55); image is the compact
 // tile-major float4 buffer.
 __global__ __launch_bounds__(kBlock) void kAccumulate(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image)
@@ -492,7 +969,9 @@ struct Renderer::Impl
     int         device = 0;
     hipStream_t stream = nullptr;
 
-    DeviceBuffer<float4>            nodes, triangles;
+    DeviceBuffer<float4>            nodes, triangles, wideNodes;
+    DeviceBuffer<uint2>             bigLeaves;
+    WideScene                       wide{};
     DeviceBuffer<VertexAttributes>  attributes;
     DeviceBuffer<TextureDescriptor> textureDescriptors;
     DeviceBuffer<uint32_t>          texels;
@@ -519,6 +998,9 @@ struct Renderer::Impl
     DeviceBuffer<DeviceCounters> counters;
 
     bool counting = false, timing = false;
+    int      traversalVariant = 2; // 0 = one ray per thread, 1 = persistent + refill (32-B nodes), 2 = persistent, 64-B wide nodes
+    uint32_t persistentBlocks = 0, wideBlocks = 0;
+    uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote;
     RenderStats hostStats;
 
     struct TimedLaunch
@@ -663,7 +1145,9 @@ struct Renderer::Impl
         BatchTiming bt{getEvent(), getEvent(), numSamples};
         RF_HIP(hipEventRecord(bt.start, stream));
 
-        if (queueCounts.count < numBounces + 2) queueCounts.alloc(numBounces + 2);
+        // [0, numBounces+1]: queue lengths; then two work cursors per bounce for the persistent kernels
+        if (queueCounts.count < 3 * numBounces + 4) queueCounts.alloc(3 * numBounces + 4);
+        uint32_t* const cursors = queueCounts.ptr + numBounces + 2;
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
 
         uint32_t* qIn = queueA.ptr;
@@ -676,20 +1160,58 @@ struct Renderer::Impl
             uint32_t* countIn = queueCounts.ptr + (bounce - 1);
             uint32_t* countOut = queueCounts.ptr + bounce;
             launchTimed(1, [&] {
-                if (counting)
-                    hipLaunchKernelGGL(kTraceClosest<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+                if (traversalVariant == 0)
+                {
+                    if (counting)
+                        hipLaunchKernelGGL(kTraceClosest<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+                    else
+                        hipLaunchKernelGGL(kTraceClosest<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+                }
+                else if (traversalVariant == 2)
+                {
+                    const dim3 grid(std::min(blocks, wideBlocks));
+                    if (counting)
+                        hipLaunchKernelGGL((kTraceWide<false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
+                    else
+                        hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
+                }
                 else
-                    hipLaunchKernelGGL(kTraceClosest<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+                {
+                    const dim3 grid(std::min(blocks, persistentBlocks));
+                    if (counting)
+                        hipLaunchKernelGGL((kTracePersistent<false, true>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
+                    else
+                        hipLaunchKernelGGL((kTracePersistent<false, false>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
+                }
             });
             launchTimed(2, [&] {
                 hipLaunchKernelGGL(kShade, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, qOut, countOut,
                                    bounce == numBounces ? 1u : 0u);
             });
             launchTimed(3, [&] {
-                if (counting)
-                    hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                if (traversalVariant == 0)
+                {
+                    if (counting)
+                        hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                    else
+                        hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                }
+                else if (traversalVariant == 2)
+                {
+                    const dim3 grid(std::min(blocks, wideBlocks));
+                    if (counting)
+                        hipLaunchKernelGGL((kTraceWide<true, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
+                    else
+                        hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
+                }
                 else
-                    hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                {
+                    const dim3 grid(std::min(blocks, persistentBlocks));
+                    if (counting)
+                        hipLaunchKernelGGL((kTracePersistent<true, true>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
+                    else
+                        hipLaunchKernelGGL((kTracePersistent<true, false>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
+                }
             });
             std::swap(qIn, qOut);
         }
@@ -733,6 +1255,14 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             packed[2 * i + 1] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, bitsFloat(meta));
         }
         m.nodes.upload(packed.data(), packed.size());
+        const WideBuild wb = buildWide(sceneView.bvhNodes.data(), sceneView.bvhNodes.size());
+        m.wideNodes.upload(wb.nodes.data(), wb.nodes.size());
+        m.bigLeaves.upload(wb.bigLeaves.data(), wb.bigLeaves.size());
+        m.wide.nodes = m.wideNodes.ptr;
+        m.wide.bigLeaves = m.bigLeaves.ptr;
+        m.wide.rootLo = wb.rootLo;
+        m.wide.rootHi = wb.rootHi;
+        m.wide.rootLeaf = wb.rootLeaf;
     }
     m.triangles.upload(reinterpret_cast<const float4*>(sceneView.positionAttributes.data()), 3 * sceneView.positionAttributes.size());
     m.attributes.upload(sceneView.vertexAttributes.data(), sceneView.vertexAttributes.size());
@@ -774,6 +1304,16 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
 
     DeviceCounters zero{};
     m.counters.upload(&zero, 1);
+    {
+        hipDeviceProp_t prop{};
+        RF_HIP(hipGetDeviceProperties(&prop, m.device));
+        int perCu = 0;
+        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTracePersistent<false, false>, kBlock, 0));
+        m.persistentBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
+        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, 0));
+        m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
+        if (const char* v = std::getenv("RF_TRAVERSAL_VARIANT")) m.traversalVariant = std::atoi(v);
+    }
 
     m.maxWidth = desc.maxWidth ? desc.maxWidth : desc.renderParams.width;
     m.maxHeight = desc.maxHeight ? desc.maxHeight : desc.renderParams.height;
@@ -950,6 +1490,15 @@ void Renderer::readTonemapped(uint32_t* dst)
 }
 
 void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
+
+void Renderer::setOption(const std::string& name, int64_t value)
+{
+    if (name == "traversal_variant") mImpl->traversalVariant = static_cast<int>(value);
+    else if (name == "refill_min") mImpl->optRefillMin = static_cast<uint32_t>(value);
+    else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
+    else if (name == "persistent_blocks") mImpl->persistentBlocks = mImpl->wideBlocks = static_cast<uint32_t>(value);
+    else throw std::invalid_argument("unknown option " + name);
+}
 void Renderer::setTiming(bool enabled) { mImpl->timing = enabled; }
 
 void Renderer::resetStats()

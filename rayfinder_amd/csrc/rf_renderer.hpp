@@ -115,6 +115,9 @@ public:
     void readTonemapped(uint32_t* dstBgra8);
 
     void        setCounting(bool enabled);
+    // Tuning knobs for A/B measurements inside one process ("traversal_variant": 0 = one ray per
+    // thread kernels, 1 = persistent waves with lane refill).  Results never depend on them.
+    void        setOption(const std::string& name, int64_t value);
     void        setTiming(bool enabled);
     void        resetStats();
     RenderStats stats();
