@@ -57,12 +57,13 @@ namespace
 
 struct PathStreams
 {
-    float4* rayO;    // origin.xyz (hit point after traceClosest), w = noise.x
-    float4* rayD;    // direction.xyz, w = cos(2 pi noise.y)
-    float4* thr;     // throughput.rgb, w = sin(2 pi noise.y)
+    float4* rayO;    // origin.xyz (hit point after traceClosest)
+    float4* rayD;    // direction.xyz
+    float4* thr;     // throughput.rgb
     float4* rad;     // radiance.rgb
     float4* hit;     // {triangle bits, u, v, -}
     float4* pending; // (throughput * solar radiance) * reflectance, waiting for visibility
+    float4* noise;   // {u.x, cos(2 pi u.y), sin(2 pi u.y), -}: the path's one blue-noise pair
 };
 
 struct DeviceCounters
@@ -96,18 +97,40 @@ __device__ __forceinline__ bool localPixelToXY(const FrameParams& fp, const uint
     return x < fp.width && y < fp.height;
 }
 
-// Append `slot` to `queue` for every lane with `keep`: one atomic per wave.
-__device__ __forceinline__ void waveAppend(bool keep, uint32_t slot, uint32_t* queue, uint32_t* count)
+// Block-wide append of up to ITEMS candidates per thread with ONE atomic per block.  A single
+// device-scope counter saturates near 90 atomics/us (MI355X_MICROARCH.md "dequeue"), so a
+// one-atomic-per-wave append made the shade and raygen launches atomic-bound (130 k waves per
+// launch = 1.5 ms); per block of 1024 entries it is 8 k atomics.  Must be reached by every thread of
+// the block.  Output order: wave-major, then item, then lane (stays local to the block's entries).
+constexpr int kItems = 4; // queue entries per thread in the per-entry kernels
+
+template<int ITEMS>
+__device__ __forceinline__ void blockAppend(const bool (&keep)[ITEMS], const uint32_t (&slot)[ITEMS], uint32_t* queue, uint32_t* count, uint32_t* sScratch)
 {
-    const unsigned long long mask = __ballot(keep);
-    if (mask == 0) return;
-    const uint32_t lane = __lane_id();
-    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    const int      leader = __ffsll(static_cast<long long>(mask)) - 1;
-    uint32_t       base = 0;
-    if (static_cast<int>(lane) == leader) base = atomicAdd(count, static_cast<uint32_t>(__popcll(mask)));
-    base = __shfl(base, leader);
-    if (keep) queue[base + prefix] = slot;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    uint32_t       offs[ITEMS];
+    uint32_t       waveTotal = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+    {
+        const unsigned long long mask = __ballot(keep[k]);
+        offs[k] = waveTotal + __popcll(mask & ((1ull << lane) - 1ull));
+        waveTotal += __popcll(mask);
+    }
+    if (lane == 0) sScratch[wave] = waveTotal;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const uint32_t total = sScratch[0] + sScratch[1] + sScratch[2] + sScratch[3];
+        sScratch[4] = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = sScratch[4];
+    for (uint32_t w = 0; w < wave; ++w) base += sScratch[w];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+        if (keep[k]) queue[base + offs[k]] = slot[k];
+    __syncthreads(); // sScratch may be reused by the next append
 }
 
 __device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
@@ -125,43 +148,50 @@ __device__ __forceinline__ uint32_t waveMax(uint32_t v)
 __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene scene, const uint32_t* tileIds, PathStreams ps,
                                                    uint32_t* queue, uint32_t* queueCount, DeviceCounters* counters)
 {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t total = fp.numSamples * fp.pixelsPadded;
-    bool           valid = slot < total;
-    uint32_t       x = 0, y = 0;
-    if (valid)
+    __shared__ uint32_t sScratch[8];
+    const uint32_t      total = fp.numSamples * fp.pixelsPadded;
+    bool                keep[kItems];
+    uint32_t            slots[kItems];
+    uint32_t            numValid = 0;
+#pragma unroll 1
+    for (int k = 0; k < kItems; ++k)
     {
-        const uint32_t lp = slot % fp.pixelsPadded;
-        valid = localPixelToXY(fp, tileIds, lp, x, y);
+        const uint32_t slot = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
+        bool           valid = slot < total;
+        uint32_t       x = 0, y = 0;
+        if (valid) valid = localPixelToXY(fp, tileIds, slot % fp.pixelsPadded, x, y);
+        if (valid)
+        {
+            const uint32_t frame = fp.firstFrame + slot / fp.pixelsPadded;
+            float          nx, ny;
+            animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
+
+            // fragment centre (wgsl:36-43); v runs down the image
+            const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(fp.width);
+            const float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(fp.height);
+            const float s = u + nx / static_cast<float>(fp.width);
+            const float t = (1.0f - v) + ny / static_cast<float>(fp.height);
+
+            const float phi = 2.0f * kPi * ny;
+            const float cosPhi = wCos(phi), sinPhi = wSin(phi);
+            const float r = rf_sqrt(nx);
+            const float lensX = fp.camera.lensRadius * (r * cosPhi);
+            const float lensY = fp.camera.lensRadius * (r * sinPhi);
+            const Vec3  origin = fp.camera.origin + (lensX * fp.camera.right + lensY * fp.camera.up);
+            const Vec3  dir = normalize(fp.camera.lowerLeftCorner + s * fp.camera.horizontal + t * fp.camera.vertical - origin);
+
+            ps.rayO[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+            ps.rayD[slot] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+            ps.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            ps.noise[slot] = make_float4(nx, cosPhi, sinPhi, 0.0f);
+            ++numValid;
+        }
+        keep[k] = valid;
+        slots[k] = slot;
     }
-    if (valid)
-    {
-        const uint32_t k = slot / fp.pixelsPadded;
-        const uint32_t frame = fp.firstFrame + k;
-        float          nx, ny;
-        animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
-
-        // fragment centre (wgsl:36-43); v runs down the image
-        const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(fp.width);
-        const float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(fp.height);
-        const float s = u + nx / static_cast<float>(fp.width);
-        const float t = (1.0f - v) + ny / static_cast<float>(fp.height);
-
-        const float phi = 2.0f * kPi * ny;
-        const float cosPhi = wCos(phi), sinPhi = wSin(phi);
-        const float r = rf_sqrt(nx);
-        const float lensX = fp.camera.lensRadius * (r * cosPhi);
-        const float lensY = fp.camera.lensRadius * (r * sinPhi);
-        const Vec3  origin = fp.camera.origin + (lensX * fp.camera.right + lensY * fp.camera.up);
-        const Vec3  dir = normalize(fp.camera.lowerLeftCorner + s * fp.camera.horizontal + t * fp.camera.vertical - origin);
-
-        ps.rayO[slot] = make_float4(origin.x, origin.y, origin.z, nx);
-        ps.rayD[slot] = make_float4(dir.x, dir.y, dir.z, cosPhi);
-        ps.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, sinPhi);
-        ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    waveAppend(valid, slot, queue, queueCount);
-    const unsigned long long n = waveSum(valid ? 1ull : 0ull);
+    blockAppend<kItems>(keep, slots, queue, queueCount, sScratch);
+    const unsigned long long n = waveSum(numValid);
     if (__lane_id() == 0 && n) atomicAdd(&counters->primaryRays, n);
 }
 
@@ -182,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
         ClosestHit     h;
         traverse<false, COUNT>(scene, vec3(o.x, o.y, o.z), vec3(d.x, d.y, d.z), kTMax, &sStack[threadIdx.x], h, tc);
         ps.hit[slot] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f);
-        if (h.triangle != kMiss) ps.rayO[slot] = make_float4(h.p.x, h.p.y, h.p.z, o.w);
+        if (h.triangle != kMiss) ps.rayO[slot] = make_float4(h.p.x, h.p.y, h.p.z, 0.0f);
     }
     if (COUNT)
     {
@@ -212,68 +242,86 @@ __device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, float nx, floa
 }
 
 __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
-                                                  const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t isLastBounce)
+                                                  const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
+                                                  uint32_t* missCount, uint32_t isLastBounce)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t count = *queueCount;
-    if (blockIdx.x * kBlock >= count) return;
-    bool     isHit = false;
-    uint32_t slot = 0;
-    if (i < count)
+    __shared__ uint32_t sScratch[8];
+    const uint32_t      count = *queueCount;
+    if (blockIdx.x * kItems * kBlock >= count) return; // whole block out of range (uniform)
+    bool     isHit[kItems], isMiss[kItems];
+    uint32_t slots[kItems];
+#pragma unroll 1
+    for (int k = 0; k < kItems; ++k)
     {
-        slot = queue[i];
+        const uint32_t i = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
+        isHit[k] = isMiss[k] = false;
+        slots[k] = 0;
+        if (i >= count) continue;
+        const uint32_t slot = queue[i];
+        slots[k] = slot;
         const float4   h = ps.hit[slot];
         const uint32_t tri = __float_as_uint(h.x);
-        const float4   thr4 = ps.thr[slot];
-        const float4   d4 = ps.rayD[slot];
-        const Vec3     throughput = vec3(thr4.x, thr4.y, thr4.z);
         if (tri == kMiss)
         {
-            // wgsl:212-228
-            const Vec3  v = vec3(d4.x, d4.y, d4.z);
-            const Vec3  s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
-            const float theta = wAcos(v.y);
-            const float gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
-            const Vec3  dome = vec3(skyRadiance(sky, theta, gamma, 0), skyRadiance(sky, theta, gamma, 1), skyRadiance(sky, theta, gamma, 2));
-            float4      rad4 = ps.rad[slot];
-            const Vec3  radiance = vec3(rad4.x, rad4.y, rad4.z) + throughput * dome;
-            ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            isMiss[k] = true; // the path ends in the sky: evaluated densely by kSky at the end of the batch
+            continue;
         }
-        else
+        isHit[k] = true;
+        const float4            thr4 = ps.thr[slot];
+        const float4            nz = ps.noise[slot];
+        const Vec3              throughput = vec3(thr4.x, thr4.y, thr4.z);
+        const float             nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
+        const VertexAttributes& va = scene.attributes[tri];
+        const float             b0 = 1.0f - h.y - h.z, b1 = h.y, b2 = h.z; // wgsl:515
+        const Vec3              n = (b0 * va.n0 + b1 * va.n1) + b2 * va.n2; // not normalised, wgsl:396
+        const float             uvx = (b0 * va.uv0.x + b1 * va.uv1.x) + b2 * va.uv2.x;
+        const float             uvy = (b0 * va.uv0.y + b1 * va.uv1.y) + b2 * va.uv2.y;
+        const Vec3              albedo = evalTexture(scene, va.textureIdx, uvx, uvy);
+
+        // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
+        const Vec3 lightDirection = sunSample(sky, nx, cosPhi, sinPhi);
+        const Vec3 lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
+        const Vec3 brdf = albedo * kFrac1Pi;
+        const Vec3 reflectance = brdf * dot(n, lightDirection);
+        const Vec3 pend = (throughput * lightIntensity) * reflectance;
+        ps.pending[slot] = make_float4(pend.x, pend.y, pend.z, 0.0f);
+
+        if (!isLastBounce)
         {
-            isHit = true;
-            const float             nx = ps.rayO[slot].w;
-            const float             cosPhi = d4.w, sinPhi = thr4.w;
-            const VertexAttributes& va = scene.attributes[tri];
-            const float             b0 = 1.0f - h.y - h.z, b1 = h.y, b2 = h.z; // wgsl:515
-            const Vec3              n = (b0 * va.n0 + b1 * va.n1) + b2 * va.n2; // not normalised, wgsl:396
-            const float             uvx = (b0 * va.uv0.x + b1 * va.uv1.x) + b2 * va.uv2.x;
-            const float             uvy = (b0 * va.uv0.y + b1 * va.uv1.y) + b2 * va.uv2.y;
-            const Vec3              albedo = evalTexture(scene, va.textureIdx, uvx, uvy);
-
-            // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
-            const Vec3 lightDirection = sunSample(sky, nx, cosPhi, sinPhi);
-            const Vec3 lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
-            const Vec3 brdf = albedo * kFrac1Pi;
-            const Vec3 reflectance = brdf * dot(n, lightDirection);
-            const Vec3 pend = (throughput * lightIntensity) * reflectance;
-            ps.pending[slot] = make_float4(pend.x, pend.y, pend.z, 0.0f);
-
-            if (!isLastBounce)
-            {
-                // cosine-weighted bounce about the interpolated normal, wgsl:209-211,294-301,582-592
-                const float sinTheta = rf_sqrt(1.0f - nx);
-                const Vec3  local = vec3(cosPhi * sinTheta, sinPhi * sinTheta, rf_sqrt(nx));
-                Vec3        bu, bv;
-                pixarOnb(n, bu, bv);
-                const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
-                const Vec3 t2 = throughput * albedo;
-                ps.rayD[slot] = make_float4(wi.x, wi.y, wi.z, cosPhi);
-                ps.thr[slot] = make_float4(t2.x, t2.y, t2.z, sinPhi);
-            }
+            // cosine-weighted bounce about the interpolated normal, wgsl:209-211,294-301,582-592
+            const float sinTheta = rf_sqrt(1.0f - nx);
+            const Vec3  local = vec3(cosPhi * sinTheta, sinPhi * sinTheta, rf_sqrt(nx));
+            Vec3        bu, bv;
+            pixarOnb(n, bu, bv);
+            const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
+            const Vec3 t2 = throughput * albedo;
+            ps.rayD[slot] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+            ps.thr[slot] = make_float4(t2.x, t2.y, t2.z, 0.0f);
         }
     }
-    waveAppend(isHit, slot, hitQueue, hitCount);
+    blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch);
+    blockAppend<kItems>(isMiss, slots, missQueue, missCount, sScratch);
+}
+
+// Paths that left the scene (at any bounce of this batch): radiance += throughput * sky
+// (wgsl:212-228,247-275).  A terminated path's direction, throughput and radiance stay in place
+// until the batch ends, and all its NEE terms have been added by then, so one dense launch over
+// the batch's miss list replaces a divergent branch in every shade launch.
+__global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, const uint32_t* missQueue, const uint32_t* missCount)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= *missCount) return;
+    const uint32_t slot = missQueue[i];
+    const float4   d4 = ps.rayD[slot];
+    const float4   thr4 = ps.thr[slot];
+    const Vec3     v = vec3(d4.x, d4.y, d4.z);
+    const Vec3     s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
+    const float    theta = wAcos(v.y);
+    const float    gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
+    const Vec3     dome = vec3(skyRadiance(sky, theta, gamma, 0), skyRadiance(sky, theta, gamma, 1), skyRadiance(sky, theta, gamma, 2));
+    const float4   rad4 = ps.rad[slot];
+    const Vec3     radiance = vec3(rad4.x, rad4.y, rad4.z) + vec3(thr4.x, thr4.y, thr4.z) * dome;
+    ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
 }
 
 template<bool COUNT>
@@ -289,8 +337,8 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
     {
         const uint32_t slot = queue[i];
         const float4   o = ps.rayO[slot];
-        const float    cosPhi = ps.rayD[slot].w, sinPhi = ps.thr[slot].w;
-        const Vec3     l = sunSample(sky, o.w, cosPhi, sinPhi);
+        const float4   nz = ps.noise[slot];
+        const Vec3     l = sunSample(sky, nz.x, nz.y, nz.z);
         ClosestHit     h;
         const bool     occluded = traverse<true, COUNT>(scene, vec3(o.x, o.y, o.z), l, kTMax, &sStack[threadIdx.x], h, tc);
         const float    visibility = occluded ? 0.0f : 1.0f;
@@ -314,235 +362,32 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent traversal: the production form of kTraceClosest / kTraceShadow.
-//
-// A wave is 64 independent rays whose trip counts differ by an order of magnitude (atrium: mean 62
-// node visits, tail > 300), and 19 visits in 20 are interior nodes.  Two things keep the lanes
-// busy without changing any ray's visit order (results and counters stay bit-identical):
-//   * lane refill -- a lane whose ray has finished takes the next ray of the wave's current chunk
-//     (chunks of kChunk queue entries are claimed with one atomic per chunk), so waves stay full
-//     until the queue is dry instead of idling behind their longest ray;
-//   * deferred leaves -- a lane that reaches a leaf parks on it; the wave keeps visiting interior
-//     nodes with the other lanes until fewer than kLeafVote of them are still descending, then all
-//     parked lanes run the Moller-Trumbore code together (instead of every step paying for both
-//     the interior and the leaf path).
-// Grid = resident blocks only (CUs x blocks/CU); each wave loops until the queue is exhausted.
+// Scheduling constants of the persistent traversal kernel (tuned on the atrium, tools/gpu_ab.py).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kChunk = 256;   // queue entries claimed per atomic
-constexpr uint32_t kRefillMin = 8; // refill once this many lanes are idle (or the wave is empty)
+constexpr uint32_t kChunk = 64;    // queue entries claimed per atomic (small: the tail is load balance)
+constexpr uint32_t kRefillMin = 16; // refill once this many lanes are idle
 constexpr uint32_t kLeafVote = 40; // leave the descent loop when fewer lanes than this are descending
 
 enum LaneState : uint32_t
 {
     kIdle = 0,    // no ray
-    kDescend = 1, // `current` is the next node to visit
-    kAtLeaf = 2,  // parked on a leaf (leafLink, leafCount)
+    kDescend = 1, // `current` is the next interior record to fetch
+    kAtLeaf = 2,  // parked on a leaf (leafWord)
     kDone = 3,    // ray finished, result not yet written
 };
 
-template<bool ANY_HIT, bool COUNT>
-__global__ __launch_bounds__(kBlock) void kTracePersistent(DeviceScene scene, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
-                                                            const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote)
-{
-    __shared__ uint32_t sStack[kLdsStack * kBlock];
-    const uint32_t      count = *queueCount;
-    const uint32_t      lane = __lane_id();
-
-    // wave-uniform work cursor
-    uint32_t chunkPos = 0, chunkEnd = 0;
-    bool     exhausted = count == 0;
-
-    // per-lane ray state
-    uint32_t  state = kIdle;
-    uint32_t  slot = 0, current = 0, leafLink = 0, leafCount = 0;
-    float     noiseX = 0.0f;
-    RayPrep   ray{};
-    float     rayTMax = kTMax;
-    LaneStack stack;
-    stack.lds = &sStack[threadIdx.x];
-    ClosestHit        best{};
-    bool              occluded = false;
-    TraversalCounters tc;
-
-    for (;;)
-    {
-        // ---- refill idle lanes
-        const unsigned long long idleMask = __ballot(state == kIdle);
-        const uint32_t           idleCount = __popcll(idleMask);
-        if (!exhausted && idleCount >= refillMin)
-        {
-            if (chunkPos == chunkEnd)
-            {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, kChunk);
-                base = __shfl(base, 0);
-                if (base >= count)
-                {
-                    exhausted = true;
-                    chunkPos = chunkEnd = 0;
-                }
-                else
-                {
-                    chunkPos = base;
-                    chunkEnd = min(base + kChunk, count);
-                }
-            }
-            const uint32_t take = min(idleCount, chunkEnd - chunkPos);
-            const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
-            if (state == kIdle && rankInIdle < take)
-            {
-                slot = queue[chunkPos + rankInIdle];
-                const float4 o = ps.rayO[slot];
-                Vec3         dir;
-                if (ANY_HIT)
-                {
-                    dir = sunSample(sky, o.w, ps.rayD[slot].w, ps.thr[slot].w);
-                }
-                else
-                {
-                    const float4 d = ps.rayD[slot];
-                    dir = vec3(d.x, d.y, d.z);
-                }
-                ray = prepareRay(vec3(o.x, o.y, o.z), dir);
-                noiseX = o.w;
-                rayTMax = kTMax;
-                current = 0;
-                stack.size = 0;
-                best.triangle = kMiss;
-                occluded = false;
-                state = kDescend;
-            }
-            chunkPos += take;
-        }
-        if (__ballot(state != kIdle) == 0ull)
-        {
-            if (exhausted) break;
-            continue;
-        }
-
-        // ---- descend: interior-node visits only, until too few lanes are still descending
-        do
-        {
-            if (state == kDescend)
-            {
-                const float4 lo = scene.nodes[2 * current];
-                const float4 hi = scene.nodes[2 * current + 1];
-                if (COUNT) ++tc.nodesVisited;
-                bool needPop = true;
-                if (slabTest(ray, lo, hi, rayTMax))
-                {
-                    const uint32_t link = __float_as_uint(lo.w);
-                    const uint32_t meta = __float_as_uint(hi.w);
-                    const uint32_t axis = meta & 3u;
-                    if (axis == kLeafAxis)
-                    {
-                        leafLink = link;
-                        leafCount = meta >> 2;
-                        state = kAtLeaf;
-                        needPop = false;
-                    }
-                    else
-                    {
-                        const uint32_t neg = axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ);
-                        const uint32_t deferred = neg ? current + 1 : link;
-                        current = neg ? link : current + 1;
-                        needPop = !stack.push(deferred); // overflow: abandon the ray
-                        if (COUNT) tc.stackHigh = max(tc.stackHigh, static_cast<uint32_t>(stack.size));
-                        if (needPop) stack.size = 0;
-                    }
-                }
-                if (needPop)
-                {
-                    if (stack.size == 0) state = kDone;
-                    else current = stack.pop();
-                }
-            }
-        } while (__popcll(__ballot(state == kDescend)) >= leafVote);
-
-        // ---- leaves: all parked lanes intersect their triangles together
-        if (state == kAtLeaf)
-        {
-            bool finished = false;
-            for (uint32_t i = 0; i < leafCount; ++i)
-            {
-                const uint32_t tri = leafLink + i;
-                const float4   a = scene.triangles[3 * tri];
-                const float4   b = scene.triangles[3 * tri + 1];
-                const float4   c = scene.triangles[3 * tri + 2];
-                if (COUNT) ++tc.triangleTests;
-                TriangleHit th;
-                const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
-                if (intersectTriangle(ray, p0, p1, p2, rayTMax, th))
-                {
-                    if (ANY_HIT)
-                    {
-                        occluded = true;
-                        finished = true;
-                        break;
-                    }
-                    rayTMax = th.t;
-                    const Vec3 e1 = p1 - p0, e2 = p2 - p0;
-                    const Vec3 p = p0 + th.u * e1 + th.v * e2;
-                    const Vec3 n = normalize(cross(e1, e2));
-                    best.p = offsetRay(p, n);
-                    best.t = th.t;
-                    best.u = th.u;
-                    best.v = th.v;
-                    best.triangle = tri;
-                }
-            }
-            if (finished || stack.size == 0) state = kDone;
-            else
-            {
-                current = stack.pop();
-                state = kDescend;
-            }
-        }
-
-        // ---- write back finished rays
-        if (state == (kDone))
-        {
-            if (ANY_HIT)
-            {
-                const float  visibility = occluded ? 0.0f : 1.0f;
-                const float4 pend = ps.pending[slot];
-                const float4 rad4 = ps.rad[slot];
-                const Vec3   add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
-                const Vec3   radiance = vec3(rad4.x, rad4.y, rad4.z) + add;
-                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            }
-            else
-            {
-                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, 0.0f);
-                if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, noiseX);
-            }
-            state = kIdle;
-        }
-    }
-
-    if (COUNT)
-    {
-        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
-        const uint32_t           sh = waveMax(tc.stackHigh);
-        if (lane == 0)
-        {
-            atomicAdd(ANY_HIT ? &counters->shadowNodeVisits : &counters->closestNodeVisits, nv);
-            atomicAdd(ANY_HIT ? &counters->shadowTriangleTests : &counters->closestTriangleTests, tt);
-            if (!ANY_HIT) atomicMax(&counters->stackHigh, sh);
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
-}
-
 // ------------------------------------------------------------------------------------------------
 // kTraceWide: persistent traversal over the 64-byte children-in-parent layout (rf_wide.hpp).
-// Same scheduling as kTracePersistent (chunked queue claims, lane refill, deferred leaves); one
-// dependent fetch now tests two boxes and leaf nodes are never fetched.
+// Scheduling: a wave is 64 independent rays whose trip counts differ by an order of magnitude, and
+// most visits are interior nodes.  Waves are persistent (grid = resident blocks), claim `chunk`
+// queue entries per atomic, refill lanes whose ray has finished, and park lanes that reach a leaf
+// until fewer than `leafVote` lanes are still descending, so that the Moller-Trumbore code runs for
+// many lanes at once.  None of this changes any ray's own visit order.
 // ------------------------------------------------------------------------------------------------
 template<bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
                                                       const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin,
-                                                      uint32_t leafVote)
+                                                      uint32_t leafVote, uint32_t chunk)
 {
     __shared__ uint2 sStack[kWideLdsStack * kBlock];
     const uint32_t   count = *queueCount;
@@ -553,7 +398,6 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
 
     uint32_t  state = kIdle;
     uint32_t  slot = 0, current = 0, leafWord = 0;
-    float     noiseX = 0.0f;
     RayPrep   ray{};
     float     rayTMax = kTMax;
     WideStack stack;
@@ -600,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
             if (chunkPos == chunkEnd)
             {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, kChunk);
+                if (lane == 0) base = atomicAdd(cursor, chunk);
                 base = __shfl(base, 0);
                 if (base >= count)
                 {
@@ -610,7 +454,7 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
                 else
                 {
                     chunkPos = base;
-                    chunkEnd = min(base + kChunk, count);
+                    chunkEnd = min(base + chunk, count);
                 }
             }
             const uint32_t take = min(idleCount, chunkEnd - chunkPos);
@@ -622,7 +466,8 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
                 Vec3         dir;
                 if (ANY_HIT)
                 {
-                    dir = sunSample(sky, o.w, ps.rayD[slot].w, ps.thr[slot].w);
+                    const float4 nz = ps.noise[slot];
+                    dir = sunSample(sky, nz.x, nz.y, nz.z);
                 }
                 else
                 {
@@ -630,7 +475,6 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
                     dir = vec3(d.x, d.y, d.z);
                 }
                 ray = prepareRay(vec3(o.x, o.y, o.z), dir);
-                noiseX = o.w;
                 rayTMax = kTMax;
                 stack.size = 0;
                 best.triangle = kMiss;
@@ -768,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
             else
             {
                 ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, 0.0f);
-                if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, noiseX);
+                if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, 0.0f);
             }
             state = kIdle;
         }
@@ -993,14 +837,14 @@ struct Renderer::Impl
     bool                    imageDirty = true; // needs zeroing before the next sample
 
     uint64_t                maxPaths = 0;
-    DeviceBuffer<float4>    sRayO, sRayD, sThr, sRad, sHit, sPending;
-    DeviceBuffer<uint32_t>  queueA, queueB, queueCounts;
+    DeviceBuffer<float4>    sRayO, sRayD, sThr, sRad, sHit, sPending, sNoise;
+    DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
 
     bool counting = false, timing = false;
-    int      traversalVariant = 2; // 0 = one ray per thread, 1 = persistent + refill (32-B nodes), 2 = persistent, 64-B wide nodes
-    uint32_t persistentBlocks = 0, wideBlocks = 0;
-    uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote;
+    int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
+    uint32_t wideBlocks = 0;
+    uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     RenderStats hostStats;
 
     struct TimedLaunch
@@ -1041,8 +885,10 @@ struct Renderer::Impl
         sRad.alloc(paths);
         sHit.alloc(paths);
         sPending.alloc(paths);
+        sNoise.alloc(paths);
         queueA.alloc(paths);
         queueB.alloc(paths);
+        missQueue.alloc(paths);
     }
 
     void configureShard()
@@ -1139,26 +985,33 @@ struct Renderer::Impl
 
         const uint64_t paths = static_cast<uint64_t>(numSamples) * fp.pixelsPadded;
         const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
-        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr};
+        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr};
         const uint32_t numBounces = fp.numBounces;
 
         BatchTiming bt{getEvent(), getEvent(), numSamples};
         RF_HIP(hipEventRecord(bt.start, stream));
 
-        // [0, numBounces+1]: queue lengths; then two work cursors per bounce for the persistent kernels
-        if (queueCounts.count < 3 * numBounces + 4) queueCounts.alloc(3 * numBounces + 4);
-        uint32_t* const cursors = queueCounts.ptr + numBounces + 2;
+        // device words, one per 64-byte line (they are all hot atomics): [0, B]: queue lengths per
+        // bounce; [B+1]: miss-list length; then two work cursors per bounce for the traversal launches
+        constexpr uint32_t kLine = 16;
+        if (queueCounts.count < kLine * (3 * numBounces + 4)) queueCounts.alloc(kLine * (3 * numBounces + 4));
+        uint32_t* const missCount = queueCounts.ptr + kLine * (numBounces + 1);
+        uint32_t* const cursors = queueCounts.ptr + kLine * (numBounces + 2);
+        const uint32_t  itemBlocks = static_cast<uint32_t>((paths + kBlock * kItems - 1) / (kBlock * kItems));
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
 
         uint32_t* qIn = queueA.ptr;
         uint32_t* qOut = queueB.ptr;
         launchTimed(0, [&] {
-            hipLaunchKernelGGL(kRaygen, dim3(blocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
+            hipLaunchKernelGGL(kRaygen, dim3(itemBlocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
         });
+        const dim3 persistentGrid(std::min(blocks, wideBlocks));
         for (uint32_t bounce = 1; bounce <= numBounces; ++bounce)
         {
-            uint32_t* countIn = queueCounts.ptr + (bounce - 1);
-            uint32_t* countOut = queueCounts.ptr + bounce;
+            uint32_t* countIn = queueCounts.ptr + kLine * (bounce - 1);
+            uint32_t* countOut = queueCounts.ptr + kLine * bounce;
+            uint32_t* cursorClosest = cursors + kLine * 2 * (bounce - 1);
+            uint32_t* cursorShadow = cursorClosest + kLine;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
                 {
@@ -1167,25 +1020,15 @@ struct Renderer::Impl
                     else
                         hipLaunchKernelGGL(kTraceClosest<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
                 }
-                else if (traversalVariant == 2)
-                {
-                    const dim3 grid(std::min(blocks, wideBlocks));
-                    if (counting)
-                        hipLaunchKernelGGL((kTraceWide<false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
-                    else
-                        hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
-                }
+                else if (counting)
+                    hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
                 else
-                {
-                    const dim3 grid(std::min(blocks, persistentBlocks));
-                    if (counting)
-                        hipLaunchKernelGGL((kTracePersistent<false, true>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
-                    else
-                        hipLaunchKernelGGL((kTracePersistent<false, false>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, cursors + 2 * (bounce - 1), counters.ptr, optRefillMin, optLeafVote);
-                }
+                    hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
             });
             launchTimed(2, [&] {
-                hipLaunchKernelGGL(kShade, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, qOut, countOut,
+                hipLaunchKernelGGL(kShade, dim3(itemBlocks), dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
                                    bounce == numBounces ? 1u : 0u);
             });
             launchTimed(3, [&] {
@@ -1196,25 +1039,16 @@ struct Renderer::Impl
                     else
                         hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
                 }
-                else if (traversalVariant == 2)
-                {
-                    const dim3 grid(std::min(blocks, wideBlocks));
-                    if (counting)
-                        hipLaunchKernelGGL((kTraceWide<true, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
-                    else
-                        hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
-                }
+                else if (counting)
+                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
                 else
-                {
-                    const dim3 grid(std::min(blocks, persistentBlocks));
-                    if (counting)
-                        hipLaunchKernelGGL((kTracePersistent<true, true>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
-                    else
-                        hipLaunchKernelGGL((kTracePersistent<true, false>), grid, dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, cursors + 2 * (bounce - 1) + 1, counters.ptr, optRefillMin, optLeafVote);
-                }
+                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
             });
             std::swap(qIn, qOut);
         }
+        launchTimed(2, [&] { hipLaunchKernelGGL(kSky, dim3(blocks), dim3(kBlock), 0, stream, sky, ps, missQueue.ptr, missCount); });
         launchTimed(4, [&] {
             hipLaunchKernelGGL(kAccumulate, dim3((fp.pixelsPadded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, fp, tileIds.ptr, ps, image);
         });
@@ -1308,8 +1142,6 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         hipDeviceProp_t prop{};
         RF_HIP(hipGetDeviceProperties(&prop, m.device));
         int perCu = 0;
-        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTracePersistent<false, false>, kBlock, 0));
-        m.persistentBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
         RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, 0));
         m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
         if (const char* v = std::getenv("RF_TRAVERSAL_VARIANT")) m.traversalVariant = std::atoi(v);
@@ -1496,7 +1328,8 @@ void Renderer::setOption(const std::string& name, int64_t value)
     if (name == "traversal_variant") mImpl->traversalVariant = static_cast<int>(value);
     else if (name == "refill_min") mImpl->optRefillMin = static_cast<uint32_t>(value);
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
-    else if (name == "persistent_blocks") mImpl->persistentBlocks = mImpl->wideBlocks = static_cast<uint32_t>(value);
+    else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);
+    else if (name == "persistent_blocks") mImpl->wideBlocks = static_cast<uint32_t>(value);
     else throw std::invalid_argument("unknown option " + name);
 }
 void Renderer::setTiming(bool enabled) { mImpl->timing = enabled; }

@@ -22,7 +22,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
 for r in rows:
-    k = r.get("Kernel_Name", "?").split("(")[0][:60]
+    k = r.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").replace("rf::", "").replace("void ", "").split("(")[0][:60]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r.get("Dispatch_Id"))
 print("counters:", sys.argv[2])
 for k in sorted(agg, key=lambda k: -len(n[k])):
