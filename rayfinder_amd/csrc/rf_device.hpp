@@ -142,30 +142,6 @@ struct TraversalCounters
     uint32_t stackHigh = 0;
 };
 
-// Per-lane traversal stack: LDS first, scratch beyond.
-struct LaneStack
-{
-    uint32_t* lds; // &shared[0][threadIdx.x], stride kBlock
-    uint32_t  spill[kSpillStack];
-    int       size = 0;
-
-    // Returns false when the tree is deeper than kLdsStack + kSpillStack (the reference is
-    // undefined past 32 entries); the caller then abandons the ray.
-    __device__ __forceinline__ bool push(uint32_t v)
-    {
-        if (size < kLdsStack) lds[size * kBlock] = v;
-        else if (size - kLdsStack < kSpillStack) spill[size - kLdsStack] = v;
-        else return false;
-        ++size;
-        return true;
-    }
-    __device__ __forceinline__ uint32_t pop()
-    {
-        --size;
-        return size < kLdsStack ? lds[size * kBlock] : spill[size - kLdsStack];
-    }
-};
-
 // One ray, the reference's visit order.  ANY_HIT: return at the first accepted triangle
 // (shadowRay); otherwise keep the closest (rayIntersectBvh).  COUNT: maintain counters.
 template<bool ANY_HIT, bool COUNT>
@@ -173,8 +149,10 @@ __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, 
                                          uint32_t* ldsStackLane, ClosestHit& out, TraversalCounters& counters)
 {
     const RayPrep ray = prepareRay(origin, direction);
-    LaneStack     stack;
-    stack.lds = ldsStackLane;
+    // stack: first kLdsStack entries in LDS (ldsStackLane[depth * kBlock]), the rest in scratch;
+    // size and pointer are plain locals so they stay in registers
+    uint32_t spill[kSpillStack];
+    int      stackSize = 0;
     uint32_t current = 0;
     bool     found = false;
     out.triangle = kMiss;
@@ -223,15 +201,21 @@ __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, 
                 const uint32_t neg = axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ);
                 const uint32_t deferred = neg ? current + 1 : link;
                 current = neg ? link : current + 1;
-                if (!stack.push(deferred)) break;
-                if (COUNT) counters.stackHigh = max(counters.stackHigh, static_cast<uint32_t>(stack.size));
+                if (stackSize < kLdsStack) ldsStackLane[stackSize * kBlock] = deferred;
+                else if (stackSize - kLdsStack < kSpillStack) spill[stackSize - kLdsStack] = deferred;
+                else break; // deeper than kLdsStack + kSpillStack: abandon the ray (reference: undefined past 32)
+                ++stackSize;
+                if (COUNT) counters.stackHigh = max(counters.stackHigh, static_cast<uint32_t>(stackSize));
                 advance = true;
             }
         }
         if (!advance)
         {
-            if (stack.size == 0) break;
-            current = stack.pop();
+            if (stackSize == 0) break;
+            --stackSize;
+            current = ldsStackLane[min(stackSize, kLdsStack - 1) * kBlock]; // see kTraceWide's pop()
+            asm volatile("" : "+v"(current));
+            if (stackSize >= kLdsStack) current = spill[stackSize - kLdsStack];
         }
     }
     return found;

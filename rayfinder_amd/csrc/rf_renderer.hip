@@ -384,8 +384,14 @@ enum LaneState : uint32_t
 // until fewer than `leafVote` lanes are still descending, so that the Moller-Trumbore code runs for
 // many lanes at once.  None of this changes any ray's own visit order.
 // ------------------------------------------------------------------------------------------------
-template<bool ANY_HIT, bool COUNT>
-__global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
+// NEAREST_FIRST (any-hit only): visit the child with the smaller slab tmin first instead of the
+// reference's split-axis order.  A shadow ray's answer is "does ANY triangle of any reachable leaf
+// intersect", and with the fixed rayTMax of shadowRay (wgsl:323-368) the set of reachable leaves
+// does not depend on the visit order, so the visibility bit is identical while occluded rays
+// terminate after fewer fetches.  (Closest-hit keeps the reference order: ties in t are resolved
+// by visit order.)
+template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false>
+__global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
                                                       const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin,
                                                       uint32_t leafVote, uint32_t chunk)
 {
@@ -400,8 +406,29 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
     uint32_t  slot = 0, current = 0, leafWord = 0;
     RayPrep   ray{};
     float     rayTMax = kTMax;
-    WideStack stack;
-    stack.lds = &sStack[threadIdx.x];
+    // Traversal stack of (child word, tmin) pairs: the first kWideLdsStack entries of every lane in
+    // LDS ([depth][lane], conflict-free b64 accesses), deeper ones in scratch.  Kept as separate
+    // locals (not a struct holding the spill array) so that the stack size and the LDS address stay
+    // in registers and the accesses are ds_* / scratch_*, not flat_* through the texture addresser.
+    uint2 spill[kWideSpillStack];
+    int   stackSize = 0;
+    auto  push = [&](uint32_t word, float tmin) -> bool {
+        const uint2 e = make_uint2(word, __float_as_uint(tmin));
+        if (stackSize < kWideLdsStack) sStack[stackSize * kBlock + threadIdx.x] = e;
+        else if (stackSize - kWideLdsStack < kWideSpillStack) spill[stackSize - kWideLdsStack] = e;
+        else return false;
+        ++stackSize;
+        return true;
+    };
+    auto pop = [&]() -> uint2 {
+        --stackSize;
+        // unconditional LDS read + conditional scratch read: an if/else of the two would be
+        // if-converted into a pointer select and a flat_load
+        uint2 e = sStack[min(stackSize, kWideLdsStack - 1) * kBlock + threadIdx.x];
+        asm volatile("" : "+v"(e.x), "+v"(e.y)); // pin the ds_read: keeps the two address spaces apart
+        if (stackSize >= kWideLdsStack) e = spill[stackSize - kWideLdsStack];
+        return e;
+    };
     ClosestHit        best{};
     bool              occluded = false;
     TraversalCounters tc;
@@ -410,13 +437,13 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
     auto popNext = [&]() {
         for (;;)
         {
-            if (stack.size == 0)
+            if (stackSize == 0)
             {
                 state = kDone;
                 return;
             }
-            const uint2 e = stack.pop();
-            if (COUNT) ++tc.nodesVisited;
+            const uint2 e = pop();
+            if (COUNT && !NEAREST_FIRST) ++tc.nodesVisited;
             if (__uint_as_float(e.y) < rayTMax)
             {
                 if (e.x & kWideLeafBit)
@@ -476,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
                 }
                 ray = prepareRay(vec3(o.x, o.y, o.z), dir);
                 rayTMax = kTMax;
-                stack.size = 0;
+                stackSize = 0;
                 best.triangle = kMiss;
                 occluded = false;
                 // the root visit (wgsl:379-382)
@@ -511,28 +538,31 @@ __global__ __launch_bounds__(kBlock) void kTraceWide(DeviceScene scene, WideScen
                 const float4*  n = wide.nodes + 4 * static_cast<size_t>(current);
                 const float4   a0 = n[0], a1 = n[1], b0 = n[2], b1 = n[3];
                 const uint32_t axis = __float_as_uint(a1.w) & 3u;
-                const uint32_t neg = axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ);
                 float          t0, t1;
                 const bool     ok0 = slabBounds(ray, a0, a1, t0);
                 const bool     ok1 = slabBounds(ray, b0, b1, t1);
+                const uint32_t neg = NEAREST_FIRST ? static_cast<uint32_t>(ok1 && (!ok0 || t1 < t0))
+                                                   : (axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ));
                 // reference order: dirNeg[axis] ? second child first : first child first
                 const uint32_t nearWord = __float_as_uint(neg ? b0.w : a0.w), farWord = __float_as_uint(neg ? a0.w : b0.w);
                 const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
                 const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
                 bool           overflow = false;
-                if (COUNT)
+                if (COUNT && !NEAREST_FIRST)
                 {
-                    overflow = !stack.push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
-                    tc.stackHigh = max(tc.stackHigh, static_cast<uint32_t>(stack.size));
+                    // reference bookkeeping: every far child is pushed and counted when popped
+                    overflow = !push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
+                    tc.stackHigh = max(tc.stackHigh, static_cast<uint32_t>(stackSize));
                     ++tc.nodesVisited; // the near child
                 }
-                else if (okFar)
+                else
                 {
-                    overflow = !stack.push(farWord, tFar);
+                    if (okFar) overflow = !push(farWord, tFar);
+                    if (COUNT) tc.nodesVisited += 2; // this build counts box tests
                 }
                 if (overflow)
                 {
-                    stack.size = 0; // deeper than 96: abandon the ray
+                    stackSize = 0; // deeper than 96: abandon the ray
                     state = kDone;
                 }
                 else if (okNear && tNear < rayTMax)
@@ -844,6 +874,7 @@ struct Renderer::Impl
     bool counting = false, timing = false;
     int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
     uint32_t wideBlocks = 0;
+    bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     RenderStats hostStats;
 
@@ -1038,6 +1069,15 @@ struct Renderer::Impl
                         hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
                     else
                         hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                }
+                else if (shadowNearestFirst)
+                {
+                    if (counting)
+                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk);
+                    else
+                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk);
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
@@ -1329,6 +1369,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "refill_min") mImpl->optRefillMin = static_cast<uint32_t>(value);
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);
+    else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "persistent_blocks") mImpl->wideBlocks = static_cast<uint32_t>(value);
     else throw std::invalid_argument("unknown option " + name);
 }

@@ -108,28 +108,5 @@ __device__ __forceinline__ bool slabBounds(const RayPrep& r, float4 lo, float4 h
     return tmax > 0.0f;
 }
 
-// Per-lane stack of (child word, tmin): LDS first ([depth][lane] uint2: conflict-free b64
-// accesses), scratch beyond.
-struct WideStack
-{
-    uint2* lds; // &shared[threadIdx.x], stride kBlock
-    uint2  spill[kWideSpillStack];
-    int    size = 0;
-
-    __device__ __forceinline__ bool push(uint32_t word, float tmin)
-    {
-        const uint2 e = make_uint2(word, __float_as_uint(tmin));
-        if (size < kWideLdsStack) lds[size * kBlock] = e;
-        else if (size - kWideLdsStack < kWideSpillStack) spill[size - kWideLdsStack] = e;
-        else return false;
-        ++size;
-        return true;
-    }
-    __device__ __forceinline__ uint2 pop()
-    {
-        --size;
-        return size < kWideLdsStack ? lds[size * kBlock] : spill[size - kWideLdsStack];
-    }
-};
 #endif
 } // namespace rf

@@ -167,16 +167,32 @@ def test_lens_sampling_and_other_sky_parameters(duck_pt, duck_oracle):
 
 def test_counting_build_matches_oracle_counts(duck_pt, duck_oracle):
     W, H, spp, bounces = 128, 96, 4, 4
-    r, params = _renderer(duck_pt, W, H, spp, bounces)
-    r.set_counting(True)
-    r.render(spp)
-    s = r.stats()
-    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
-    _, st = orc.render(duck_oracle.scene, rp, 0, spp)
-    assert s["closest_node_visits"] == st.closestNodeVisits and s["closest_triangle_tests"] == st.closestTriTests
-    assert s["shadow_node_visits"] == st.shadowNodeVisits and s["shadow_triangle_tests"] == st.shadowTriTests
-    assert s["stack_high_water"] == st.stackHigh
-    assert s["primary_rays"] == W * H * spp
+    rp = None
+    images = {}
+    for variant, nearest_first in ((2, 0), (0, 0), (2, 1)):
+        r, params = _renderer(duck_pt, W, H, spp, bounces)
+        r.set_option("traversal_variant", variant)          # 2: 64-B wide nodes (production), 0: 32-B nodes
+        r.set_option("shadow_nearest_first", nearest_first)  # 0: the reference's child order for shadow rays
+        r.set_counting(True)
+        r.render(spp)
+        s = r.stats()
+        images[(variant, nearest_first)] = r.read_accumulation()[0]
+        if rp is None:
+            rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+            _, st = orc.render(duck_oracle.scene, rp, 0, spp)
+        # closest-hit traversal always follows the reference's visit order: counts are exact
+        assert s["closest_node_visits"] == st.closestNodeVisits and s["closest_triangle_tests"] == st.closestTriTests
+        assert s["stack_high_water"] == st.stackHigh
+        assert s["primary_rays"] == W * H * spp and s["shadow_rays"] == st.shadowRays
+        if not nearest_first:
+            assert s["shadow_node_visits"] == st.shadowNodeVisits and s["shadow_triangle_tests"] == st.shadowTriTests
+        else:
+            # production default: shadow rays visit the nearer child first.  The visibility bit is order
+            # independent (identical image below); this build counts box tests, and needs fewer of them.
+            assert 0 < s["shadow_node_visits"] < 1.2 * st.shadowNodeVisits
+        r.close()
+    assert np.array_equal(bits(images[(2, 0)]), bits(images[(0, 0)]))
+    assert np.array_equal(bits(images[(2, 0)]), bits(images[(2, 1)]))
 
 
 # ------------------------------------------------------------------ renderer state machine

@@ -26,7 +26,7 @@ for rd in range(rounds):
         if len(parts) > 1: r.set_option("refill_min", parts[1])
         if len(parts) > 2: r.set_option("leaf_vote", parts[2])
         if len(parts) > 3: r.set_option("chunk", parts[3])
-        if len(parts) > 4: r.set_option("persistent_blocks", parts[4])
+        if len(parts) > 4: r.set_option("shadow_nearest_first", parts[4])
         expo *= 0.99
         r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, b, rf.make_sky(), expo))
         # frameCount must be a multiple of spp for identical sample sets: pad
