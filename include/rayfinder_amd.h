@@ -112,6 +112,7 @@ typedef struct rf_stats
     uint32_t stack_high_water, reserved;
     double   ms_raygen, ms_closest, ms_shade, ms_shadow, ms_accumulate; /* while timing is enabled */
     uint32_t launches_raygen, launches_closest, launches_shade, launches_shadow, launches_accumulate, reserved2;
+    uint64_t closest_record_fetches, shadow_record_fetches; /* 64-byte BVH records fetched (counting build) */
 } rf_stats;
 
 typedef struct rf_renderer rf_renderer;

@@ -62,7 +62,8 @@ class Stats(C.Structure):
                 ("ms_raygen", C.c_double), ("ms_closest", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
                 ("ms_accumulate", C.c_double),
                 ("launches_raygen", C.c_uint32), ("launches_closest", C.c_uint32), ("launches_shade", C.c_uint32),
-                ("launches_shadow", C.c_uint32), ("launches_accumulate", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("launches_shadow", C.c_uint32), ("launches_accumulate", C.c_uint32), ("reserved2", C.c_uint32),
+                ("closest_record_fetches", C.c_uint64), ("shadow_record_fetches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}

@@ -262,6 +262,8 @@ int rf_renderer_get_stats(rf_renderer* r, rf_stats* out)
         out->launches_shade = s.launchesShade;
         out->launches_shadow = s.launchesShadow;
         out->launches_accumulate = s.launchesAccumulate;
+        out->closest_record_fetches = s.closestRecordFetches;
+        out->shadow_record_fetches = s.shadowRecordFetches;
         return RF_OK;
     });
 }

@@ -72,6 +72,7 @@ struct DeviceCounters
     unsigned long long closestNodeVisits, closestTriangleTests, shadowNodeVisits, shadowTriangleTests;
     unsigned int       stackHigh;
     unsigned int       pad;
+    unsigned long long closestRecordFetches, shadowRecordFetches; // 64-byte wide records actually fetched (counting build)
 };
 
 struct FrameParams
@@ -364,9 +365,12 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
 // ------------------------------------------------------------------------------------------------
 // Scheduling constants of the persistent traversal kernel (tuned on the atrium, tools/gpu_ab.py).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kChunk = 64;    // queue entries claimed per atomic (small: the tail is load balance)
+constexpr uint32_t kChunk = 128;   // queue entries claimed per atomic (small enough that the tail stays balanced)
+constexpr uint32_t kShards = 16;   // work cursors per launch, one 64-byte line each: a single cursor
+                                   // saturates near 90 claims/us (8 M rays / 64 per 1.2 ms = 100/us)
+constexpr uint32_t kLineWords = 16;
 constexpr uint32_t kRefillMin = 16; // refill once this many lanes are idle
-constexpr uint32_t kLeafVote = 40; // leave the descent loop when fewer lanes than this are descending
+constexpr uint32_t kLeafVote = 32; // leave the descent loop when fewer lanes than this are descending
 
 enum LaneState : uint32_t
 {
@@ -399,8 +403,12 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
 
-    uint32_t chunkPos = 0, chunkEnd = 0;
-    bool     exhausted = count == 0;
+    // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
+    // shard of its block and moves on round-robin when a shard is dry.
+    const uint32_t shardLen = ((count + kShards - 1) / kShards + chunk - 1) / chunk * chunk;
+    uint32_t       shard = blockIdx.x % kShards, shardsTried = 0;
+    uint32_t       chunkPos = 0, chunkEnd = 0;
+    bool           exhausted = count == 0;
 
     uint32_t  state = kIdle;
     uint32_t  slot = 0, current = 0, leafWord = 0;
@@ -432,6 +440,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
     ClosestHit        best{};
     bool              occluded = false;
     TraversalCounters tc;
+    uint32_t          recordFetches = 0;
 
     // Pop entries until one passes `tmin < rayTMax` (the reference's box test at pop time).
     auto popNext = [&]() {
@@ -468,20 +477,21 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
         const uint32_t           idleCount = __popcll(idleMask);
         if (!exhausted && idleCount >= refillMin)
         {
-            if (chunkPos == chunkEnd)
+            while (chunkPos == chunkEnd && !exhausted)
             {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, chunk);
-                base = __shfl(base, 0);
-                if (base >= count)
+                const uint32_t shardBegin = shard * shardLen, shardEnd = min(shardBegin + shardLen, count);
+                uint32_t       base = 0;
+                if (lane == 0) base = shardBegin < count ? atomicAdd(cursor + shard * kLineWords, chunk) : shardLen;
+                base = shardBegin + __shfl(base, 0);
+                if (base >= shardEnd)
                 {
-                    exhausted = true;
-                    chunkPos = chunkEnd = 0;
+                    shard = (shard + 1) % kShards;
+                    if (++shardsTried == kShards) exhausted = true;
                 }
                 else
                 {
                     chunkPos = base;
-                    chunkEnd = min(base + chunk, count);
+                    chunkEnd = min(base + chunk, shardEnd);
                 }
             }
             const uint32_t take = min(idleCount, chunkEnd - chunkPos);
@@ -535,6 +545,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
         {
             if (state == kDescend)
             {
+                if (COUNT) ++recordFetches;
                 const float4*  n = wide.nodes + 4 * static_cast<size_t>(current);
                 const float4   a0 = n[0], a1 = n[1], b0 = n[2], b1 = n[3];
                 const uint32_t axis = __float_as_uint(a1.w) & 3u;
@@ -658,6 +669,8 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
             atomicAdd(ANY_HIT ? &counters->shadowTriangleTests : &counters->closestTriangleTests, tt);
             if (!ANY_HIT) atomicMax(&counters->stackHigh, sh);
         }
+        const unsigned long long rf = waveSum(recordFetches);
+        if (lane == 0) atomicAdd(ANY_HIT ? &counters->shadowRecordFetches : &counters->closestRecordFetches, rf);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
 }
@@ -1024,8 +1037,9 @@ struct Renderer::Impl
 
         // device words, one per 64-byte line (they are all hot atomics): [0, B]: queue lengths per
         // bounce; [B+1]: miss-list length; then two work cursors per bounce for the traversal launches
-        constexpr uint32_t kLine = 16;
-        if (queueCounts.count < kLine * (3 * numBounces + 4)) queueCounts.alloc(kLine * (3 * numBounces + 4));
+        constexpr uint32_t kLine = kLineWords;
+        const uint32_t words = kLine * (numBounces + 2) + kLine * kShards * 2 * numBounces;
+        if (queueCounts.count < words) queueCounts.alloc(words);
         uint32_t* const missCount = queueCounts.ptr + kLine * (numBounces + 1);
         uint32_t* const cursors = queueCounts.ptr + kLine * (numBounces + 2);
         const uint32_t  itemBlocks = static_cast<uint32_t>((paths + kBlock * kItems - 1) / (kBlock * kItems));
@@ -1041,8 +1055,8 @@ struct Renderer::Impl
         {
             uint32_t* countIn = queueCounts.ptr + kLine * (bounce - 1);
             uint32_t* countOut = queueCounts.ptr + kLine * bounce;
-            uint32_t* cursorClosest = cursors + kLine * 2 * (bounce - 1);
-            uint32_t* cursorShadow = cursorClosest + kLine;
+            uint32_t* cursorClosest = cursors + kLine * kShards * 2 * (bounce - 1);
+            uint32_t* cursorShadow = cursorClosest + kLine * kShards;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
                 {
@@ -1401,6 +1415,8 @@ RenderStats Renderer::stats()
     s.shadowNodeVisits = c.shadowNodeVisits;
     s.shadowTriangleTests = c.shadowTriangleTests;
     s.stackHighWater = c.stackHigh;
+    s.closestRecordFetches = c.closestRecordFetches;
+    s.shadowRecordFetches = c.shadowRecordFetches;
     s.paths = c.primaryRays;
     return s;
 }

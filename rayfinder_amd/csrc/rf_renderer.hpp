@@ -73,6 +73,7 @@ struct RenderStats
     uint64_t shadowNodeVisits = 0, shadowTriangleTests = 0;
     uint64_t paths = 0;
     uint32_t stackHighWater = 0;
+    uint64_t closestRecordFetches = 0, shadowRecordFetches = 0; // 64-B BVH records fetched (counting build)
     // hipEvent-timed kernel time (ms) and launch counts, per kernel class, while timing is enabled
     double   msRaygen = 0, msClosest = 0, msShade = 0, msShadow = 0, msAccumulate = 0;
     uint32_t launchesRaygen = 0, launchesClosest = 0, launchesShade = 0, launchesShadow = 0, launchesAccumulate = 0;
