@@ -374,3 +374,47 @@ def test_known_answer_quad_scene_on_gpu():
     rp = orc.make_render_params(16, 16, rf.camera_to_array(cam), 4, 1, 1.0, sky)
     ref, _ = orc.render(sc, rp, 0, 1)
     assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
+
+
+# ------------------------------------------------------------------ two ranks sharing one GPU
+def _rank_worker(rank, world, port, w, h, spp, bounces, outdir):
+    import os
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import torch
+    import torch.distributed as dist
+    import rayfinder_amd as rf2
+    from rayfinder_amd.sharding import gather_image, shard_layout
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # NCCL refuses two ranks on one GPU
+    pt = rf2.PtFormat.from_gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "Duck.glb"))
+    params = rf2.make_render_parameters(w, h, rf2.fly_camera(w, h), spp, bounces, rf2.make_sky(), 0.25)
+    r = rf2.ReferencePathTracer(params, pt.scene())
+    r.set_tile_shard(rank, world)
+    tiles, max_tiles = shard_layout(w, h, rank, world)
+    accum = torch.zeros((max_tiles * 1024, 4), dtype=torch.float32, device="cuda:0")
+    r.bind_accumulation_buffer(accum.data_ptr(), accum.numel() * 4)
+    r.render(spp)
+    r.synchronize()
+    image = gather_image(accum.cpu(), w, h, rank, world)          # same code path as bench.py, CPU tensors for gloo
+    if rank == 0:
+        np.save(os.path.join(outdir, "sharded.npy"), image)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_reassemble_the_single_rank_image(duck_pt, tmp_path):
+    """End-to-end multi-rank path (tile shard -> render into a torch tensor -> gather -> un-tile)
+    with two processes; the result equals the single-rank image bit for bit."""
+    import socket
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    W, H, spp, bounces = 300, 200, 4, 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_rank_worker, args=(2, port, W, H, spp, bounces, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npy")
+    r, _ = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(spp)
+    want = r.read_accumulation()[0]
+    assert np.array_equal(bits(got), bits(want))

@@ -8,13 +8,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps ${STEPS:-32} --warmup 4 --no-cpu-baseline"
 
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace.log
 for f in $(find $OUT/trace -name '*kernel_stats.csv' -o -name '*_stats.csv' | head -5); do cp $f $OUT/; done
 
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- $CMD > /dev/null 2> $OUT/pmc$i.log
+  timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/pmc$i -o r -- $CMD > /dev/null 2> $OUT/pmc$i.log
   f=$(find $OUT/pmc$i -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then
     python3 - "$f" "$ctrs" > $OUT/pmc${i}_summary.txt <<'PY'
