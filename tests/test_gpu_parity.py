@@ -418,3 +418,85 @@ def test_two_ranks_on_one_gpu_reassemble_the_single_rank_image(duck_pt, tmp_path
     r.render(spp)
     want = r.read_accumulation()[0]
     assert np.array_equal(bits(got), bits(want))
+
+
+# ------------------------------------------------------------------ layout edge cases of the wide BVH
+def _soup_pt(P, tex_rgb=(200, 180, 160)):
+    n = P.shape[0]
+    N = np.tile(np.array([0, 1, 0], np.float32), (n, 3))
+    UV = np.tile(np.array([0, 0, 1, 0, 0, 1], np.float32), (n, 1))
+    r, g, b = tex_rgb
+    return rf.PtFormat.from_triangles(P, N, UV, np.zeros(n, np.uint32), [(np.array([b | (g << 8) | (r << 16) | (255 << 24)], np.uint32), 1, 1)])
+
+
+def _check_scene_against_oracle(pt, rays, render_wh=(64, 48), cam=None):
+    sc, a = oracle_scene_from_pt(pt)
+    W, H = render_wh
+    cam = cam if cam is not None else rf.create_camera([0.3, 0.4, 3.0], [0, 0, 0], 0.0, 1.0, orc.degrees_to_radians(60.0), W / H)
+    r, params = _renderer(pt, W, H, 4, 5, cam=cam)
+    with np.errstate(all="ignore"):
+        cpu = orc.intersect_bvh_batch(a["bvhNodes"], a["trianglePositionAttributes"], rays, 10000.0)
+        cpu_vis = orc.shadow_batch(a["bvhNodes"], a["trianglePositionAttributes"], rays, 10000.0)
+    gpu = r.intersect_rays(rays, 10000.0)
+    assert np.array_equal(gpu["tri"], cpu["tri"]) and np.array_equal(bits(gpu["t"]), bits(cpu["t"]))
+    assert np.array_equal(gpu["nodesVisited"], cpu["nodesVisited"])
+    assert np.array_equal(r.occluded_rays(rays, 10000.0), cpu_vis)
+    # the render path (wide records, persistent kernel) in counting mode, reference order
+    r.set_option("shadow_nearest_first", 0)
+    r.set_counting(True)
+    r.render(4)
+    img = r.read_accumulation()[0]
+    s = r.stats()
+    rp = orc.make_render_params(W, H, rf.camera_to_array(cam), 4, 5, 0.25, rf.aligned_sky_state(params.sky))
+    ref, st = orc.render(sc, rp, 0, 4)
+    _compare(img, ref, 4)
+    assert s["closest_node_visits"] == st.closestNodeVisits and s["shadow_node_visits"] == st.shadowNodeVisits
+    assert s["closest_triangle_tests"] == st.closestTriTests and s["stack_high_water"] == st.stackHigh
+    return st, cpu
+
+
+def test_single_leaf_root_and_big_leaves():
+    rng = np.random.default_rng(3)
+    rays = _random_rays(rng, 4000, np.array([-1.0, -1, -1]), np.array([1.0, 1, 1]))
+    # (a) one triangle: the whole tree is one leaf (root leaf word)
+    P = np.array([[-1, -1, 0, 1, -1, 0, 0, 1, 0]], np.float32)
+    _check_scene_against_oracle(_soup_pt(P), rays)
+    # (b) 40 identical-centroid triangles: ONE leaf of 40 (> 7 -> big-leaf table), and a mix with normal leaves
+    fan = np.zeros((40, 9), np.float32)
+    ang = np.linspace(0, np.pi, 40, endpoint=False)
+    fan[:, 0] = np.cos(ang); fan[:, 1] = np.sin(ang); fan[:, 3] = -np.cos(ang); fan[:, 4] = -np.sin(ang)
+    fan[:, 8] = 0.3; fan[:, 2] = fan[:, 5] = -0.15      # all centroids at the origin
+    pt = _soup_pt(fan)
+    nodes = pt.arrays()["bvhNodes"]
+    assert len(nodes) == 1 and nodes[0]["triangleCount"] == 40
+    _check_scene_against_oracle(pt, rays)
+    others = (rng.uniform(-1, 1, (300, 1, 3)) + rng.normal(0, 0.08, (300, 3, 3))).astype(np.float32).reshape(300, 9)
+    pt = _soup_pt(np.concatenate([fan + np.float32(2.0), others]))
+    assert (pt.arrays()["bvhNodes"]["triangleCount"] >= 8).any()
+    _check_scene_against_oracle(pt, rays)
+
+
+def test_deep_tree_uses_the_scratch_part_of_the_stack():
+    """Geometrically shrinking triangles along +x make the SAH builder peel a few primitives per
+    level: a ~30-level chain.  Rays along the chain keep one pending far child per level, so the
+    traversal stack goes past its LDS-resident part (12 entries on the render path, 24 on the query
+    path) into scratch -- but stays inside the reference's 32 and the oracle's 64."""
+    rng = np.random.default_rng(9)
+    n = 160
+    x = 4.0 * 1.3 ** (-np.arange(n, dtype=np.float64))
+    sz = 0.2 * x
+    P = np.zeros((n, 9))
+    P[:, 0] = x; P[:, 1] = -sz; P[:, 2] = -0.3 * sz
+    P[:, 3] = x; P[:, 4] = sz; P[:, 5] = -0.3 * sz
+    P[:, 6] = x + 0.1 * sz; P[:, 8] = 0.6 * sz
+    P = P.astype(np.float32)
+    pt = _soup_pt(P)
+    # rays aimed at the apex of the chain (the origin) from x = -1 pass through every box of it
+    o = np.stack([np.full(3000, -1.0), rng.uniform(-0.1, 0.1, 3000), rng.uniform(-0.05, 0.05, 3000)], axis=1)
+    d = -o / np.linalg.norm(o, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    rays = np.concatenate([rays, _random_rays(rng, 3000, np.array([0.0, -1, -1]), np.array([4.0, 1, 1]))])
+    cam = rf.create_camera([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], 0.0, 1.0, orc.degrees_to_radians(12.0), 1.5)  # eye at the apex
+    st, cpu = _check_scene_against_oracle(pt, rays, render_wh=(48, 32), cam=cam)
+    assert 24 < cpu["stackHigh"].max() < 32, int(cpu["stackHigh"].max())
+    assert 12 < st.stackHigh < 32, st.stackHigh
