@@ -95,9 +95,9 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ table, 
     out[tid] = acc;
 }
 
-int main()
+int main(int argc, char** argv)
 {
-    const size_t records = 1u << 18;                 // 256 Ki x 64 B = 16 MiB
+    const size_t records = argc > 1 ? (size_t)atol(argv[1]) : (1u << 18);   // default 256 Ki x 64 B = 16 MiB
     std::vector<float4> host(4 * records);
     for (size_t i = 0; i < host.size(); ++i) host[i] = make_float4(1.0f, 2.0f, 3.0f, __builtin_bit_cast(float, (uint32_t)(i * 2654435761u)));
     float4* table; float* out;
@@ -106,6 +106,7 @@ int main()
     const int blocks = 256 * 5, iters = 2000;
     hipMalloc(&out, blocks * 256 * sizeof(float));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("table: %zu records = %.1f KiB\n", records, records * 64 / 1024.0);
     const char* names[] = {"A lane-private 4x dwordx4 (64 B)", "B quad-cooperative + shuffles", "C lane-private 2x dwordx4 (32 B)", "D as A, half the lanes", "E quad-cooperative via LDS"};
     for (int rep = 0; rep < 2; ++rep)
         for (int mode = 0; mode < 5; ++mode)
