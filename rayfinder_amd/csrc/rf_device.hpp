@@ -102,20 +102,20 @@ struct TriangleHit
 
 // Returns true when the triangle is hit with 1e-5 < t < rayTMax.
 __device__ __forceinline__ bool
-intersectTriangle(const RayPrep& r, Vec3 p0, Vec3 p1, Vec3 p2, float rayTMax, TriangleHit& hit)
+intersectTriangle(Vec3 origin, Vec3 direction, Vec3 p0, Vec3 p1, Vec3 p2, float rayTMax, TriangleHit& hit)
 {
     constexpr float kEpsilon = 0.00001f;
     const Vec3      e1 = p1 - p0;
     const Vec3      e2 = p2 - p0;
-    const Vec3      h = cross(r.direction, e2);
+    const Vec3      h = cross(direction, e2);
     const float     det = dot(e1, h);
     if (det > -kEpsilon && det < kEpsilon) return false;
     const float invDet = 1.0f / det;
-    const Vec3  s = r.origin - p0;
+    const Vec3  s = origin - p0;
     const float u = invDet * dot(s, h);
     if (u < 0.0f || u > 1.0f) return false;
     const Vec3  q = cross(s, e1);
-    const float v = invDet * dot(r.direction, q);
+    const float v = invDet * dot(direction, q);
     if (v < 0.0f || u + v > 1.0f) return false;
     const float t = invDet * dot(e2, q);
     if (t > kEpsilon && t < rayTMax)
@@ -126,6 +126,11 @@ intersectTriangle(const RayPrep& r, Vec3 p0, Vec3 p1, Vec3 p2, float rayTMax, Tr
         return true;
     }
     return false;
+}
+__device__ __forceinline__ bool
+intersectTriangle(const RayPrep& r, Vec3 p0, Vec3 p1, Vec3 p2, float rayTMax, TriangleHit& hit)
+{
+    return intersectTriangle(r.origin, r.direction, p0, p1, p2, rayTMax, hit);
 }
 
 struct ClosestHit
@@ -144,17 +149,19 @@ struct TraversalCounters
 
 // One ray, the reference's visit order.  ANY_HIT: return at the first accepted triangle
 // (shadowRay); otherwise keep the closest (rayIntersectBvh).  COUNT: maintain counters.
-template<bool ANY_HIT, bool COUNT>
+// LDS: stack entries kept in LDS (0: the whole stack in scratch, ldsStackLane unused).
+template<bool ANY_HIT, bool COUNT, int LDS = kLdsStack>
 __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, Vec3 direction, float rayTMax,
                                          uint32_t* ldsStackLane, ClosestHit& out, TraversalCounters& counters)
 {
     const RayPrep ray = prepareRay(origin, direction);
     // stack: first kLdsStack entries in LDS (ldsStackLane[depth * kBlock]), the rest in scratch;
     // size and pointer are plain locals so they stay in registers
-    uint32_t spill[kSpillStack];
-    int      stackSize = 0;
-    uint32_t current = 0;
-    bool     found = false;
+    constexpr int kSpill = kLdsStack + kSpillStack - LDS;
+    uint32_t      spill[kSpill];
+    int           stackSize = 0;
+    uint32_t      current = 0;
+    bool          found = false;
     out.triangle = kMiss;
 
     for (;;)
@@ -201,8 +208,8 @@ __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, 
                 const uint32_t neg = axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ);
                 const uint32_t deferred = neg ? current + 1 : link;
                 current = neg ? link : current + 1;
-                if (stackSize < kLdsStack) ldsStackLane[stackSize * kBlock] = deferred;
-                else if (stackSize - kLdsStack < kSpillStack) spill[stackSize - kLdsStack] = deferred;
+                if (LDS > 0 && stackSize < LDS) ldsStackLane[stackSize * kBlock] = deferred;
+                else if (stackSize - LDS < kSpill) spill[stackSize - LDS] = deferred;
                 else break; // deeper than kLdsStack + kSpillStack: abandon the ray (reference: undefined past 32)
                 ++stackSize;
                 if (COUNT) counters.stackHigh = max(counters.stackHigh, static_cast<uint32_t>(stackSize));
@@ -213,9 +220,16 @@ __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, 
         {
             if (stackSize == 0) break;
             --stackSize;
-            current = ldsStackLane[min(stackSize, kLdsStack - 1) * kBlock]; // see kTraceWide's pop()
-            asm volatile("" : "+v"(current));
-            if (stackSize >= kLdsStack) current = spill[stackSize - kLdsStack];
+            if constexpr (LDS > 0)
+            {
+                current = ldsStackLane[min(stackSize, LDS - 1) * kBlock]; // see kTraceWide's pop()
+                asm volatile("" : "+v"(current));
+                if (stackSize >= LDS) current = spill[stackSize - LDS];
+            }
+            else
+            {
+                current = spill[stackSize];
+            }
         }
     }
     return found;

@@ -412,7 +412,9 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
 
     uint32_t  state = kIdle;
     uint32_t  slot = 0, current = 0, leafWord = 0;
-    RayPrep   ray{};
+    PackedRay pr{};      // origin and 1/direction in the pairings of the record (rf_wide.hpp)
+    Vec3      rayDir{};  // for the triangle tests
+    uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order)
     float     rayTMax = kTMax;
     // Traversal stack of (child word, tmin) pairs: the first kWideLdsStack entries of every lane in
     // LDS ([depth][lane], conflict-free b64 accesses), deeper ones in scratch.  Kept as separate
@@ -511,25 +513,45 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                     const float4 d = ps.rayD[slot];
                     dir = vec3(d.x, d.y, d.z);
                 }
-                ray = prepareRay(vec3(o.x, o.y, o.z), dir);
+                const RayPrep ray = prepareRay(vec3(o.x, o.y, o.z), dir);
+                pr = packRay(ray);
+                rayDir = dir;
+                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2);
                 rayTMax = kTMax;
                 stackSize = 0;
                 best.triangle = kMiss;
                 occluded = false;
-                // the root visit (wgsl:379-382)
-                if (COUNT) ++tc.nodesVisited;
-                float      rootTMin;
-                const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
-                if (!rootOk) state = kDone;
-                else if (wide.rootLeaf != kWideNone)
+                if (!isRegularRay(ray))
                 {
-                    leafWord = wide.rootLeaf;
-                    state = kAtLeaf;
+                    // axis-parallel / denormal / non-finite rays (0 * inf slabs): the reference's own
+                    // scalar traversal, whole ray at once (in practice never taken; keeps parity exact)
+                    TraversalCounters c2;
+                    occluded = traverse<ANY_HIT, COUNT, 0>(scene, ray.origin, dir, kTMax, nullptr, best, c2);
+                    if (COUNT)
+                    {
+                        tc.nodesVisited += c2.nodesVisited;
+                        tc.triangleTests += c2.triangleTests;
+                        tc.stackHigh = max(tc.stackHigh, c2.stackHigh);
+                    }
+                    state = kDone;
                 }
                 else
                 {
-                    current = 0;
-                    state = kDescend;
+                    // the root visit (wgsl:379-382)
+                    if (COUNT) ++tc.nodesVisited;
+                    float      rootTMin;
+                    const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
+                    if (!rootOk) state = kDone;
+                    else if (wide.rootLeaf != kWideNone)
+                    {
+                        leafWord = wide.rootLeaf;
+                        state = kAtLeaf;
+                    }
+                    else
+                    {
+                        current = 0;
+                        state = kDescend;
+                    }
                 }
             }
             chunkPos += take;
@@ -547,15 +569,14 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
             {
                 if (COUNT) ++recordFetches;
                 const float4*  n = wide.nodes + 4 * static_cast<size_t>(current);
-                const float4   a0 = n[0], a1 = n[1], b0 = n[2], b1 = n[3];
-                const uint32_t axis = __float_as_uint(a1.w) & 3u;
+                const float4   q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                const uint32_t word0 = __float_as_uint(q3.x), word1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
                 float          t0, t1;
-                const bool     ok0 = slabBounds(ray, a0, a1, t0);
-                const bool     ok1 = slabBounds(ray, b0, b1, t1);
-                const uint32_t neg = NEAREST_FIRST ? static_cast<uint32_t>(ok1 && (!ok0 || t1 < t0))
-                                                   : (axis == 0 ? ray.negX : (axis == 1 ? ray.negY : ray.negZ));
+                bool           ok0, ok1;
+                slabPair(pr, q0, q1, q2, ok0, t0, ok1, t1);
+                const uint32_t neg = NEAREST_FIRST ? static_cast<uint32_t>(ok1 && (!ok0 || t1 < t0)) : ((negMask >> axis) & 1u);
                 // reference order: dirNeg[axis] ? second child first : first child first
-                const uint32_t nearWord = __float_as_uint(neg ? b0.w : a0.w), farWord = __float_as_uint(neg ? a0.w : b0.w);
+                const uint32_t nearWord = neg ? word1 : word0, farWord = neg ? word0 : word1;
                 const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
                 const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
                 bool           overflow = false;
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                 if (COUNT) ++tc.triangleTests;
                 TriangleHit th;
                 const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
-                if (intersectTriangle(ray, p0, p1, p2, rayTMax, th))
+                if (intersectTriangle(vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, p0, p1, p2, rayTMax, th))
                 {
                     if (ANY_HIT)
                     {
@@ -887,6 +908,7 @@ struct Renderer::Impl
     bool counting = false, timing = false;
     int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
     uint32_t wideBlocks = 0;
+    bool     wideUsable = true;
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     RenderStats hostStats;
@@ -1157,6 +1179,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         m.wide.rootLo = wb.rootLo;
         m.wide.rootHi = wb.rootHi;
         m.wide.rootLeaf = wb.rootLeaf;
+        m.wideUsable = wb.boxesRegular; // NaN / inverted boxes: only the reference-ordered scalar kernels are exact
     }
     m.triangles.upload(reinterpret_cast<const float4*>(sceneView.positionAttributes.data()), 3 * sceneView.positionAttributes.size());
     m.attributes.upload(sceneView.vertexAttributes.data(), sceneView.vertexAttributes.size());
@@ -1205,6 +1228,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, 0));
         m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
         if (const char* v = std::getenv("RF_TRAVERSAL_VARIANT")) m.traversalVariant = std::atoi(v);
+        if (!m.wideUsable) m.traversalVariant = 0;
     }
 
     m.maxWidth = desc.maxWidth ? desc.maxWidth : desc.renderParams.width;
@@ -1389,7 +1413,7 @@ void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
 
 void Renderer::setOption(const std::string& name, int64_t value)
 {
-    if (name == "traversal_variant") mImpl->traversalVariant = static_cast<int>(value);
+    if (name == "traversal_variant") mImpl->traversalVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
     else if (name == "refill_min") mImpl->optRefillMin = static_cast<uint32_t>(value);
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);

@@ -8,7 +8,9 @@
 // triangles tested against the same rayTMax, hence bit-identical hits):
 //
 //   * one record per INTERIOR node holding BOTH children's boxes (16 dwords = 64 B, 64-B aligned:
-//     one cache line, four dwordx4 loads, one dependent fetch per two box tests);
+//     one cache line, four dwordx4 loads, one dependent fetch per two box tests), laid out
+//     {c0.lo.xyz c0.hi.xyz c1.lo.xyz c1.hi.xyz | word0 word1 axis -} so that consecutive float
+//     pairs are (x,y) (z,x) (y,z): six v_pk_add_f32 + six v_pk_mul_f32 do all twelve slab planes;
 //   * the near child (reference order: dirNeg[splitAxis], wgsl:409-417) is handled at once; the
 //     far child is pushed together with its tmin only if P holds, and when popped it is accepted
 //     iff tmin < rayTMax *then* -- exactly the test the reference performs at pop time;
@@ -26,6 +28,7 @@
 
 #include "rf_device.hpp"
 
+#include <cmath>
 #include <vector>
 
 namespace rf
@@ -50,6 +53,7 @@ struct WideBuild
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
+    bool                boxesRegular = true; // every child box finite with min <= max (see slabPair)
 };
 
 // Host: 48-byte reference nodes -> wide records.
@@ -78,10 +82,16 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         const size_t   c0 = i + 1, c1 = n.secondChildOffset;
         const BvhNode &a = nodes[c0], &b = nodes[c1];
         float4*        w = &out.nodes[4 * static_cast<size_t>(wideIndex[i])];
-        w[0] = make_float4(a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, bitsFloat(childWord(c0)));
-        w[1] = make_float4(a.aabb.max.x, a.aabb.max.y, a.aabb.max.z, bitsFloat(n.splitAxis & 3u));
-        w[2] = make_float4(b.aabb.min.x, b.aabb.min.y, b.aabb.min.z, bitsFloat(childWord(c1)));
-        w[3] = make_float4(b.aabb.max.x, b.aabb.max.y, b.aabb.max.z, 0.0f);
+        // 12 box floats back to back so that the device forms (x,y) (z,x) (y,z) pairs for packed f32 math
+        w[0] = make_float4(a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, a.aabb.max.x);
+        w[1] = make_float4(a.aabb.max.y, a.aabb.max.z, b.aabb.min.x, b.aabb.min.y);
+        w[2] = make_float4(b.aabb.min.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z);
+        w[3] = make_float4(bitsFloat(childWord(c0)), bitsFloat(childWord(c1)), bitsFloat(n.splitAxis & 3u), 0.0f);
+        // the packed slab test assumes ordered, finite boxes (always true for boxes of real triangles)
+        const float lo[6] = {a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, b.aabb.min.x, b.aabb.min.y, b.aabb.min.z};
+        const float hi[6] = {a.aabb.max.x, a.aabb.max.y, a.aabb.max.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z};
+        for (int k = 0; k < 6; ++k)
+            if (!(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) out.boxesRegular = false;
     }
     if (out.bigLeaves.empty()) out.bigLeaves.push_back(make_uint2(0, 0));
     return out;
@@ -106,6 +116,67 @@ __device__ __forceinline__ bool slabBounds(const RayPrep& r, float4 lo, float4 h
     tmax = minf(tzmax, tmax);
     tminOut = tmin;
     return tmax > 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Both boxes of one record at once, for REGULAR rays: origin finite, 1/direction finite and
+// non-zero on all three axes (every ray except exactly axis-parallel / denormal-direction / NaN
+// ones), against ordered finite boxes (WideBuild::boxesRegular).  Then none of the twelve slab
+// products (b - o) * inv can be NaN, and per axis t(lo) <= t(hi) for inv > 0, t(hi) <= t(lo) for
+// inv < 0 (IEEE rounding is monotonic), so the reference's sign-selected near/far planes equal
+// min(t(lo), t(hi)) / max(t(lo), t(hi)) bit for bit, its ternary max/min chains equal the
+// hardware max3/min3, and its pairwise early-outs
+//     !(tmin > tymax) && !(tymin > tmax) && !(max(tmin,tymin) > tzmax) && !(tzmin > min(tmax,tymax))
+// are together equivalent to  max3(near) <= min3(far)  (each axis has near <= far; the remaining six
+// cross pairs are exactly the four tests).  So P and tmin are those of slabBounds(), with 12 packed
+// f32 ops + 16 min/max/compare instead of ~70 VALU and no data-dependent branches.  Rays that are
+// not regular never reach this function (kTraceWide runs the reference-ordered scalar traversal
+// for them).  Bit-equality with slabBounds() is checked on the GPU by tests/test_gpu_parity.py.
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct PackedRay
+{
+    v2f oXY, oZX, oYZ; // origin, in the pairings of the record's 12 floats
+    v2f iXY, iZX, iYZ; // 1 / direction
+};
+
+__device__ __forceinline__ bool isRegularRay(const RayPrep& r)
+{
+    const bool fo = __builtin_isfinite(r.origin.x) && __builtin_isfinite(r.origin.y) && __builtin_isfinite(r.origin.z);
+    const bool fi = __builtin_isfinite(r.invDir.x) && __builtin_isfinite(r.invDir.y) && __builtin_isfinite(r.invDir.z);
+    return fo && fi && r.invDir.x != 0.0f && r.invDir.y != 0.0f && r.invDir.z != 0.0f;
+}
+
+__device__ __forceinline__ PackedRay packRay(const RayPrep& r)
+{
+    PackedRay p;
+    p.oXY = v2f{r.origin.x, r.origin.y};
+    p.oZX = v2f{r.origin.z, r.origin.x};
+    p.oYZ = v2f{r.origin.y, r.origin.z};
+    p.iXY = v2f{r.invDir.x, r.invDir.y};
+    p.iZX = v2f{r.invDir.z, r.invDir.x};
+    p.iYZ = v2f{r.invDir.y, r.invDir.z};
+    return p;
+}
+
+// q0 = {c0.lo.xyz, c0.hi.x}  q1 = {c0.hi.yz, c1.lo.xy}  q2 = {c1.lo.z, c1.hi.xyz}
+__device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q1, float4 q2, bool& ok0, float& tmin0, bool& ok1, float& tmin1)
+{
+    const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY; // c0: t(lo.x), t(lo.y)
+    const v2f b = (v2f{q0.z, q0.w} - r.oZX) * r.iZX; // c0: t(lo.z), t(hi.x)
+    const v2f c = (v2f{q1.x, q1.y} - r.oYZ) * r.iYZ; // c0: t(hi.y), t(hi.z)
+    const v2f d = (v2f{q1.z, q1.w} - r.oXY) * r.iXY; // c1: t(lo.x), t(lo.y)
+    const v2f e = (v2f{q2.x, q2.y} - r.oZX) * r.iZX; // c1: t(lo.z), t(hi.x)
+    const v2f f = (v2f{q2.z, q2.w} - r.oYZ) * r.iYZ; // c1: t(hi.y), t(hi.z)
+    const float near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.y), __builtin_fminf(a.y, c.x)), __builtin_fminf(b.x, c.y));
+    const float far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.y), __builtin_fmaxf(a.y, c.x)), __builtin_fmaxf(b.x, c.y));
+    const float near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d.x, e.y), __builtin_fminf(d.y, f.x)), __builtin_fminf(e.x, f.y));
+    const float far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d.x, e.y), __builtin_fmaxf(d.y, f.x)), __builtin_fmaxf(e.x, f.y));
+    ok0 = near0 <= far0 && far0 > 0.0f;
+    ok1 = near1 <= far1 && far1 > 0.0f;
+    tmin0 = near0;
+    tmin1 = near1;
 }
 
 #endif
