@@ -397,7 +397,7 @@ enum LaneState : uint32_t
 template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false>
 __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
                                                       const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin,
-                                                      uint32_t leafVote, uint32_t chunk)
+                                                      uint32_t leafVote, uint32_t chunk, float tMax, uint32_t shadowDirFromStream)
 {
     __shared__ uint2 sStack[kWideLdsStack * kBlock];
     const uint32_t   count = *queueCount;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
     PackedRay pr{};      // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};  // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order)
-    float     rayTMax = kTMax;
+    float     rayTMax = tMax;
     // Traversal stack of (child word, tmin) pairs: the first kWideLdsStack entries of every lane in
     // LDS ([depth][lane], conflict-free b64 accesses), deeper ones in scratch.  Kept as separate
     // locals (not a struct holding the spill array) so that the stack size and the LDS address stay
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                 slot = queue[chunkPos + rankInIdle];
                 const float4 o = ps.rayO[slot];
                 Vec3         dir;
-                if (ANY_HIT)
+                if (ANY_HIT && !shadowDirFromStream)
                 {
                     const float4 nz = ps.noise[slot];
                     dir = sunSample(sky, nz.x, nz.y, nz.z);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                 pr = packRay(ray);
                 rayDir = dir;
                 negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2);
-                rayTMax = kTMax;
+                rayTMax = tMax;
                 stackSize = 0;
                 best.triangle = kMiss;
                 occluded = false;
@@ -526,7 +526,8 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                     // axis-parallel / denormal / non-finite rays (0 * inf slabs): the reference's own
                     // scalar traversal, whole ray at once (in practice never taken; keeps parity exact)
                     TraversalCounters c2;
-                    occluded = traverse<ANY_HIT, COUNT, 0>(scene, ray.origin, dir, kTMax, nullptr, best, c2);
+                    occluded = traverse<ANY_HIT, COUNT, 0>(scene, ray.origin, dir, tMax, nullptr, best, c2);
+                    if (!ANY_HIT && best.triangle != kMiss) rayTMax = best.t;
                     if (COUNT)
                     {
                         tc.nodesVisited += c2.nodesVisited;
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
             }
             else
             {
-                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, 0.0f);
+                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, rayTMax); // .w = t of the hit (rayTMax == best.t then)
                 if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, 0.0f);
             }
             state = kIdle;
@@ -909,6 +910,7 @@ struct Renderer::Impl
     int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
     uint32_t wideBlocks = 0;
     bool     wideUsable = true;
+    int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     RenderStats hostStats;
@@ -1039,6 +1041,60 @@ struct Renderer::Impl
         pendingBatches.clear();
     }
 
+    // Test hook (option query_variant = 2): arbitrary rays through the render path's persistent
+    // traversal kernel.  closest: out0 = hit stream {tri, u, v, t}, out1 = rayO stream (offset hit
+    // point); shadow: out0 = rad stream, .x != 0 iff the ray is unoccluded.
+    void queryWide(const float* rays6, uint64_t n, float tMax, bool shadow, std::vector<float4>& out0, std::vector<float4>& out1)
+    {
+        if (n > 0xFFFFFFFFull) throw std::runtime_error("too many rays");
+        ensurePathState(n);
+        std::vector<float4>   o(n), d(n);
+        std::vector<uint32_t> ids(n);
+        for (uint64_t i = 0; i < n; ++i)
+        {
+            o[i] = make_float4(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2], 0.0f);
+            d[i] = make_float4(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], 0.0f);
+            ids[i] = static_cast<uint32_t>(i);
+        }
+        RF_HIP(hipMemcpy(sRayO.ptr, o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        RF_HIP(hipMemcpy(sRayD.ptr, d.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        RF_HIP(hipMemcpy(queueA.ptr, ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        const uint32_t words = kLineWords * (1 + kShards);
+        if (queueCounts.count < words) queueCounts.alloc(words);
+        RF_HIP(hipMemset(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t)));
+        const uint32_t count = static_cast<uint32_t>(n);
+        RF_HIP(hipMemcpy(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice));
+        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr};
+        const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
+        if (shadow)
+        {
+            // rad = 0, pending = 1: rad.x becomes visibility * SOLAR_INV_PDF
+            std::vector<float4> ones(n, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
+            RF_HIP(hipMemcpy(sPending.ptr, ones.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+            RF_HIP(hipMemset(sRad.ptr, 0, n * sizeof(float4)));
+            if (shadowNearestFirst)
+                hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 1u);
+            else
+                hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 1u);
+        }
+        else
+        {
+            hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
+                               queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+        }
+        RF_HIP(hipGetLastError());
+        RF_HIP(hipStreamSynchronize(stream));
+        out0.resize(n);
+        RF_HIP(hipMemcpy(out0.data(), shadow ? sRad.ptr : sHit.ptr, n * sizeof(float4), hipMemcpyDeviceToHost));
+        if (!shadow)
+        {
+            out1.resize(n);
+            RF_HIP(hipMemcpy(out1.data(), sRayO.ptr, n * sizeof(float4), hipMemcpyDeviceToHost));
+        }
+    }
+
     // Trace `numSamples` consecutive samples (sample indices start at frame `firstFrame`).
     void traceBatch(uint32_t firstFrame, uint32_t numSamples)
     {
@@ -1095,10 +1151,10 @@ struct Renderer::Impl
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                 else
                     hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
             });
             launchTimed(2, [&] {
                 hipLaunchKernelGGL(kShade, dim3(itemBlocks), dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
@@ -1116,17 +1172,17 @@ struct Renderer::Impl
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                     else
                         hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                 else
                     hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
             });
             std::swap(qIn, qOut);
         }
@@ -1418,6 +1474,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
+    else if (name == "query_variant") mImpl->queryVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
     else if (name == "persistent_blocks") mImpl->wideBlocks = static_cast<uint32_t>(value);
     else throw std::invalid_argument("unknown option " + name);
 }
@@ -1485,6 +1542,23 @@ void Renderer::intersectRays(const float* rays6, uint64_t numRays, float tMax, u
     Impl& m = *mImpl;
     synchronize();
     if (numRays == 0) return;
+    if (m.queryVariant == 2)
+    {
+        std::vector<float4> hit, p4;
+        m.queryWide(rays6, numRays, tMax, false, hit, p4);
+        for (uint64_t i = 0; i < numRays; ++i)
+        {
+            const uint32_t tri = floatBits(hit[i].x);
+            const bool     found = tri != kMiss;
+            triangleOut[i] = tri;
+            if (tOut) tOut[i] = found ? hit[i].w : 0.0f;
+            if (uvOut) uvOut[2 * i] = found ? hit[i].y : 0.0f, uvOut[2 * i + 1] = found ? hit[i].z : 0.0f;
+            if (pOut) pOut[3 * i] = found ? p4[i].x : 0.0f, pOut[3 * i + 1] = found ? p4[i].y : 0.0f, pOut[3 * i + 2] = found ? p4[i].z : 0.0f;
+            if (nodesVisitedOut) nodesVisitedOut[i] = 0;
+            if (triangleTestsOut) triangleTestsOut[i] = 0;
+        }
+        return;
+    }
     DeviceBuffer<float>    rays, t, uv, p;
     DeviceBuffer<uint32_t> tri, nv, tt;
     rays.upload(rays6, 6 * numRays);
@@ -1511,6 +1585,13 @@ void Renderer::occludedRays(const float* rays6, uint64_t numRays, float tMax, fl
     Impl& m = *mImpl;
     synchronize();
     if (numRays == 0) return;
+    if (m.queryVariant == 2)
+    {
+        std::vector<float4> rad, unused;
+        m.queryWide(rays6, numRays, tMax, true, rad, unused);
+        for (uint64_t i = 0; i < numRays; ++i) visibilityOut[i] = rad[i].x != 0.0f ? 1.0f : 0.0f;
+        return;
+    }
     DeviceBuffer<float> rays, vis;
     rays.upload(rays6, 6 * numRays);
     vis.alloc(numRays);

@@ -121,6 +121,35 @@ def test_any_hit_random_rays_bit_exact(duck_pt, duck_oracle):
     assert r.intersect_rays(np.zeros((0, 6), np.float32), 1.0)["tri"].size == 0   # empty input
 
 
+@pytest.mark.parametrize("tmax", [10000.0, 1.5])
+def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tmax):
+    """The persistent wide-layout kernel the render path uses (packed slab pairs for regular rays,
+    reference-ordered scalar traversal for axis-parallel / zero-component ones), driven with
+    arbitrary rays through the query API: hit, t, barycentrics and offset hit point bit-exact."""
+    rng = np.random.default_rng(44)
+    lo, hi = duck_oracle.nodes[0]["min"].astype(np.float64), duck_oracle.nodes[0]["max"].astype(np.float64)
+    rays = _random_rays(rng, 30000, lo, hi)
+    rays[-50:, 3:] = 0.0                                  # degenerate directions
+    rays[-100:-50, 3] = np.float32(1e-42)                 # denormal component: 1/d = inf
+    rays[-150:-100, 0] = np.float32(np.nan)               # NaN origin
+    rays[-200:-150, 3:] *= np.float32(1e30)               # huge directions
+    r, _ = _renderer(duck_pt, 64, 64, 1, 1)
+    r.set_option("query_variant", 2)
+    with np.errstate(all="ignore"):
+        cpu = orc.intersect_bvh_batch(duck_oracle.nodes, duck_oracle.pos48, rays, tmax)
+        cpu_vis = orc.shadow_batch(duck_oracle.nodes, duck_oracle.pos48, rays, tmax)
+    gpu = r.intersect_rays(rays, tmax)
+    assert np.array_equal(gpu["hit"], cpu["hit"])
+    assert np.array_equal(gpu["tri"], cpu["tri"])
+    for k in ("t", "uv", "p"):
+        assert np.array_equal(bits(gpu[k]), bits(cpu[k])), k
+    for nearest_first in (1, 0):
+        r.set_option("shadow_nearest_first", nearest_first)
+        assert np.array_equal(r.occluded_rays(rays, tmax), cpu_vis), nearest_first
+    r.set_option("query_variant", 0)
+    assert np.array_equal(r.intersect_rays(rays, tmax)["tri"], cpu["tri"])
+
+
 # ------------------------------------------------------------------ config 2: radiance parity
 def test_duck_render_matches_golden_crops(duck_pt):
     g = np.load(os.path.join(GOLDEN, "duck_render_golden.npz"))
