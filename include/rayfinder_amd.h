@@ -154,6 +154,12 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
 RF_API int rf_renderer_set_option(rf_renderer* r, const char* name, int64_t value);
 RF_API int rf_renderer_reset_stats(rf_renderer* r);
 RF_API int rf_renderer_get_stats(rf_renderer* r, rf_stats* out);
+/* Queue occupancy and traversal kernel time per bounce since the last reset (entry b = bounce b+1;
+ * bounces past 32 are folded into entry 31).  Each array holds `capacity` entries (or is NULL);
+ * *num_bounces receives the number of entries that are meaningful (the current numBounces, <= 32).
+ * No reference counterpart: the megakernel has no queues. */
+RF_API int rf_renderer_get_bounce_stats(rf_renderer* r, uint32_t capacity, uint64_t* closest_rays, uint64_t* shadow_rays,
+                                        double* ms_closest, double* ms_shadow, uint32_t* num_bounces);
 
 /* Multi-GPU tile sharding (no reference counterpart: the reference is single-device).  The image
  * is cut into 32x32 tiles dealt to ranks in a scrambled round-robin; each rank renders its tiles

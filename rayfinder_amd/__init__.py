@@ -306,6 +306,15 @@ class ReferencePathTracer:
         check(lib.rf_renderer_get_stats(self._h, C.byref(s)))
         return s.as_dict()
 
+    def bounce_stats(self):
+        """Per-bounce queue occupancy (rays traced) and traversal kernel ms since the last reset."""
+        cap = 32
+        cr = np.zeros(cap, np.uint64); sr = np.zeros(cap, np.uint64); mc = np.zeros(cap, np.float64); ms = np.zeros(cap, np.float64)
+        n = C.c_uint32(0)
+        check(lib.rf_renderer_get_bounce_stats(self._h, cap, _ptr(cr), _ptr(sr), _ptr(mc), _ptr(ms), C.byref(n)))
+        k = n.value
+        return dict(closest_rays=cr[:k], shadow_rays=sr[:k], ms_closest=mc[:k], ms_shadow=ms[:k])
+
     # multi-GPU tile sharding
     def set_tile_shard(self, rank, world_size):
         check(lib.rf_renderer_set_tile_shard(self._h, rank, world_size))

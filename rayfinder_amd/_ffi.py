@@ -111,6 +111,7 @@ SIGNATURES = {
     "rf_tiles_for_rank": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rf_renderer_trace_primary_stats": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rf_renderer_get_bounce_stats": (C.c_int, [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5),
     "rf_renderer_intersect_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float] + [C.c_void_p] * 6),
     "rf_renderer_occluded_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]),
     "rf_build_bvh": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_int32)]),

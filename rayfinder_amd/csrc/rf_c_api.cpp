@@ -237,6 +237,26 @@ int rf_renderer_reset_stats(rf_renderer* r)
     });
 }
 
+int rf_renderer_get_bounce_stats(rf_renderer* r, uint32_t capacity, uint64_t* closest_rays, uint64_t* shadow_rays, double* ms_closest,
+                                 double* ms_shadow, uint32_t* num_bounces)
+{
+    return guarded([&] {
+        require(r != nullptr, "null argument");
+        const rf::RenderStats s = r->impl->stats();
+        const uint32_t        n = std::min<uint32_t>(r->impl->numBounces(), rf::RenderStats::kMaxBounceStats);
+        if (num_bounces) *num_bounces = n;
+        for (uint32_t b = 0; b < capacity; ++b)
+        {
+            const bool in = b < rf::RenderStats::kMaxBounceStats;
+            if (closest_rays) closest_rays[b] = in ? s.closestRaysByBounce[b] : 0;
+            if (shadow_rays) shadow_rays[b] = in ? s.shadowRaysByBounce[b] : 0;
+            if (ms_closest) ms_closest[b] = in ? s.msClosestByBounce[b] : 0.0;
+            if (ms_shadow) ms_shadow[b] = in ? s.msShadowByBounce[b] : 0.0;
+        }
+        return RF_OK;
+    });
+}
+
 int rf_renderer_get_stats(rf_renderer* r, rf_stats* out)
 {
     return guarded([&] {

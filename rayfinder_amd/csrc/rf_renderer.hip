@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -73,6 +74,8 @@ struct DeviceCounters
     unsigned int       stackHigh;
     unsigned int       pad;
     unsigned long long closestRecordFetches, shadowRecordFetches; // 64-byte wide records actually fetched (counting build)
+    // wave-level trip counts of kTraceWide's loops (counting build): lane utilisation = lane work / (64 * trips)
+    unsigned long long descendTrips[2], leafTrips[2], leafPhases[2], refillTrips[2], popLaneTrips[2], outerTrips[2];
 };
 
 struct FrameParams
@@ -372,13 +375,12 @@ constexpr uint32_t kLineWords = 16;
 constexpr uint32_t kRefillMin = 16; // refill once this many lanes are idle
 constexpr uint32_t kLeafVote = 32; // leave the descent loop when fewer lanes than this are descending
 
-enum LaneState : uint32_t
-{
-    kIdle = 0,    // no ray
-    kDescend = 1, // `current` is the next interior record to fetch
-    kAtLeaf = 2,  // parked on a leaf (leafWord)
-    kDone = 3,    // ray finished, result not yet written
-};
+constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
+// Lane state of kTraceWide lives in ONE register, the next thing to visit: a child word of
+// rf_wide.hpp (bit 31 clear: interior record index; set: leaf descriptor) or one of two sentinels
+// (no leaf word reaches them: that would take count field 7 with big-leaf index 0x0FFFFFFE).
+constexpr uint32_t kNodeIdle = 0xFFFFFFFFu; // no ray
+constexpr uint32_t kNodeDone = 0xFFFFFFFEu; // ray finished, result not yet written
 
 // ------------------------------------------------------------------------------------------------
 // kTraceWide: persistent traversal over the 64-byte children-in-parent layout (rf_wide.hpp).
@@ -387,6 +389,19 @@ enum LaneState : uint32_t
 // queue entries per atomic, refill lanes whose ray has finished, and park lanes that reach a leaf
 // until fewer than `leafVote` lanes are still descending, so that the Moller-Trumbore code runs for
 // many lanes at once.  None of this changes any ray's own visit order.
+//
+// One step = one record = both children of an accepted interior node.  With hit(c) = P(c) &&
+// tmin(c) < rayTMax (rf_wide.hpp), near/far in the reference's order (dirNeg[splitAxis]):
+//     near hit, far hit : go to near, push (far, tmin(far))     reference: push far, visit near
+//     near hit only     : go to near                             far would be popped and rejected later:
+//                                                                rayTMax only ever shrinks
+//     far hit only      : go to far, no stack traffic            reference: near rejected, far popped at once
+//                                                                and tested against the same rayTMax
+//     none              : pop until an entry passes tmin < rayTMax (the reference's test at pop time)
+// The stack holds (child word, tmin) pairs, kWideLdsStack per lane in LDS ([depth][lane], ds_*_b64).
+// A ray that would need more, and any ray that is not "regular" (axis-parallel / denormal / NaN,
+// rf_wide.hpp), is redone whole by the reference-ordered scalar traversal over the 32-byte nodes
+// (rf_device.hpp) -- same result by construction, and rare enough not to matter.
 // ------------------------------------------------------------------------------------------------
 // NEAREST_FIRST (any-hit only): visit the child with the smaller slab tmin first instead of the
 // reference's split-axis order.  A shadow ray's answer is "does ANY triangle of any reachable leaf
@@ -394,14 +409,28 @@ enum LaneState : uint32_t
 // does not depend on the visit order, so the visibility bit is identical while occluded rays
 // terminate after fewer fetches.  (Closest-hit keeps the reference order: ties in t are resolved
 // by visit order.)
-template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false>
-__global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
-                                                      const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin,
-                                                      uint32_t leafVote, uint32_t chunk, float tMax, uint32_t shadowDirFromStream)
+//
+// COUNT && !NEAREST_FIRST is the reference-bookkeeping build: every far child is pushed (tmin = +inf
+// when its box is missed) and counted when popped, so nodesVisited and the stack high-water mark
+// equal the reference's exactly; it trades occupancy for a deeper LDS stack.
+template<bool COUNT, bool NEAREST_FIRST>
+constexpr int wideStackDepth()
 {
-    __shared__ uint2 sStack[kWideLdsStack * kBlock];
+    return (COUNT && !NEAREST_FIRST) ? 28 : kWideLdsStack;
+}
+
+template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false>
+__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps,
+                                                                                        const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
+                                                                                        DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
+                                                                                        uint32_t chunk, float tMax, uint32_t flags)
+{
+    constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
+    constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
+    __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
+    const bool       shadowDirFromStream = flags & kFlagShadowDirFromStream;
 
     // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
     // shard of its block and moves on round-robin when a shard is dry.
@@ -410,75 +439,53 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
     uint32_t       chunkPos = 0, chunkEnd = 0;
     bool           exhausted = count == 0;
 
-    uint32_t  state = kIdle;
-    uint32_t  slot = 0, current = 0, leafWord = 0;
-    PackedRay pr{};      // origin and 1/direction in the pairings of the record (rf_wide.hpp)
-    Vec3      rayDir{};  // for the triangle tests
+    uint32_t  node = kNodeIdle;
+    uint32_t  slot = 0;
+    PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
+    Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order)
     float     rayTMax = tMax;
-    // Traversal stack of (child word, tmin) pairs: the first kWideLdsStack entries of every lane in
-    // LDS ([depth][lane], conflict-free b64 accesses), deeper ones in scratch.  Kept as separate
-    // locals (not a struct holding the spill array) so that the stack size and the LDS address stay
-    // in registers and the accesses are ds_* / scratch_*, not flat_* through the texture addresser.
-    uint2 spill[kWideSpillStack];
-    int   stackSize = 0;
-    auto  push = [&](uint32_t word, float tmin) -> bool {
-        const uint2 e = make_uint2(word, __float_as_uint(tmin));
-        if (stackSize < kWideLdsStack) sStack[stackSize * kBlock + threadIdx.x] = e;
-        else if (stackSize - kWideLdsStack < kWideSpillStack) spill[stackSize - kWideLdsStack] = e;
-        else return false;
+    int       stackSize = 0;
+    bool      needScalar = false; // irregular ray or stack overflow: redo with the scalar traversal
+    auto      push = [&](uint32_t word, float tmin) -> bool {
+        if (stackSize >= kDepth) return false;
+        sStack[stackSize * kBlock + threadIdx.x] = make_uint2(word, __float_as_uint(tmin));
         ++stackSize;
         return true;
     };
-    auto pop = [&]() -> uint2 {
-        --stackSize;
-        // unconditional LDS read + conditional scratch read: an if/else of the two would be
-        // if-converted into a pointer select and a flat_load
-        uint2 e = sStack[min(stackSize, kWideLdsStack - 1) * kBlock + threadIdx.x];
-        asm volatile("" : "+v"(e.x), "+v"(e.y)); // pin the ds_read: keeps the two address spaces apart
-        if (stackSize >= kWideLdsStack) e = spill[stackSize - kWideLdsStack];
-        return e;
-    };
     ClosestHit        best{};
     bool              occluded = false;
-    TraversalCounters tc;
+    TraversalCounters tc;                                           // COUNT: totals of this lane's finished rays
+    uint32_t          rayNodes = 0, rayTris = 0, rayStackHigh = 0;  // COUNT: the ray in flight
     uint32_t          recordFetches = 0;
+    uint32_t          wDescend = 0, wLeaf = 0, wLeafPhase = 0, wRefill = 0, wPop = 0, wOuter = 0; // COUNT: loop trips
 
     // Pop entries until one passes `tmin < rayTMax` (the reference's box test at pop time).
     auto popNext = [&]() {
-        for (;;)
+        node = kNodeDone;
+        while (stackSize > 0)
         {
-            if (stackSize == 0)
-            {
-                state = kDone;
-                return;
-            }
-            const uint2 e = pop();
-            if (COUNT && !NEAREST_FIRST) ++tc.nodesVisited;
+            --stackSize;
+            const uint2 e = sStack[stackSize * kBlock + threadIdx.x];
+            if (COUNT) ++wPop;
+            if (kRefCount) ++rayNodes;
             if (__uint_as_float(e.y) < rayTMax)
             {
-                if (e.x & kWideLeafBit)
-                {
-                    leafWord = e.x;
-                    state = kAtLeaf;
-                }
-                else
-                {
-                    current = e.x;
-                    state = kDescend;
-                }
-                return;
+                node = e.x;
+                break;
             }
         }
     };
 
     for (;;)
     {
+        if (COUNT) ++wOuter;
         // ---- refill idle lanes from the wave's chunk
-        const unsigned long long idleMask = __ballot(state == kIdle);
+        const unsigned long long idleMask = __ballot(node == kNodeIdle);
         const uint32_t           idleCount = __popcll(idleMask);
         if (!exhausted && idleCount >= refillMin)
         {
+            if (COUNT) ++wRefill;
             while (chunkPos == chunkEnd && !exhausted)
             {
                 const uint32_t shardBegin = shard * shardLen, shardEnd = min(shardBegin + shardLen, count);
@@ -498,7 +505,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
             }
             const uint32_t take = min(idleCount, chunkEnd - chunkPos);
             const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
-            if (state == kIdle && rankInIdle < take)
+            if (node == kNodeIdle && rankInIdle < take)
             {
                 slot = queue[chunkPos + rankInIdle];
                 const float4 o = ps.rayO[slot];
@@ -521,43 +528,17 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                 stackSize = 0;
                 best.triangle = kMiss;
                 occluded = false;
-                if (!isRegularRay(ray))
-                {
-                    // axis-parallel / denormal / non-finite rays (0 * inf slabs): the reference's own
-                    // scalar traversal, whole ray at once (in practice never taken; keeps parity exact)
-                    TraversalCounters c2;
-                    occluded = traverse<ANY_HIT, COUNT, 0>(scene, ray.origin, dir, tMax, nullptr, best, c2);
-                    if (!ANY_HIT && best.triangle != kMiss) rayTMax = best.t;
-                    if (COUNT)
-                    {
-                        tc.nodesVisited += c2.nodesVisited;
-                        tc.triangleTests += c2.triangleTests;
-                        tc.stackHigh = max(tc.stackHigh, c2.stackHigh);
-                    }
-                    state = kDone;
-                }
-                else
-                {
-                    // the root visit (wgsl:379-382)
-                    if (COUNT) ++tc.nodesVisited;
-                    float      rootTMin;
-                    const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
-                    if (!rootOk) state = kDone;
-                    else if (wide.rootLeaf != kWideNone)
-                    {
-                        leafWord = wide.rootLeaf;
-                        state = kAtLeaf;
-                    }
-                    else
-                    {
-                        current = 0;
-                        state = kDescend;
-                    }
-                }
+                rayNodes = 1; // the root visit (wgsl:379-382)
+                rayTris = 0;
+                rayStackHigh = 0;
+                needScalar = !isRegularRay(ray);
+                float      rootTMin;
+                const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
+                node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
             }
             chunkPos += take;
         }
-        if (__ballot(state != kIdle) == 0ull)
+        if (__ballot(node != kNodeIdle) == 0ull)
         {
             if (exhausted) break;
             continue;
@@ -566,61 +547,57 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
         // ---- descend: one 64-byte record = both children of an accepted interior node
         do
         {
-            if (state == kDescend)
+            if (COUNT) ++wDescend;
+            if (static_cast<int32_t>(node) >= 0)
             {
                 if (COUNT) ++recordFetches;
-                const float4*  n = wide.nodes + 4 * static_cast<size_t>(current);
+                const float4*  n = wide.nodes + 4 * static_cast<size_t>(node);
                 const float4   q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
                 const uint32_t word0 = __float_as_uint(q3.x), word1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
                 float          t0, t1;
                 bool           ok0, ok1;
                 slabPair(pr, q0, q1, q2, ok0, t0, ok1, t1);
-                const uint32_t neg = NEAREST_FIRST ? static_cast<uint32_t>(ok1 && (!ok0 || t1 < t0)) : ((negMask >> axis) & 1u);
                 // reference order: dirNeg[axis] ? second child first : first child first
+                const bool     neg = NEAREST_FIRST ? (ok1 && (!ok0 || t1 < t0)) : (((negMask >> axis) & 1u) != 0u);
                 const uint32_t nearWord = neg ? word1 : word0, farWord = neg ? word0 : word1;
                 const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
                 const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
-                bool           overflow = false;
-                if (COUNT && !NEAREST_FIRST)
+                if constexpr (kRefCount)
                 {
-                    // reference bookkeeping: every far child is pushed and counted when popped
-                    overflow = !push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
-                    tc.stackHigh = max(tc.stackHigh, static_cast<uint32_t>(stackSize));
-                    ++tc.nodesVisited; // the near child
+                    const bool pushed = push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
+                    rayStackHigh = max(rayStackHigh, static_cast<uint32_t>(stackSize));
+                    ++rayNodes; // the near child
+                    if (!pushed)
+                    {
+                        needScalar = true;
+                        node = kNodeDone;
+                    }
+                    else if (okNear && tNear < rayTMax) node = nearWord;
+                    else popNext();
                 }
                 else
                 {
-                    if (okFar) overflow = !push(farWord, tFar);
-                    if (COUNT) tc.nodesVisited += 2; // this build counts box tests
-                }
-                if (overflow)
-                {
-                    stackSize = 0; // deeper than 96: abandon the ray
-                    state = kDone;
-                }
-                else if (okNear && tNear < rayTMax)
-                {
-                    if (nearWord & kWideLeafBit)
+                    if (COUNT) rayNodes += 2; // this build counts box tests
+                    const bool hitNear = okNear && tNear < rayTMax, hitFar = okFar && tFar < rayTMax;
+                    if (hitNear)
                     {
-                        leafWord = nearWord;
-                        state = kAtLeaf;
+                        node = nearWord;
+                        if (hitFar && !push(farWord, tFar))
+                        {
+                            needScalar = true;
+                            node = kNodeDone;
+                        }
                     }
-                    else
-                    {
-                        current = nearWord;
-                    }
-                }
-                else
-                {
-                    popNext();
+                    else if (hitFar) node = farWord;
+                    else popNext();
                 }
             }
-        } while (__popcll(__ballot(state == kDescend)) >= leafVote);
+        } while (__popcll(__ballot(static_cast<int32_t>(node) >= 0)) >= leafVote);
 
         // ---- leaves
-        if (state == kAtLeaf)
+        if (node - kWideLeafBit < kNodeDone - kWideLeafBit)
         {
-            uint32_t first = leafWord & 0x0FFFFFFFu, n = ((leafWord >> 28) & 7u) + 1u;
+            uint32_t first = node & 0x0FFFFFFFu, n = ((node >> 28) & 7u) + 1u;
             if (n == 8u)
             {
                 const uint2 big = wide.bigLeaves[first];
@@ -628,13 +605,15 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                 n = big.y;
             }
             bool finished = false;
+            if (COUNT) ++wLeafPhase;
             for (uint32_t i = 0; i < n; ++i)
             {
+                if (COUNT) ++wLeaf;
                 const uint32_t tri = first + i;
                 const float4   a = scene.triangles[3 * tri];
                 const float4   b = scene.triangles[3 * tri + 1];
                 const float4   c = scene.triangles[3 * tri + 2];
-                if (COUNT) ++tc.triangleTests;
+                if (COUNT) ++rayTris;
                 TriangleHit th;
                 const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
                 if (intersectTriangle(vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, p0, p1, p2, rayTMax, th))
@@ -656,13 +635,31 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
                     best.triangle = tri;
                 }
             }
-            if (finished) state = kDone;
+            if (finished) node = kNodeDone;
             else popNext();
         }
 
         // ---- write back finished rays
-        if (state == kDone)
+        if (node == kNodeDone)
         {
+            if (needScalar)
+            {
+                // axis-parallel / denormal / non-finite rays (0 * inf slabs) and rays whose stack outgrew
+                // LDS: the reference's own scalar traversal, whole ray at once
+                TraversalCounters c2;
+                best.triangle = kMiss;
+                occluded = traverse<ANY_HIT, COUNT, 0>(scene, vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, tMax, nullptr, best, c2);
+                rayTMax = best.triangle != kMiss ? best.t : tMax;
+                rayNodes = c2.nodesVisited;
+                rayTris = c2.triangleTests;
+                rayStackHigh = c2.stackHigh;
+            }
+            if (COUNT)
+            {
+                tc.nodesVisited += rayNodes;
+                tc.triangleTests += rayTris;
+                tc.stackHigh = max(tc.stackHigh, rayStackHigh);
+            }
             if (ANY_HIT)
             {
                 const float  visibility = occluded ? 0.0f : 1.0f;
@@ -674,10 +671,11 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
             }
             else
             {
-                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, rayTMax); // .w = t of the hit (rayTMax == best.t then)
+                // .w = t of the hit (rayTMax == best.t then); read by the query path only
+                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, rayTMax);
                 if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, 0.0f);
             }
-            state = kIdle;
+            node = kNodeIdle;
         }
     }
 
@@ -693,8 +691,34 @@ __global__ __launch_bounds__(kBlock, 6) void kTraceWide(DeviceScene scene, WideS
         }
         const unsigned long long rf = waveSum(recordFetches);
         if (lane == 0) atomicAdd(ANY_HIT ? &counters->shadowRecordFetches : &counters->closestRecordFetches, rf);
+        // wave-level trips: a loop body executed by the wave counts once whatever the number of active lanes
+        // (lanes that were active carry the count; take the max over the wave), except pops (lane work)
+        const int                k = ANY_HIT ? 1 : 0;
+        const unsigned long long pops = waveSum(wPop);
+        const uint32_t           d = waveMax(wDescend), l = waveMax(wLeaf), lp = waveMax(wLeafPhase), r = waveMax(wRefill), o = waveMax(wOuter);
+        if (lane == 0)
+        {
+            atomicAdd(&counters->descendTrips[k], static_cast<unsigned long long>(d));
+            atomicAdd(&counters->leafTrips[k], static_cast<unsigned long long>(l));
+            atomicAdd(&counters->leafPhases[k], static_cast<unsigned long long>(lp));
+            atomicAdd(&counters->refillTrips[k], static_cast<unsigned long long>(r));
+            atomicAdd(&counters->popLaneTrips[k], pops);
+            atomicAdd(&counters->outerTrips[k], static_cast<unsigned long long>(o));
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
+}
+
+
+// Queue occupancy per bounce: Q[b-1] paths enter bounce b (closest-hit rays), Q[b] of them hit
+// something (shadow rays).  Folded into running totals at the end of every batch.
+__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals)
+{
+    const uint32_t b = threadIdx.x;
+    if (b >= numBounces) return;
+    const uint32_t k = min(b, RenderStats::kMaxBounceStats - 1);
+    atomicAdd(&totals[k], static_cast<unsigned long long>(queueCounts[kLineWords * b]));
+    atomicAdd(&totals[RenderStats::kMaxBounceStats + k], static_cast<unsigned long long>(queueCounts[kLineWords * (b + 1)]));
 }
 
 // image[lp] += radiance of samples 0..numSamples-1 in order (f32, wgsl:55); image is the compact
@@ -905,6 +929,7 @@ struct Renderer::Impl
     DeviceBuffer<float4>    sRayO, sRayD, sThr, sRad, sHit, sPending, sNoise;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
+    DeviceBuffer<unsigned long long> bounceTotals; // 2 x kMaxBounceStats
 
     bool counting = false, timing = false;
     int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
@@ -919,6 +944,7 @@ struct Renderer::Impl
     {
         hipEvent_t start, stop;
         int        kind;
+        uint32_t   bounce;
     };
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t>  eventPool;
@@ -985,11 +1011,11 @@ struct Renderer::Impl
     }
 
     template<typename F>
-    void launchTimed(int kind, F&& launch)
+    void launchTimed(int kind, F&& launch, uint32_t bounce = 0)
     {
         if (timing)
         {
-            TimedLaunch t{getEvent(), getEvent(), kind};
+            TimedLaunch t{getEvent(), getEvent(), kind, std::min(bounce, RenderStats::kMaxBounceStats - 1)};
             RF_HIP(hipEventRecord(t.start, stream));
             launch();
             RF_HIP(hipEventRecord(t.stop, stream));
@@ -1012,9 +1038,9 @@ struct Renderer::Impl
             switch (t.kind)
             {
             case 0: hostStats.msRaygen += ms; hostStats.launchesRaygen++; break;
-            case 1: hostStats.msClosest += ms; hostStats.launchesClosest++; break;
+            case 1: hostStats.msClosest += ms; hostStats.launchesClosest++; hostStats.msClosestByBounce[t.bounce] += ms; break;
             case 2: hostStats.msShade += ms; hostStats.launchesShade++; break;
-            case 3: hostStats.msShadow += ms; hostStats.launchesShadow++; break;
+            case 3: hostStats.msShadow += ms; hostStats.launchesShadow++; hostStats.msShadowByBounce[t.bounce] += ms; break;
             default: hostStats.msAccumulate += ms; hostStats.launchesAccumulate++; break;
             }
             eventPool.push_back(t.start);
@@ -1074,10 +1100,10 @@ struct Renderer::Impl
             RF_HIP(hipMemset(sRad.ptr, 0, n * sizeof(float4)));
             if (shadowNearestFirst)
                 hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 1u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
             else
                 hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 1u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
         }
         else
         {
@@ -1155,7 +1181,7 @@ struct Renderer::Impl
                 else
                     hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
-            });
+            }, bounce - 1);
             launchTimed(2, [&] {
                 hipLaunchKernelGGL(kShade, dim3(itemBlocks), dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
                                    bounce == numBounces ? 1u : 0u);
@@ -1183,10 +1209,11 @@ struct Renderer::Impl
                 else
                     hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
-            });
+            }, bounce - 1);
             std::swap(qIn, qOut);
         }
         launchTimed(2, [&] { hipLaunchKernelGGL(kSky, dim3(blocks), dim3(kBlock), 0, stream, sky, ps, missQueue.ptr, missCount); });
+        hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr);
         launchTimed(4, [&] {
             hipLaunchKernelGGL(kAccumulate, dim3((fp.pixelsPadded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, fp, tileIds.ptr, ps, image);
         });
@@ -1277,6 +1304,10 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
 
     DeviceCounters zero{};
     m.counters.upload(&zero, 1);
+    {
+        const std::vector<unsigned long long> z(2 * RenderStats::kMaxBounceStats, 0ull);
+        m.bounceTotals.upload(z.data(), z.size());
+    }
     {
         hipDeviceProp_t prop{};
         RF_HIP(hipGetDeviceProperties(&prop, m.device));
@@ -1398,6 +1429,7 @@ float Renderer::renderProgressPercentage() const
 }
 
 uint32_t Renderer::accumulatedSampleCount() const { return mImpl->accumulated; }
+uint32_t Renderer::numBounces() const { return mImpl->params.samplingParams.numBounces; }
 
 void Renderer::synchronize()
 {
@@ -1487,6 +1519,7 @@ void Renderer::resetStats()
     m.collectTimings();
     DeviceCounters zero{};
     RF_HIP(hipMemcpy(m.counters.ptr, &zero, sizeof zero, hipMemcpyHostToDevice));
+    RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 2 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
     m.hostStats = RenderStats{};
 }
 
@@ -1509,6 +1542,27 @@ RenderStats Renderer::stats()
     s.closestRecordFetches = c.closestRecordFetches;
     s.shadowRecordFetches = c.shadowRecordFetches;
     s.paths = c.primaryRays;
+    if (std::getenv("RF_DEBUG_COUNTERS") && m.counting)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            const double rays = static_cast<double>(k ? c.shadowRays : c.closestRays), steps = static_cast<double>(k ? c.shadowRecordFetches : c.closestRecordFetches);
+            const double tris = static_cast<double>(k ? c.shadowTriangleTests : c.closestTriangleTests);
+            std::fprintf(stderr,
+                         "[rf] %s: rays %.0f | per ray: steps %.2f tris %.2f pops %.2f | wave trips per 64 rays: outer %.2f descend %.2f leafphase %.2f leaf %.2f refill %.2f"
+                         " | lane utilisation: descend %.3f leaf %.3f\n",
+                         k ? "shadow " : "closest", rays, steps / rays, tris / rays, c.popLaneTrips[k] / rays, c.outerTrips[k] * 64.0 / rays,
+                         c.descendTrips[k] * 64.0 / rays, c.leafPhases[k] * 64.0 / rays, c.leafTrips[k] * 64.0 / rays, c.refillTrips[k] * 64.0 / rays,
+                         steps / (64.0 * c.descendTrips[k]), tris / (64.0 * c.leafTrips[k]));
+        }
+    }
+    unsigned long long totals[2 * RenderStats::kMaxBounceStats];
+    RF_HIP(hipMemcpy(totals, m.bounceTotals.ptr, sizeof totals, hipMemcpyDeviceToHost));
+    for (uint32_t b = 0; b < RenderStats::kMaxBounceStats; ++b)
+    {
+        s.closestRaysByBounce[b] = totals[b];
+        s.shadowRaysByBounce[b] = totals[RenderStats::kMaxBounceStats + b];
+    }
     return s;
 }
 

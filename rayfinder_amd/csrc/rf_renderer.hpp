@@ -77,6 +77,11 @@ struct RenderStats
     // hipEvent-timed kernel time (ms) and launch counts, per kernel class, while timing is enabled
     double   msRaygen = 0, msClosest = 0, msShade = 0, msShadow = 0, msAccumulate = 0;
     uint32_t launchesRaygen = 0, launchesClosest = 0, launchesShade = 0, launchesShadow = 0, launchesAccumulate = 0;
+    // per bounce (index b = bounce b+1; bounces past kMaxBounceStats are folded into the last entry):
+    // queue occupancy = rays traced, and kernel time while timing is enabled
+    static constexpr uint32_t kMaxBounceStats = 32;
+    uint64_t closestRaysByBounce[kMaxBounceStats] = {}, shadowRaysByBounce[kMaxBounceStats] = {};
+    double   msClosestByBounce[kMaxBounceStats] = {}, msShadowByBounce[kMaxBounceStats] = {};
 };
 
 constexpr uint32_t kTileSize = 32; // shard tile edge in pixels (32x32 = 16 waves of 8x8 pixels)
@@ -119,6 +124,7 @@ public:
     // Tuning knobs for A/B measurements inside one process ("traversal_variant": 0 = one ray per
     // thread kernels, 1 = persistent waves with lane refill).  Results never depend on them.
     void        setOption(const std::string& name, int64_t value);
+    uint32_t    numBounces() const;
     void        setTiming(bool enabled);
     void        resetStats();
     RenderStats stats();

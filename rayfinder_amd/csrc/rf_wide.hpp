@@ -35,8 +35,7 @@ namespace rf
 {
 constexpr uint32_t kWideLeafBit = 0x80000000u;
 constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is interior
-constexpr int      kWideLdsStack = 12;      // (child word, tmin) pairs kept in LDS per lane
-constexpr int      kWideSpillStack = 84;    // further pairs in scratch (total depth 96, as rf_device.hpp)
+constexpr int      kWideLdsStack = 12;      // (child word, tmin) pairs per lane, all in LDS; deeper rays are redone by the scalar traversal
 
 struct WideScene
 {

@@ -74,6 +74,22 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ table, 
             acc += a.x + b.y;
             idx = hash32(idx + __float_as_uint(a.w) + it) & mask;
         }
+        else if (MODE == 5)
+        {
+            // 128-byte records (128-B aligned), lane-private 8 x dwordx4: a 4-wide BVH node
+            const float4* r = table + 8 * (size_t)idx;
+            const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6], h = r[7];
+            acc += a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w;
+            idx = hash32(idx + __float_as_uint(a.w) + it) & mask;
+        }
+        else if (MODE == 6)
+        {
+            // 96 of the 128 bytes (6 x dwordx4)
+            const float4* r = table + 8 * (size_t)idx;
+            const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5];
+            acc += a.x + b.y + c.z + d.w + e.x + f.y;
+            idx = hash32(idx + __float_as_uint(a.w) + it) & mask;
+        }
         else if (MODE == 4)
         {
             // quad-cooperative through LDS: 4 loads land in LDS, each lane reads its 64 B back
@@ -107,9 +123,9 @@ int main(int argc, char** argv)
     hipMalloc(&out, blocks * 256 * sizeof(float));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("table: %zu records = %.1f KiB\n", records, records * 64 / 1024.0);
-    const char* names[] = {"A lane-private 4x dwordx4 (64 B)", "B quad-cooperative + shuffles", "C lane-private 2x dwordx4 (32 B)", "D as A, half the lanes", "E quad-cooperative via LDS"};
+    const char* names[] = {"A lane-private 4x dwordx4 (64 B)", "B quad-cooperative + shuffles", "C lane-private 2x dwordx4 (32 B)", "D as A, half the lanes", "E quad-cooperative via LDS", "F lane-private 8x dwordx4 (128 B)", "G lane-private 6x dwordx4 of 128 B"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 5; ++mode)
+        for (int mode = 0; mode < 7; ++mode)
         {
             hipEventRecord(e0);
             switch (mode)
@@ -119,11 +135,13 @@ int main(int argc, char** argv)
             case 2: hipLaunchKernelGGL(gather<2>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(2 * records - 1), iters, out); break;
             case 3: hipLaunchKernelGGL(gather<3>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(records - 1), iters, out); break;
             case 4: hipLaunchKernelGGL(gather<4>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(records - 1), iters, out); break;
+            case 5: hipLaunchKernelGGL(gather<5>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(records / 2 - 1), iters, out); break;
+            case 6: hipLaunchKernelGGL(gather<6>, dim3(blocks), dim3(256), 0, 0, table, (uint32_t)(records / 2 - 1), iters, out); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double gathers = (double)blocks * 256 * iters * (mode == 3 ? 0.5 : 1.0);
-            if (rep) printf("%-40s %8.3f ms  %7.1f G records/s  %7.1f GB/s\n", names[mode], ms, gathers / ms * 1e-6, gathers * (mode == 2 ? 32 : 64) / ms * 1e-6);
+            if (rep) printf("%-40s %8.3f ms  %7.1f G records/s  %7.1f GB/s\n", names[mode], ms, gathers / ms * 1e-6, gathers * (mode == 2 ? 32 : (mode == 5 ? 128 : (mode == 6 ? 96 : 64))) / ms * 1e-6);
         }
     return 0;
 }
