@@ -76,6 +76,7 @@ struct DeviceCounters
     unsigned long long closestRecordFetches, shadowRecordFetches; // 64-byte wide records actually fetched (counting build)
     // wave-level trip counts of kTraceWide's loops (counting build): lane utilisation = lane work / (64 * trips)
     unsigned long long descendTrips[2], leafTrips[2], leafPhases[2], refillTrips[2], popLaneTrips[2], outerTrips[2];
+    unsigned long long scalarRedo[2]; // rays redone by the scalar traversal (irregular or stack overflow), all builds
 };
 
 struct FrameParams
@@ -232,6 +233,18 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
     if (i == 0) atomicAdd(&counters->closestRays, static_cast<unsigned long long>(count));
 }
 
+// p = p0 + u*e1 + v*e2 offset along normalize(e1 x e2) (wgsl:511-519,523-544)
+__device__ __forceinline__ Vec3 hitPoint(const DeviceScene& scene, uint32_t tri, float u, float v)
+{
+    const float4 a = scene.triangles[3 * tri];
+    const float4 b = scene.triangles[3 * tri + 1];
+    const float4 c = scene.triangles[3 * tri + 2];
+    const Vec3   p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
+    const Vec3   e1 = p1 - p0, e2 = p2 - p0;
+    const Vec3   p = p0 + u * e1 + v * e2;
+    return offsetRay(p, normalize(cross(e1, e2)));
+}
+
 // Sun direction sample for this path (wgsl:194,287-292,568-579): cone about sunDirection.
 __device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, float nx, float cosPhi, float sinPhi)
 {
@@ -271,6 +284,12 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             continue;
         }
         isHit[k] = true;
+        {
+            // hit point pushed off the surface along the geometric normal (wgsl:511-519,523-544): origin of
+            // the shadow ray and of the next bounce; same arithmetic as the scalar traversal (rf_device.hpp)
+            const Vec3 hp = hitPoint(scene, tri, h.y, h.z);
+            ps.rayO[slot] = make_float4(hp.x, hp.y, hp.z, 0.0f);
+        }
         const float4            thr4 = ps.thr[slot];
         const float4            nz = ps.noise[slot];
         const Vec3              throughput = vec3(thr4.x, thr4.y, thr4.z);
@@ -372,8 +391,8 @@ constexpr uint32_t kChunk = 128;   // queue entries claimed per atomic (small en
 constexpr uint32_t kShards = 16;   // work cursors per launch, one 64-byte line each: a single cursor
                                    // saturates near 90 claims/us (8 M rays / 64 per 1.2 ms = 100/us)
 constexpr uint32_t kLineWords = 16;
-constexpr uint32_t kRefillMin = 16; // refill once this many lanes are idle
-constexpr uint32_t kLeafVote = 32; // leave the descent loop when fewer lanes than this are descending
+constexpr uint32_t kRefillMin = 32; // refill once this many lanes are idle
+constexpr uint32_t kLeafVote = 24; // leave the descent loop when fewer lanes than this are descending
 
 constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
 // Lane state of kTraceWide lives in ONE register, the next thing to visit: a child word of
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
     uint32_t  slot = 0;
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
-    uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order)
+    uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
     float     rayTMax = tMax;
     int       stackSize = 0;
     bool      needScalar = false; // irregular ray or stack overflow: redo with the scalar traversal
@@ -466,7 +485,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
         while (stackSize > 0)
         {
             --stackSize;
-            const uint2 e = sStack[stackSize * kBlock + threadIdx.x];
+            uint2 e = sStack[stackSize * kBlock + threadIdx.x];
+            asm volatile("" : "+v"(e.x), "+v"(e.y)); // one ds_read_b64 (not tmin first, word after the loop)
             if (COUNT) ++wPop;
             if (kRefCount) ++rayNodes;
             if (__uint_as_float(e.y) < rayTMax)
@@ -523,7 +543,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                 const RayPrep ray = prepareRay(vec3(o.x, o.y, o.z), dir);
                 pr = packRay(ray);
                 rayDir = dir;
-                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2);
+                const uint32_t rayClass = classifyRay(ray);
+                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u);
                 rayTMax = tMax;
                 stackSize = 0;
                 best.triangle = kMiss;
@@ -531,7 +552,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                 rayNodes = 1; // the root visit (wgsl:379-382)
                 rayTris = 0;
                 rayStackHigh = 0;
-                needScalar = !isRegularRay(ray);
+                needScalar = rayClass == kRayIrregular;
                 float      rootTMin;
                 const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
                 node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
@@ -557,14 +578,44 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                 float          t0, t1;
                 bool           ok0, ok1;
                 slabPair(pr, q0, q1, q2, ok0, t0, ok1, t1);
+                if (__builtin_expect((negMask & 8u) != 0u, 0))
+                {
+                    // class B ray: a 0 * inf product means the packed test is not the reference's here
+                    if (slabPairHasNaN(pr, q0, q1, q2))
+                    {
+                        needScalar = true;
+                        ok0 = ok1 = false;
+                        stackSize = 0; // -> popNext() ends the ray; it is redone below
+                    }
+                }
+#if defined(RF_ABLATE) && RF_ABLATE == 1
+                {   // ablation: the slab arithmetic twice more (result kept alive, never different)
+                    float4 z0 = q0, z1 = q1, z2 = q2;
+                    for (int rep = 0; rep < 2; ++rep)
+                    {
+                        asm volatile("" : "+v"(z0.x), "+v"(z0.y), "+v"(z0.z), "+v"(z0.w), "+v"(z1.x), "+v"(z1.y), "+v"(z1.z), "+v"(z1.w), "+v"(z2.x), "+v"(z2.y), "+v"(z2.z), "+v"(z2.w));
+                        float a0, a1; bool b0, b1;
+                        slabPair(pr, z0, z1, z2, b0, a0, b1, a1);
+                        if (a0 != t0 || a1 != t1 || b0 != ok0 || b1 != ok1) t0 = __uint_as_float(0x7FC00000u);
+                    }
+                }
+#elif defined(RF_ABLATE) && RF_ABLATE == 2
+                {   // ablation: one more 64-byte record fetch per step, from an unrelated place
+                    const uint32_t other = (node * 2654435761u) % wide.numRecords;
+                    const float4*  m = wide.nodes + 4 * static_cast<size_t>(other);
+                    const float4   y0 = m[0], y1 = m[1], y2 = m[2], y3 = m[3];
+                    const float sum = ((y0.x + y0.y) + (y0.z + y0.w)) + ((y1.x + y1.y) + (y1.z + y1.w)) + ((y2.x + y2.y) + (y2.z + y2.w)) + ((y3.x + y3.y) + (y3.z + y3.w));
+                    if (sum == 1.2345e-33f) t0 = __uint_as_float(0x7FC00000u);
+                }
+#endif
                 // reference order: dirNeg[axis] ? second child first : first child first
-                const bool     neg = NEAREST_FIRST ? (ok1 && (!ok0 || t1 < t0)) : (((negMask >> axis) & 1u) != 0u);
-                const uint32_t nearWord = neg ? word1 : word0, farWord = neg ? word0 : word1;
-                const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
-                const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
+                const bool neg = NEAREST_FIRST ? (t1 < t0) : (((negMask >> axis) & 1u) != 0u);
                 if constexpr (kRefCount)
                 {
-                    const bool pushed = push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
+                    const uint32_t nearWord = neg ? word1 : word0, farWord = neg ? word0 : word1;
+                    const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
+                    const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
+                    const bool     pushed = push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
                     rayStackHigh = max(rayStackHigh, static_cast<uint32_t>(stackSize));
                     ++rayNodes; // the near child
                     if (!pushed)
@@ -578,17 +629,21 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                 else
                 {
                     if (COUNT) rayNodes += 2; // this build counts box tests
-                    const bool hitNear = okNear && tNear < rayTMax, hitFar = okFar && tFar < rayTMax;
-                    if (hitNear)
+                    // which child is entered first: the near one if both can still be hit, else the one that can
+                    const bool     hit0 = ok0 && t0 < rayTMax, hit1 = ok1 && t1 < rayTMax;
+                    const bool     both = hit0 && hit1;
+                    const bool     second = both ? neg : hit1;
+                    const uint32_t firstWord = second ? word1 : word0, otherWord = second ? word0 : word1;
+                    const float    otherT = second ? t0 : t1;
+                    if (hit0 || hit1)
                     {
-                        node = nearWord;
-                        if (hitFar && !push(farWord, tFar))
+                        node = firstWord;
+                        if (both && !push(otherWord, otherT))
                         {
                             needScalar = true;
                             node = kNodeDone;
                         }
                     }
-                    else if (hitFar) node = farWord;
                     else popNext();
                 }
             }
@@ -624,12 +679,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                         finished = true;
                         break;
                     }
+                    // the offset hit point (wgsl:511-519) is rebuilt from (triangle, u, v) by kShade
                     rayTMax = th.t;
-                    const Vec3 e1 = p1 - p0, e2 = p2 - p0;
-                    const Vec3 p = p0 + th.u * e1 + th.v * e2;
-                    const Vec3 nrm = normalize(cross(e1, e2));
-                    best.p = offsetRay(p, nrm);
-                    best.t = th.t;
                     best.u = th.u;
                     best.v = th.v;
                     best.triangle = tri;
@@ -647,6 +698,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                 // axis-parallel / denormal / non-finite rays (0 * inf slabs) and rays whose stack outgrew
                 // LDS: the reference's own scalar traversal, whole ray at once
                 TraversalCounters c2;
+                atomicAdd(&counters->scalarRedo[ANY_HIT ? 1 : 0], 1ull);
                 best.triangle = kMiss;
                 occluded = traverse<ANY_HIT, COUNT, 0>(scene, vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, tMax, nullptr, best, c2);
                 rayTMax = best.triangle != kMiss ? best.t : tMax;
@@ -673,7 +725,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             {
                 // .w = t of the hit (rayTMax == best.t then); read by the query path only
                 ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, rayTMax);
-                if (best.triangle != kMiss) ps.rayO[slot] = make_float4(best.p.x, best.p.y, best.p.z, 0.0f);
             }
             node = kNodeIdle;
         }
@@ -709,6 +760,18 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
 }
 
+
+// Query path: offset hit points of a hit stream (the render path does this in kShade).
+__global__ void kHitPoints(DeviceScene scene, const float4* hit, float4* rayO, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4   h = hit[i];
+    const uint32_t tri = __float_as_uint(h.x);
+    if (tri == kMiss) return;
+    const Vec3 hp = hitPoint(scene, tri, h.y, h.z);
+    rayO[i] = make_float4(hp.x, hp.y, hp.z, 0.0f);
+}
 
 // Queue occupancy per bounce: Q[b-1] paths enter bounce b (closest-hit rays), Q[b] of them hit
 // something (shadow rays).  Folded into running totals at the end of every batch.
@@ -1109,6 +1172,7 @@ struct Renderer::Impl
         {
             hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
                                queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+            hipLaunchKernelGGL(kHitPoints, dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
         }
         RF_HIP(hipGetLastError());
         RF_HIP(hipStreamSynchronize(stream));
@@ -1262,6 +1326,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         m.wide.rootLo = wb.rootLo;
         m.wide.rootHi = wb.rootHi;
         m.wide.rootLeaf = wb.rootLeaf;
+        m.wide.numRecords = static_cast<uint32_t>(wb.nodes.size() / 4);
         m.wideUsable = wb.boxesRegular; // NaN / inverted boxes: only the reference-ordered scalar kernels are exact
     }
     m.triangles.upload(reinterpret_cast<const float4*>(sceneView.positionAttributes.data()), 3 * sceneView.positionAttributes.size());
@@ -1542,6 +1607,8 @@ RenderStats Renderer::stats()
     s.closestRecordFetches = c.closestRecordFetches;
     s.shadowRecordFetches = c.shadowRecordFetches;
     s.paths = c.primaryRays;
+    if (std::getenv("RF_DEBUG_COUNTERS"))
+        std::fprintf(stderr, "[rf] rays redone by the scalar traversal: closest %llu of %llu, shadow %llu of %llu\n", c.scalarRedo[0], c.closestRays, c.scalarRedo[1], c.shadowRays);
     if (std::getenv("RF_DEBUG_COUNTERS") && m.counting)
     {
         for (int k = 0; k < 2; ++k)

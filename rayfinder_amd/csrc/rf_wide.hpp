@@ -44,6 +44,7 @@ struct WideScene
     float4        rootLo;    // root box (w unused)
     float4        rootHi;
     uint32_t      rootLeaf;  // child word of the root if the whole tree is one leaf, else kWideNone
+    uint32_t      numRecords;
 };
 
 struct WideBuild
@@ -52,7 +53,7 @@ struct WideBuild
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
-    bool                boxesRegular = true; // every child box finite with min <= max (see slabPair)
+    bool                boxesRegular = true; // every child box finite (|x| < 1e30) with min <= max (see slabPair)
 };
 
 // Host: 48-byte reference nodes -> wide records.
@@ -90,7 +91,7 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         const float lo[6] = {a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, b.aabb.min.x, b.aabb.min.y, b.aabb.min.z};
         const float hi[6] = {a.aabb.max.x, a.aabb.max.y, a.aabb.max.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z};
         for (int k = 0; k < 6; ++k)
-            if (!(std::isfinite(lo[k]) && std::isfinite(hi[k]) && lo[k] <= hi[k])) out.boxesRegular = false;
+            if (!(std::fabs(lo[k]) < 1e30f && std::fabs(hi[k]) < 1e30f && lo[k] <= hi[k])) out.boxesRegular = false;
     }
     if (out.bigLeaves.empty()) out.bigLeaves.push_back(make_uint2(0, 0));
     return out;
@@ -118,19 +119,27 @@ __device__ __forceinline__ bool slabBounds(const RayPrep& r, float4 lo, float4 h
 }
 
 // ---------------------------------------------------------------------------------------------
-// Both boxes of one record at once, for REGULAR rays: origin finite, 1/direction finite and
-// non-zero on all three axes (every ray except exactly axis-parallel / denormal-direction / NaN
-// ones), against ordered finite boxes (WideBuild::boxesRegular).  Then none of the twelve slab
-// products (b - o) * inv can be NaN, and per axis t(lo) <= t(hi) for inv > 0, t(hi) <= t(lo) for
-// inv < 0 (IEEE rounding is monotonic), so the reference's sign-selected near/far planes equal
-// min(t(lo), t(hi)) / max(t(lo), t(hi)) bit for bit, its ternary max/min chains equal the
+// Both boxes of one record at once.  Precondition: none of the twelve slab products
+// (b - o) * inv is NaN.  Then per axis t(lo) <= t(hi) for inv >= 0 and t(hi) <= t(lo) for inv < 0
+// (IEEE rounding is monotonic; +-inf included), so the reference's sign-selected near/far planes
+// equal min(t(lo), t(hi)) / max(t(lo), t(hi)) bit for bit, its ternary max/min chains equal the
 // hardware max3/min3, and its pairwise early-outs
 //     !(tmin > tymax) && !(tymin > tmax) && !(max(tmin,tymin) > tzmax) && !(tzmin > min(tmax,tymax))
 // are together equivalent to  max3(near) <= min3(far)  (each axis has near <= far; the remaining six
 // cross pairs are exactly the four tests).  So P and tmin are those of slabBounds(), with 12 packed
-// f32 ops + 16 min/max/compare instead of ~70 VALU and no data-dependent branches.  Rays that are
-// not regular never reach this function (kTraceWide runs the reference-ordered scalar traversal
-// for them).  Bit-equality with slabBounds() is checked on the GPU by tests/test_gpu_parity.py.
+// f32 ops + 16 min/max/compare instead of ~70 VALU and no data-dependent branches.
+//
+// When can a product be NaN, given ordered finite boxes (WideBuild::boxesRegular)?
+//   class A  origin finite (|o| < 1e30), 1/direction finite on all axes: never
+//            (b - o is finite, finite * finite is not NaN);
+//   class B  origin finite, some 1/direction component = +-inf (direction component +-0 or denormal:
+//            axis-aligned walls + a blue-noise value of exactly 0 make these ~0.3 % of all rays):
+//            only 0 * inf, i.e. when the origin lies EXACTLY on a plane of the box being tested --
+//            checked per step (slabPairHasNaN) for these lanes only;
+//   class C  anything else (NaN direction, non-finite origin): always assumed.
+// A ray for which a NaN is possible (class C) or occurs (class B) is redone whole by the
+// reference-ordered scalar traversal (kTraceWide), so results stay bit-identical in every case.
+// Bit-equality with slabBounds() is checked on the GPU by tests/test_gpu_parity.py.
 // ---------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -140,11 +149,20 @@ struct PackedRay
     v2f iXY, iZX, iYZ; // 1 / direction
 };
 
-__device__ __forceinline__ bool isRegularRay(const RayPrep& r)
+enum RayClass : uint32_t
 {
-    const bool fo = __builtin_isfinite(r.origin.x) && __builtin_isfinite(r.origin.y) && __builtin_isfinite(r.origin.z);
+    kRayPlain = 0,    // class A
+    kRayHasInf = 1,   // class B
+    kRayIrregular = 2 // class C
+};
+
+__device__ __forceinline__ uint32_t classifyRay(const RayPrep& r)
+{
+    const bool fo = fabsf(r.origin.x) < 1e30f && fabsf(r.origin.y) < 1e30f && fabsf(r.origin.z) < 1e30f; // false for NaN
+    const bool nanInv = r.invDir.x != r.invDir.x || r.invDir.y != r.invDir.y || r.invDir.z != r.invDir.z;
+    if (!fo || nanInv) return kRayIrregular;
     const bool fi = __builtin_isfinite(r.invDir.x) && __builtin_isfinite(r.invDir.y) && __builtin_isfinite(r.invDir.z);
-    return fo && fi && r.invDir.x != 0.0f && r.invDir.y != 0.0f && r.invDir.z != 0.0f;
+    return fi ? kRayPlain : kRayHasInf;
 }
 
 __device__ __forceinline__ PackedRay packRay(const RayPrep& r)
@@ -176,6 +194,19 @@ __device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q
     ok1 = near1 <= far1 && far1 > 0.0f;
     tmin0 = near0;
     tmin1 = near1;
+}
+
+// Class B lanes only: is any of the twelve slab products of this record NaN (0 * inf)?
+__device__ __forceinline__ bool slabPairHasNaN(const PackedRay& r, float4 q0, float4 q1, float4 q2)
+{
+    const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY;
+    const v2f b = (v2f{q0.z, q0.w} - r.oZX) * r.iZX;
+    const v2f c = (v2f{q1.x, q1.y} - r.oYZ) * r.iYZ;
+    const v2f d = (v2f{q1.z, q1.w} - r.oXY) * r.iXY;
+    const v2f e = (v2f{q2.x, q2.y} - r.oZX) * r.iZX;
+    const v2f f = (v2f{q2.z, q2.w} - r.oYZ) * r.iYZ;
+    return __builtin_isunordered(a.x, a.y) || __builtin_isunordered(b.x, b.y) || __builtin_isunordered(c.x, c.y) ||
+           __builtin_isunordered(d.x, d.y) || __builtin_isunordered(e.x, e.y) || __builtin_isunordered(f.x, f.y);
 }
 
 #endif

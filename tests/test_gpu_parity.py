@@ -133,6 +133,13 @@ def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tm
     rays[-100:-50, 3] = np.float32(1e-42)                 # denormal component: 1/d = inf
     rays[-150:-100, 0] = np.float32(np.nan)               # NaN origin
     rays[-200:-150, 3:] *= np.float32(1e30)               # huge directions
+    # 0 * inf slabs: a zero direction component with the origin EXACTLY on a plane of a node's box
+    nodes = duck_oracle.nodes
+    for i in range(2000):
+        nd = nodes[rng.integers(0, len(nodes))]
+        ax = int(rng.integers(0, 3))
+        rays[1000 + i, ax] = nd["min" if i % 2 else "max"][ax]
+        rays[1000 + i, 3 + ax] = np.float32(0.0) if i % 4 < 2 else np.float32(-0.0)
     r, _ = _renderer(duck_pt, 64, 64, 1, 1)
     r.set_option("query_variant", 2)
     with np.errstate(all="ignore"):
