@@ -123,13 +123,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=32)   # one full batch (32 samples of 1080p = 64 Mi paths)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--scene", default=os.environ.get("RF_SCENE", ""), help="Sponza.pt / Sponza.glb; default: synthetic atrium")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-counting", action="store_true", help="skip the untimed counting pass (profiling runs): roofline.achieved is null then")
     args = ap.parse_args()
 
     import torch
@@ -189,6 +190,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     s = r.stats()
+    bs = r.bounce_stats()   # queue occupancy and traversal time per bounce of the timed region (this rank)
+    per_bounce = [dict(bounce=i + 1, closest_rays=int(bs["closest_rays"][i]), ms_closest=round(float(bs["ms_closest"][i]), 3),
+                       shadow_rays=int(bs["shadow_rays"][i]), ms_shadow=round(float(bs["ms_shadow"][i]), 3)) for i in range(len(bs["closest_rays"]))]
     r.set_timing(False)
 
     rays_local = s["closest_rays"] + s["shadow_rays"]
@@ -203,44 +207,52 @@ def main():
         rays_total, closest_total, shadow_total, paths_total = float(rays_local), float(s["closest_rays"]), float(s["shadow_rays"]), float(s["primary_rays"])
 
     # counting pass (untimed): node visits / triangle tests of exactly the timed frames on this rank
-    r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25))
-    # frameCount is now WU + K; the counting pass must see the same sample indices as the timed one
-    # (n = frameCount % spp): the timed pass used frames WU..WU+K-1, this one WU+K..WU+2K-1 == same set mod K
-    r.set_counting(True)
-    r.reset_stats()
-    r.render(K)
-    r.synchronize()
-    cs = r.stats()
-    r.set_counting(False)
-    assert cs["closest_rays"] == s["closest_rays"] and cs["shadow_rays"] == s["shadow_rays"], "counting pass traced different rays"
+    cs = None
+    if not args.no_counting:
+        r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25))
+        # frameCount is now WU + K; the counting pass must see the same sample indices as the timed one
+        # (n = frameCount % spp): the timed pass used frames WU..WU+K-1, this one WU+K..WU+2K-1 == same set mod K
+        r.set_counting(True)
+        r.reset_stats()
+        r.render(K)
+        r.synchronize()
+        cs = r.stats()
+        r.set_counting(False)
+        assert cs["closest_rays"] == s["closest_rays"] and cs["shadow_rays"] == s["shadow_rays"], "counting pass traced different rays"
 
     # roofline of the dominant kernel (closest-hit traversal), SURVEY.md 8(d) bytes
-    bytes_closest = 28 * cs["closest_rays"] + 16 * cs["closest_rays"] + 48 * (cs["closest_node_visits"] + cs["closest_triangle_tests"])
-    bytes_shadow = 28 * cs["shadow_rays"] + 4 * cs["shadow_rays"] + 48 * (cs["shadow_node_visits"] + cs["shadow_triangle_tests"])
     launches = max(s["launches_closest"], 1)
     avg_ms = s["ms_closest"] / launches
-    achieved = bytes_closest / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            if pmc.get("kernel") == "kTraceWide<closest>" and pmc.get("workload") == f"{W}x{H}x{B}":
+            # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes of the SAME command
+            # (same frame, bounces, steps per launch); launches differ in size, the figure is their average
+            if pmc.get("kernel") == "kTraceWide<closest>" and pmc.get("workload") == f"{W}x{H}x{B}" and pmc.get("launches_per_128_steps") == round(launches * 128 / K):
                 traffic = pmc.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                    traffic=traffic, kernel="kTraceWide<closest>", avg_launch_ms=round(avg_ms, 4), launches=launches,
-                    algorithmic_bytes_per_launch=int(bytes_closest / launches),
-                    node_visits_per_ray=round(cs["closest_node_visits"] / max(cs["closest_rays"], 1), 2),
-                    triangle_tests_per_ray=round(cs["closest_triangle_tests"] / max(cs["closest_rays"], 1), 2),
-                    shadow_kernel_GBps=round(bytes_shadow / max(s["ms_shadow"], 1e-9) / 1e6, 1),
-                    # what the kernel itself requests: 64 B per wide record + 48 B per triangle + ray I/O (the wide layout
-                    # needs one record per two reference node visits, so this is below the algorithmic figure)
-                    requested_GBps=round((44 * cs["closest_rays"] + 64 * cs["closest_record_fetches"] + 48 * cs["closest_triangle_tests"])
-                                         / max(s["ms_closest"], 1e-9) / 1e6, 1),
-                    record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2))
-
+    if cs is not None:
+        bytes_closest = 28 * cs["closest_rays"] + 16 * cs["closest_rays"] + 48 * (cs["closest_node_visits"] + cs["closest_triangle_tests"])
+        bytes_shadow = 28 * cs["shadow_rays"] + 4 * cs["shadow_rays"] + 48 * (cs["shadow_node_visits"] + cs["shadow_triangle_tests"])
+        achieved = bytes_closest / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
+                        traffic=traffic, kernel="kTraceWide<closest>", avg_launch_ms=round(avg_ms, 4), launches=launches,
+                        algorithmic_bytes_per_launch=int(bytes_closest / launches),
+                        rays_per_launch=int(cs["closest_rays"] / launches),
+                        node_visits_per_ray=round(cs["closest_node_visits"] / max(cs["closest_rays"], 1), 2),
+                        triangle_tests_per_ray=round(cs["closest_triangle_tests"] / max(cs["closest_rays"], 1), 2),
+                        shadow_kernel_GBps=round(bytes_shadow / max(s["ms_shadow"], 1e-9) / 1e6, 1),
+                        # what the kernel itself requests: 64 B per wide record + 48 B per triangle + ray I/O (the wide layout
+                        # needs one record per two reference node visits, so this is below the algorithmic figure)
+                        requested_GBps=round((44 * cs["closest_rays"] + 64 * cs["closest_record_fetches"] + 48 * cs["closest_triangle_tests"])
+                                             / max(s["ms_closest"], 1e-9) / 1e6, 1),
+                        record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2))
+    else:
+        roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=traffic, kernel="kTraceWide<closest>",
+                        avg_launch_ms=round(avg_ms, 4), launches=launches)
     if rank == 0:
         image = assemble(parts, W, H, world)      # read-back + un-tile, outside the timed region for every N
         nan_pixels = int(np.isnan(image[..., :3]).any(axis=-1).sum())
@@ -264,6 +276,7 @@ def main():
             "rays": {"closest": int(closest_total), "shadow": int(shadow_total)},
             "kernel_ms_rank0": {k: round(s[k], 3) for k in ("ms_raygen", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")},
             "nan_pixels": nan_pixels,
+            "per_bounce_rank0": per_bounce,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
