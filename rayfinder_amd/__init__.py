@@ -101,6 +101,19 @@ def build_bvh(positions36):
     return nodes[:cnt.value].copy(), idx, depth.value
 
 
+def build_bvh_gpu(positions36, device_ordinal=0):
+    """GPU build of the same tree (rf_bvh_gpu.hip) -> (nodes, triangleIndices, depth, build_ms)."""
+    tris = _f32(positions36).reshape(-1, 9)
+    n = tris.shape[0]
+    nodes = np.zeros(max(2 * n, 1), dtype=NODE_DTYPE)
+    idx = np.zeros(n, np.uint64)
+    cnt = C.c_uint64(0)
+    depth = C.c_int32(0)
+    ms = C.c_float(0)
+    check(lib.rf_build_bvh_gpu(_ptr(tris), n, _ptr(nodes), C.byref(cnt), _ptr(idx), C.byref(depth), device_ordinal, C.byref(ms)))
+    return nodes[:cnt.value].copy(), idx, depth.value, ms.value
+
+
 def tiles_for_rank(width, height, rank, world_size):
     n = C.c_uint32(0)
     check(lib.rf_tiles_for_rank(width, height, rank, world_size, None, C.byref(n)))

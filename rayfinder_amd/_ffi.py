@@ -15,6 +15,16 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build the HIP extension first (make -C rayfinder_amd/csrc). "
         "rayfinder_amd has no CPU fallback.")
 
+# Load order: the PyTorch wheel bundles its own HIP + HSA runtimes (torch/lib/libamdhip64.so, no
+# SONAME), this library links ROCm's (libamdhip64.so.7).  Both can live in one process, but only if
+# PyTorch's copies are mapped first -- with this library first, whichever runtime initialises second
+# reports "no ROCm-capable device" (seen on the MI355X box: `pytest tests/test_gpu_parity.py` alone
+# failed while `pytest tests` passed, because another test module imported torch earlier).  So when
+# torch is installed it is imported before the dlopen; the C++ CLI tools never see PyTorch at all.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
 lib = C.CDLL(LIB_PATH)
 
 RF_OK = 0
@@ -115,6 +125,7 @@ SIGNATURES = {
     "rf_renderer_intersect_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float] + [C.c_void_p] * 6),
     "rf_renderer_occluded_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]),
     "rf_build_bvh": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_int32)]),
+    "rf_build_bvh_gpu": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "rf_create_camera": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Camera)]),
     "rf_fly_camera": (C.c_int, [C.c_void_p] + [C.c_float] * 6 + [C.POINTER(Camera)]),
     "rf_bvh_visualizer_camera": (C.c_int, [C.c_void_p, C.c_float, C.POINTER(Camera)]),

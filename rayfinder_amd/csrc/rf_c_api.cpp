@@ -3,6 +3,7 @@
 #include "../../include/rayfinder_amd.h"
 
 #include "rf_bvh.hpp"
+#include "rf_bvh_gpu.hpp"
 #include "rf_camera.hpp"
 #include "rf_gltf.hpp"
 #include "rf_pt_format.hpp"
@@ -389,6 +390,22 @@ int rf_build_bvh(const float* positions36, uint64_t num_triangles, void* nodes_o
         require(positions36 && nodes_out && num_nodes_out && triangle_indices_out, "null argument");
         require(num_triangles > 0, "buildBvh needs at least one triangle"); // bvh.cpp:265 asserts
         const rf::Bvh bvh = rf::buildBvh({reinterpret_cast<const rf::Positions*>(positions36), static_cast<size_t>(num_triangles)});
+        std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rf::BvhNode));
+        *num_nodes_out = bvh.nodes.size();
+        for (size_t i = 0; i < bvh.triangleIndices.size(); ++i) triangle_indices_out[i] = bvh.triangleIndices[i];
+        if (depth_out) *depth_out = bvh.depth;
+        return RF_OK;
+    });
+}
+
+int rf_build_bvh_gpu(const float* positions36, uint64_t num_triangles, void* nodes_out, uint64_t* num_nodes_out, uint64_t* triangle_indices_out,
+                     int32_t* depth_out, int32_t device_ordinal, float* build_ms_out)
+{
+    return guarded([&] {
+        require(positions36 && nodes_out && num_nodes_out && triangle_indices_out, "null argument");
+        require(num_triangles > 0, "buildBvh needs at least one triangle"); // bvh.cpp:265 asserts
+        const rf::Bvh bvh = rf::buildBvhGpu({reinterpret_cast<const rf::Positions*>(positions36), static_cast<size_t>(num_triangles)}, device_ordinal,
+                                            build_ms_out);
         std::memcpy(nodes_out, bvh.nodes.data(), bvh.nodes.size() * sizeof(rf::BvhNode));
         *num_nodes_out = bvh.nodes.size();
         for (size_t i = 0; i < bvh.triangleIndices.size(); ++i) triangle_indices_out[i] = bvh.triangleIndices[i];
