@@ -248,6 +248,8 @@ typedef struct rf_pt_format_view
 } rf_pt_format_view;
 
 /* PtFormat(std::filesystem::path gltfPath) (pt_format.cpp:20-151): glTF/GLB -> BVH + GPU arrays. */
+/* BVH builder used by rf_pt_format_from_gltf / _from_triangles: -1 = host (default), >= 0 = rf_build_bvh_gpu on that device. */
+RF_API int rf_pt_format_set_bvh_builder(int32_t gpu_device_or_minus_one);
 RF_API int rf_pt_format_from_gltf(const char* gltf_path, rf_pt_format** out);
 /* deserialize(InputStream&, PtFormat&) (pt_format.cpp:271-321) from a file / from memory.
  * Wrong magic -> RF_ERROR_RUNTIME with the reference's exact messages (src/tests/pt_format.cpp:192-210). */

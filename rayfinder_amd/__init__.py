@@ -101,6 +101,11 @@ def build_bvh(positions36):
     return nodes[:cnt.value].copy(), idx, depth.value
 
 
+def set_bake_bvh_builder(gpu_device=None):
+    """BVH builder of PtFormat.from_gltf / from_triangles: None = host (default), int = GPU builder on that device."""
+    check(lib.rf_pt_format_set_bvh_builder(-1 if gpu_device is None else int(gpu_device)))
+
+
 def build_bvh_gpu(positions36, device_ordinal=0):
     """GPU build of the same tree (rf_bvh_gpu.hip) -> (nodes, triangleIndices, depth, build_ms)."""
     tris = _f32(positions36).reshape(-1, 9)

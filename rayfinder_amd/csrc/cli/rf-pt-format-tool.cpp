@@ -2,16 +2,27 @@
 // Command-line behaviour of the reference's src/pt-format-tool/main.cpp:16-44.
 #include "cli_common.hpp"
 
+#include <cstdlib>
 #include <filesystem>
+#include <string>
 
 int main(int argc, char** argv)
 {
-    if (argc != 2)
+    // extension over the reference's tool: --gpu-bvh[=device] builds the BVH with rf_build_bvh_gpu
+    int gpuDevice = -1, argi = 1;
+    if (argc >= 2 && std::string(argv[1]).rfind("--gpu-bvh", 0) == 0)
     {
-        std::printf("Usage:\n\trf-pt-format-tool <input_gltf_file>\n");
+        const std::string a = argv[1];
+        gpuDevice = a.size() > 10 ? std::atoi(a.c_str() + 10) : 0;
+        argi = 2;
+    }
+    if (argc != argi + 1)
+    {
+        std::printf("Usage:\n\trf-pt-format-tool [--gpu-bvh[=device]] <input_gltf_file>\n");
         return 0;
     }
-    std::filesystem::path path = argv[1];
+    rfCheck(rf_pt_format_set_bvh_builder(gpuDevice), "select BVH builder");
+    std::filesystem::path path = argv[argi];
     if (!std::filesystem::exists(path))
     {
         std::fprintf(stderr, "File %s does not exist\n", path.string().c_str());

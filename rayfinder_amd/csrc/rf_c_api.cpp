@@ -479,6 +479,14 @@ int rf_aligned_sky_state(const rf_sky* sky, float out40[40])
 }
 
 // ---------------------------------------------------------------------------------------- .pt files
+int rf_pt_format_set_bvh_builder(int32_t gpu_device_or_minus_one)
+{
+    return guarded([&] {
+        rf::setBakeBvhBuilder(gpu_device_or_minus_one);
+        return RF_OK;
+    });
+}
+
 int rf_pt_format_from_gltf(const char* gltf_path, rf_pt_format** out)
 {
     return guarded([&] {

@@ -1,5 +1,7 @@
 #include "rf_gltf.hpp"
 
+#include "rf_bvh_gpu.hpp"
+
 #include "rf_bvh.hpp"
 
 #include <zlib.h>
@@ -955,11 +957,19 @@ GltfModel loadGltfModel(const std::string& pathString)
     return model;
 }
 
+namespace
+{
+// which builder the bake uses: -1 = host (the reference's recursion restated, rf_bvh.cpp), >= 0 = that GPU (rf_bvh_gpu.hip)
+int gBakeBvhDevice = -1;
+} // namespace
+
+void setBakeBvhBuilder(int gpuDeviceOrMinusOne) { gBakeBvhDevice = gpuDeviceOrMinusOne; }
+
 PtFormat ptFormatFromTriangles(std::span<const Positions> positions, std::span<const Normals> normals, std::span<const TexCoords> texCoords,
                                std::span<const uint32_t> textureIndices, std::vector<Texture> textures)
 {
     PtFormat  out;
-    const Bvh bvh = buildBvh(positions);
+    const Bvh bvh = gBakeBvhDevice >= 0 ? buildBvhGpu(positions, gBakeBvhDevice) : buildBvh(positions);
     const std::span<const std::size_t> order(bvh.triangleIndices);
     out.bvhNodes = bvh.nodes;
     out.bvhPositionAttributes = reorderAttributes(positions, order);

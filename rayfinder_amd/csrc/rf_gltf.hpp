@@ -38,6 +38,9 @@ Texture textureFromMemory(std::span<const uint8_t> data);
 // Texture::fromPixel (texture.cpp:56-65)
 Texture textureFromPixel(float r, float g, float b, float a);
 
+// BVH builder used by the two bakes below: -1 = host builder (default), >= 0 = GPU builder on that device
+// (same node bytes; see rf_bvh_gpu.hpp for the order inside multi-triangle leaves).
+void     setBakeBvhBuilder(int gpuDeviceOrMinusOne);
 PtFormat ptFormatFromGltf(const std::string& path);
 PtFormat ptFormatFromTriangles(std::span<const Positions> positions, std::span<const Normals> normals, std::span<const TexCoords> texCoords,
                                std::span<const uint32_t> textureIndices, std::vector<Texture> textures);

@@ -102,3 +102,24 @@ def test_traversal_through_gpu_built_tree(duck_oracle):
     b = orc.intersect_bvh_batch(ref_nodes, tris_r, rays, 10000.0)
     assert np.array_equal(a["hit"], b["hit"]) and np.array_equal(bits(a["t"]), bits(b["t"]))
     assert np.array_equal(a["nodesVisited"], b["nodesVisited"])
+
+
+def test_bake_with_the_gpu_builder_renders_the_same_image(duck_pt):
+    """Duck.glb baked with the GPU builder: same node bytes as the host bake, and the path tracer's
+    accumulation image is bit-identical (Duck's multi-triangle leaves hold no exact ties)."""
+    from conftest import DUCK
+    rf.set_bake_bvh_builder(0)
+    try:
+        pt_gpu = rf.PtFormat.from_gltf(DUCK)
+    finally:
+        rf.set_bake_bvh_builder(None)
+    a, b = pt_gpu.arrays(), duck_pt.arrays()
+    assert a["bvhNodes"].tobytes() == b["bvhNodes"].tobytes()
+    W, H, spp, bounces = 160, 120, 4, 3
+    imgs = []
+    for pt in (pt_gpu, duck_pt):
+        r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.25), pt.scene())
+        r.render(spp)
+        imgs.append(r.read_accumulation()[0])
+        r.close()
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
