@@ -264,6 +264,9 @@ RF_API int rf_pt_format_serialize(const rf_pt_format* f, void* dst /* NULL = siz
 RF_API int rf_pt_format_from_triangles(const float* positions36, const float* normals36, const float* tex_coords24,
                                        const uint32_t* texture_indices, uint64_t num_triangles, const rf_texture* textures,
                                        uint64_t num_textures, rf_pt_format** out);
+/* Texture::fromMemory (src/common/texture.hpp:41, texture.cpp:12-54): PNG or JPEG bytes -> width*height
+ * BGRA8 texels packed as u32 (b | g<<8 | r<<16 | 255<<24).  pixels == NULL: size query. */
+RF_API int  rf_texture_from_memory(const void* data, uint64_t size, uint32_t* width, uint32_t* height, uint32_t* pixels);
 RF_API int  rf_pt_format_view_get(const rf_pt_format* f, rf_pt_format_view* out);
 RF_API int  rf_pt_format_texture(const rf_pt_format* f, uint64_t index, rf_texture* out);
 RF_API void rf_pt_format_destroy(rf_pt_format* f);

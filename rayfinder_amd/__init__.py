@@ -101,6 +101,16 @@ def build_bvh(positions36):
     return nodes[:cnt.value].copy(), idx, depth.value
 
 
+def texture_from_memory(data):
+    """Texture::fromMemory (texture.cpp:12-54): PNG / JPEG bytes -> (BGRA u32 texels [h*w], width, height)."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    check(lib.rf_texture_from_memory(_ptr(buf), buf.size, C.byref(w), C.byref(h), None))
+    px = np.zeros(w.value * h.value, np.uint32)
+    check(lib.rf_texture_from_memory(_ptr(buf), buf.size, C.byref(w), C.byref(h), _ptr(px)))
+    return px, w.value, h.value
+
+
 def set_bake_bvh_builder(gpu_device=None):
     """BVH builder of PtFormat.from_gltf / from_triangles: None = host (default), int = GPU builder on that device."""
     check(lib.rf_pt_format_set_bvh_builder(-1 if gpu_device is None else int(gpu_device)))

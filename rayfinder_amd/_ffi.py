@@ -132,6 +132,7 @@ SIGNATURES = {
     "rf_sky_state_new": (C.c_int, [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rf_sky_state_radiance": (C.c_float, [C.c_void_p, C.c_float, C.c_float, C.c_int]),
     "rf_aligned_sky_state": (C.c_int, [C.POINTER(Sky), C.c_void_p]),
+    "rf_texture_from_memory": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_pt_format_set_bvh_builder": (C.c_int, [C.c_int32]),
     "rf_pt_format_from_gltf": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rf_pt_format_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),

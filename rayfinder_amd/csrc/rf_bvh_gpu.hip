@@ -81,14 +81,6 @@ __device__ __forceinline__ Box decodeBox(const EncBox& e)
     b.hi = vec3(decodeFloat(e.hi[0]), decodeFloat(e.hi[1]), decodeFloat(e.hi[2]));
     return b;
 }
-__device__ __forceinline__ EncBox encodeBox(const Box& b)
-{
-    EncBox e;
-    e.lo[0] = encodeFloat(b.lo.x), e.lo[1] = encodeFloat(b.lo.y), e.lo[2] = encodeFloat(b.lo.z);
-    e.hi[0] = encodeFloat(b.hi.x), e.hi[1] = encodeFloat(b.hi.y), e.hi[2] = encodeFloat(b.hi.z);
-    return e;
-}
-
 // A triangle in flight: bounds, centroid, source index.  Two float4 + one float2 streams, moved
 // physically by every partition so that each pass reads them coalesced.
 struct PrimStreams

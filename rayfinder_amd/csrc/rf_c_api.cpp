@@ -479,6 +479,18 @@ int rf_aligned_sky_state(const rf_sky* sky, float out40[40])
 }
 
 // ---------------------------------------------------------------------------------------- .pt files
+int rf_texture_from_memory(const void* data, uint64_t size, uint32_t* width, uint32_t* height, uint32_t* pixels)
+{
+    return guarded([&] {
+        require(data && width && height, "null argument");
+        const rf::Texture t = rf::textureFromMemory({static_cast<const uint8_t*>(data), static_cast<size_t>(size)});
+        *width = t.width;
+        *height = t.height;
+        if (pixels) std::memcpy(pixels, t.pixels.data(), t.pixels.size() * sizeof(uint32_t));
+        return RF_OK;
+    });
+}
+
 int rf_pt_format_set_bvh_builder(int32_t gpu_device_or_minus_one)
 {
     return guarded([&] {

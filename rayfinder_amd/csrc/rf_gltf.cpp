@@ -1,6 +1,7 @@
 #include "rf_gltf.hpp"
 
 #include "rf_bvh_gpu.hpp"
+#include "rf_jpeg.hpp"
 
 #include "rf_bvh.hpp"
 
@@ -634,16 +635,10 @@ void unfilter(const uint8_t* in, uint8_t* out, std::size_t rowBytes, std::size_t
     }
 }
 
-struct Rgba8Image
-{
-    std::vector<uint8_t> rgba;
-    uint32_t             width = 0, height = 0;
-};
-
 Rgba8Image decodePng(std::span<const uint8_t> data)
 {
     static const uint8_t kSig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    if (data.size() < 8 || std::memcmp(data.data(), kSig, 8) != 0) throw std::runtime_error("image is not a PNG (only PNG textures are supported)");
+    if (data.size() < 8 || std::memcmp(data.data(), kSig, 8) != 0) throw std::runtime_error("image is neither PNG nor JPEG (the only texture containers supported)");
     uint32_t             width = 0, height = 0;
     int                  depth = 0, colorType = 0, interlace = 0;
     std::vector<uint8_t> idat, palette, trns;
@@ -787,7 +782,8 @@ uint32_t hashFactor(const float (&f)[4])
 
 Texture textureFromMemory(std::span<const uint8_t> data)
 {
-    const Rgba8Image img = decodePng(data);
+    // stb_image sniffs the container (texture.cpp:12-31 passes whatever the glTF embeds): PNG or JPEG
+    const Rgba8Image img = looksLikeJpeg(data) ? decodeJpeg(data) : decodePng(data);
     Texture          t;
     t.width = img.width;
     t.height = img.height;
