@@ -155,7 +155,7 @@ class PtFormat:
         self._h = C.c_void_p(handle)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.rf_pt_format_destroy(self._h)
             self._h = None
 
@@ -282,7 +282,7 @@ class ReferencePathTracer:
         check(lib.rf_renderer_create(C.byref(desc), C.byref(scene), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # lib is None once the interpreter is shutting down
             lib.rf_renderer_destroy(self._h)
             self._h = None
 

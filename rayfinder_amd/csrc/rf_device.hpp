@@ -13,7 +13,8 @@
 //              reference's 48-B node, bvh.cpp:31-55); meta = triangleCount << 2 | axis (axis 3 =
 //              leaf).  32-B alignment means a node never straddles a 64-B line and one visit is
 //              two dwordx4 loads instead of three; results are bit-identical.
-//   triangles  48 B each, three float4 (the reference's PositionAttribute, unchanged).
+//   triangles  the reference's 48-B PositionAttribute (three float4) padded to 64 B, so that one
+//              triangle test is one 64-B L2 request instead of 1.5 on average.
 //   traversal stack: per-lane, first RF_LDS_STACK entries in LDS ([depth][lane], conflict free
 //              because lanes l and l+32 sit in different halves), overflow in scratch.
 #pragma once
@@ -29,11 +30,12 @@ constexpr int      kLdsStack = 24;        // entries kept in LDS per lane
 constexpr int      kSpillStack = 72;      // further entries in scratch (total depth 96)
 constexpr uint32_t kMiss = 0xFFFFFFFFu;
 constexpr uint32_t kLeafAxis = 3u;
+constexpr uint32_t kTriStride = 4u;     // float4 per device triangle: 48 B of PositionAttribute padded to one 64-B sector
 
 struct DeviceScene
 {
     const float4*            nodes;      // 2 per node
-    const float4*            triangles;  // 3 per triangle
+    const float4*            triangles;  // kTriStride per triangle (p0, p1, p2, pad)
     const VertexAttributes*  attributes; // 80 B each
     const TextureDescriptor* textureDescriptors;
     const uint32_t*          texels;
@@ -181,9 +183,9 @@ __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, 
                 for (uint32_t i = 0; i < count; ++i)
                 {
                     const uint32_t tri = link + i;
-                    const float4   a = scene.triangles[3 * tri];
-                    const float4   b = scene.triangles[3 * tri + 1];
-                    const float4   c = scene.triangles[3 * tri + 2];
+                    const float4   a = scene.triangles[kTriStride * tri];
+                    const float4   b = scene.triangles[kTriStride * tri + 1];
+                    const float4   c = scene.triangles[kTriStride * tri + 2];
                     if (COUNT) ++counters.triangleTests;
                     TriangleHit th;
                     const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);

@@ -236,9 +236,9 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
 // p = p0 + u*e1 + v*e2 offset along normalize(e1 x e2) (wgsl:511-519,523-544)
 __device__ __forceinline__ Vec3 hitPoint(const DeviceScene& scene, uint32_t tri, float u, float v)
 {
-    const float4 a = scene.triangles[3 * tri];
-    const float4 b = scene.triangles[3 * tri + 1];
-    const float4 c = scene.triangles[3 * tri + 2];
+    const float4 a = scene.triangles[kTriStride * tri];
+    const float4 b = scene.triangles[kTriStride * tri + 1];
+    const float4 c = scene.triangles[kTriStride * tri + 2];
     const Vec3   p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
     const Vec3   e1 = p1 - p0, e2 = p2 - p0;
     const Vec3   p = p0 + u * e1 + v * e2;
@@ -665,9 +665,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             {
                 if (COUNT) ++wLeaf;
                 const uint32_t tri = first + i;
-                const float4   a = scene.triangles[3 * tri];
-                const float4   b = scene.triangles[3 * tri + 1];
-                const float4   c = scene.triangles[3 * tri + 2];
+                const float4   a = scene.triangles[kTriStride * tri];
+                const float4   b = scene.triangles[kTriStride * tri + 1];
+                const float4   c = scene.triangles[kTriStride * tri + 2];
                 if (COUNT) ++rayTris;
                 TriangleHit th;
                 const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
@@ -1329,7 +1329,19 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         m.wide.numRecords = static_cast<uint32_t>(wb.nodes.size() / 4);
         m.wideUsable = wb.boxesRegular; // NaN / inverted boxes: only the reference-ordered scalar kernels are exact
     }
-    m.triangles.upload(reinterpret_cast<const float4*>(sceneView.positionAttributes.data()), 3 * sceneView.positionAttributes.size());
+    {
+        // 48-B PositionAttribute -> 64-B aligned device triangles (one L2 sector per triangle test)
+        const size_t        n = sceneView.positionAttributes.size();
+        std::vector<float4> padded(kTriStride * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        for (size_t i = 0; i < n; ++i)
+        {
+            const PositionAttribute& t = sceneView.positionAttributes[i];
+            padded[kTriStride * i] = make_float4(t.p0.x, t.p0.y, t.p0.z, 0.0f);
+            padded[kTriStride * i + 1] = make_float4(t.p1.x, t.p1.y, t.p1.z, 0.0f);
+            padded[kTriStride * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
+        }
+        m.triangles.upload(padded.data(), padded.size());
+    }
     m.attributes.upload(sceneView.vertexAttributes.data(), sceneView.vertexAttributes.size());
 
     // texture blob + descriptors in the order of the model's textures (reference_path_tracer.cpp:210-270)
