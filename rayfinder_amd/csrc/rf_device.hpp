@@ -36,7 +36,7 @@ struct DeviceScene
 {
     const float4*            nodes;      // 2 per node
     const float4*            triangles;  // kTriStride per triangle (p0, p1, p2, pad)
-    const VertexAttributes*  attributes; // 80 B each
+    const float4*            attributes; // 4 per triangle: the 80-B VertexAttributes packed to 64 B (rf_renderer.hip)
     const TextureDescriptor* textureDescriptors;
     const uint32_t*          texels;
     uint64_t                 numTexels;

@@ -294,12 +294,15 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         const float4            nz = ps.noise[slot];
         const Vec3              throughput = vec3(thr4.x, thr4.y, thr4.z);
         const float             nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
-        const VertexAttributes& va = scene.attributes[tri];
-        const float             b0 = 1.0f - h.y - h.z, b1 = h.y, b2 = h.z; // wgsl:515
-        const Vec3              n = (b0 * va.n0 + b1 * va.n1) + b2 * va.n2; // not normalised, wgsl:396
-        const float             uvx = (b0 * va.uv0.x + b1 * va.uv1.x) + b2 * va.uv2.x;
-        const float             uvy = (b0 * va.uv0.y + b1 * va.uv1.y) + b2 * va.uv2.y;
-        const Vec3              albedo = evalTexture(scene, va.textureIdx, uvx, uvy);
+        // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
+        const float4* va = scene.attributes + 4 * static_cast<size_t>(tri);
+        const float4  a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
+        const Vec3    n0 = vec3(a0.x, a0.y, a0.z), n1 = vec3(a0.w, a1.x, a1.y), n2 = vec3(a1.z, a1.w, a2.x);
+        const float   b0 = 1.0f - h.y - h.z, b1 = h.y, b2 = h.z; // wgsl:515
+        const Vec3    n = (b0 * n0 + b1 * n1) + b2 * n2;         // not normalised, wgsl:396
+        const float   uvx = (b0 * a2.y + b1 * a2.w) + b2 * a3.y;
+        const float   uvy = (b0 * a2.z + b1 * a3.x) + b2 * a3.z;
+        const Vec3    albedo = evalTexture(scene, __float_as_uint(a3.w), uvx, uvy);
 
         // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
         const Vec3 lightDirection = sunSample(sky, nx, cosPhi, sinPhi);
@@ -968,7 +971,7 @@ struct Renderer::Impl
     DeviceBuffer<float4>            nodes, triangles, wideNodes;
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
-    DeviceBuffer<VertexAttributes>  attributes;
+    DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
     DeviceBuffer<TextureDescriptor> textureDescriptors;
     DeviceBuffer<uint32_t>          texels;
     DeviceBuffer<uint8_t>           blueNoise;
@@ -1342,7 +1345,20 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         }
         m.triangles.upload(padded.data(), padded.size());
     }
-    m.attributes.upload(sceneView.vertexAttributes.data(), sceneView.vertexAttributes.size());
+    {
+        // 80-B VertexAttributes (three padded normals, three uvs, texture index, pad) -> 64 B = one L2 sector per shaded hit
+        const size_t        n = sceneView.vertexAttributes.size();
+        std::vector<float4> packed(4 * n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            const VertexAttributes& v = sceneView.vertexAttributes[i];
+            packed[4 * i] = make_float4(v.n0.x, v.n0.y, v.n0.z, v.n1.x);
+            packed[4 * i + 1] = make_float4(v.n1.y, v.n1.z, v.n2.x, v.n2.y);
+            packed[4 * i + 2] = make_float4(v.n2.z, v.uv0.x, v.uv0.y, v.uv1.x);
+            packed[4 * i + 3] = make_float4(v.uv1.y, v.uv2.x, v.uv2.y, bitsFloat(v.textureIdx));
+        }
+        m.attributes.upload(packed.data(), packed.size());
+    }
 
     // texture blob + descriptors in the order of the model's textures (reference_path_tracer.cpp:210-270)
     {
