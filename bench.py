@@ -253,6 +253,8 @@ def main():
     else:
         roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=traffic, kernel="kTraceWide<closest>",
                         avg_launch_ms=round(avg_ms, 4), launches=launches)
+    cfg_label = {(1920, 1080, 8): "BASELINE.json config 3" if world == 1 else "BASELINE.json config 4", (3840, 2160, 16): "BASELINE.json config 5",
+                 (800, 600, 4): "BASELINE.json config 2"}.get((W, H, B), "custom configuration")
     if rank == 0:
         image = assemble(parts, W, H, world)      # read-back + un-tile, outside the timed region for every N
         nan_pixels = int(np.isnan(image[..., :3]).any(axis=-1).sum())
@@ -269,7 +271,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{info['name']}, {W}x{H}, {K} spp, {B} bounces, default rayfinder camera + sky (config 3; tiled over {world} GPU(s))",
+            "config": {"workload": f"{info['name']}, {W}x{H}, {K} spp, {B} bounces, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
                        "scene_triangles": info.get("triangles"), "scene_textures": info.get("textures"), "scene_digest": info.get("digest"),
                        "sharding": f"32x32 tiles, scrambled round-robin over {world} rank(s), one RCCL gather at frame end" if world > 1 else "none"},
             "paths_per_s": round(paths_total / elapsed, 1),
