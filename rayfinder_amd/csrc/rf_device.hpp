@@ -260,7 +260,7 @@ constexpr uint32_t kSolarCosThetaMaxBits = 0x3F7FFF5Au;
 constexpr uint32_t kSolarInvPdfBits = 0x38826048u;
 
 // Duff et al. orthonormal basis, wgsl:309-319.  Returns columns u, v (third column is n).
-__device__ __forceinline__ void pixarOnb(Vec3 n, Vec3& u, Vec3& v)
+__host__ __device__ __forceinline__ void pixarOnb(Vec3 n, Vec3& u, Vec3& v)
 {
     const float s = (n.z >= 0.0f) ? 1.0f : -1.0f;
     const float a = -1.0f / (s + n.z);

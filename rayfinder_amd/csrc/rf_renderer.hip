@@ -246,19 +246,25 @@ __device__ __forceinline__ Vec3 hitPoint(const DeviceScene& scene, uint32_t tri,
 }
 
 // Sun direction sample for this path (wgsl:194,287-292,568-579): cone about sunDirection.
-__device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, float nx, float cosPhi, float sinPhi)
+// The orthonormal basis about the sun direction (wgsl:309-319 applied to sunDirection) is the same for
+// every sample of a frame: computed once on the host with the same f32 expressions and passed as kernel
+// arguments (SGPRs) instead of ~15 VALU instructions per sample.
+struct SunBasis
+{
+    Vec3 u, v;
+};
+
+__device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, const SunBasis& basis, float nx, float cosPhi, float sinPhi)
 {
     const float cosThetaMax = __uint_as_float(kSolarCosThetaMaxBits);
     const float cosTheta = 1.0f - nx * (1.0f - cosThetaMax);
     const float sinTheta = rf_sqrt(1.0f - cosTheta * cosTheta);
     const Vec3  local = vec3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
     const Vec3  sun = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
-    Vec3        bu, bv;
-    pixarOnb(sun, bu, bv);
-    return basisTimes(bu, bv, sun, local);
+    return basisTimes(basis.u, basis.v, sun, local);
 }
 
-__global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
+__global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                   const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
                                                   uint32_t* missCount, uint32_t isLastBounce)
 {
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         const Vec3    albedo = evalTexture(scene, __float_as_uint(a3.w), uvx, uvy);
 
         // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
-        const Vec3 lightDirection = sunSample(sky, nx, cosPhi, sinPhi);
+        const Vec3 lightDirection = sunSample(sky, sunBasis, nx, cosPhi, sinPhi);
         const Vec3 lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
         const Vec3 brdf = albedo * kFrac1Pi;
         const Vec3 reflectance = brdf * dot(n, lightDirection);
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, 
 }
 
 template<bool COUNT>
-__global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkyStateGpu sky, PathStreams ps, const uint32_t* queue,
+__global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                         const uint32_t* queueCount, DeviceCounters* counters)
 {
     __shared__ uint32_t sStack[kLdsStack * kBlock];
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
         const uint32_t slot = queue[i];
         const float4   o = ps.rayO[slot];
         const float4   nz = ps.noise[slot];
-        const Vec3     l = sunSample(sky, nz.x, nz.y, nz.z);
+        const Vec3     l = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
         ClosestHit     h;
         const bool     occluded = traverse<true, COUNT>(scene, vec3(o.x, o.y, o.z), l, kTMax, &sStack[threadIdx.x], h, tc);
         const float    visibility = occluded ? 0.0f : 1.0f;
@@ -442,7 +448,7 @@ constexpr int wideStackDepth()
 }
 
 template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false>
-__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, PathStreams ps,
+__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
                                                                                         const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
                                                                                         DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
                                                                                         uint32_t chunk, float tMax, uint32_t flags)
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                 if (ANY_HIT && !shadowDirFromStream)
                 {
                     const float4 nz = ps.noise[slot];
-                    dir = sunSample(sky, nz.x, nz.y, nz.z);
+                    dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
                 else
                 {
@@ -980,6 +986,9 @@ struct Renderer::Impl
 
     RenderParameters params;
     SkyStateGpu      sky{};
+    SunBasis         sunBasis{};
+
+    void updateSunBasis() { pixarOnb(vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]), sunBasis.u, sunBasis.v); }
     uint32_t         maxWidth = 0, maxHeight = 0;
     uint32_t         frameCount = 0, accumulated = 0;
     uint32_t         rank = 0, worldSize = 1;
@@ -1165,15 +1174,15 @@ struct Renderer::Impl
             RF_HIP(hipMemcpy(sPending.ptr, ones.data(), n * sizeof(float4), hipMemcpyHostToDevice));
             RF_HIP(hipMemset(sRad.ptr, 0, n * sizeof(float4)));
             if (shadowNearestFirst)
-                hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
+                hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
             else
-                hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
+                hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
         }
         else
         {
-            hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, ps, queueA.ptr, queueCounts.ptr,
+            hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
             hipLaunchKernelGGL(kHitPoints, dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
         }
@@ -1243,38 +1252,38 @@ struct Renderer::Impl
                         hipLaunchKernelGGL(kTraceClosest<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
                 }
                 else if (counting)
-                    hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursorClosest,
+                    hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                 else
-                    hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qIn, countIn, cursorClosest,
+                    hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
             }, bounce - 1);
             launchTimed(2, [&] {
-                hipLaunchKernelGGL(kShade, dim3(itemBlocks), dim3(kBlock), 0, stream, scene, sky, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
+                hipLaunchKernelGGL(kShade, dim3(itemBlocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
                                    bounce == numBounces ? 1u : 0u);
             });
             launchTimed(3, [&] {
                 if (traversalVariant == 0)
                 {
                     if (counting)
-                        hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                        hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr);
                     else
-                        hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, ps, qOut, countOut, counters.ptr);
+                        hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr);
                 }
                 else if (shadowNearestFirst)
                 {
                     if (counting)
-                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                     else
-                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                 }
                 else if (counting)
-                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
+                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
                 else
-                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, ps, qOut, countOut, cursorShadow,
+                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
             }, bounce - 1);
             std::swap(qIn, qOut);
@@ -1422,6 +1431,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
 
     m.params = desc.renderParams;
     if (alignedSkyState(m.params.sky, m.sky) != SkyResult::Success) throw std::runtime_error("sky parameters out of range");
+    m.updateSunBasis();
     m.configureShard();
 }
 
@@ -1456,6 +1466,7 @@ void Renderer::setRenderParameters(const RenderParameters& p)
     const bool resized = p.width != m.params.width || p.height != m.params.height;
     m.params = p;
     m.sky = sky;
+    m.updateSunBasis();
     m.accumulated = 0;
     m.imageDirty = true;
     if (resized) m.configureShard();
