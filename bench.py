@@ -283,6 +283,14 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pt, W, H, B, args.cpu_seconds)
+            # scene bake beside it: the reference's recursive builder as restated on the host (one
+            # thread, what pt-format-tool does) and the GPU builder that emits the same node bytes
+            tris = pt.arrays()["bvhPositionAttributes"]
+            t0 = time.perf_counter(); host_nodes, _, _ = rf.build_bvh(tris); host_ms = (time.perf_counter() - t0) * 1e3
+            rf.build_bvh_gpu(tris[:4096])                                       # module load / first-launch cost outside the figure
+            gpu_nodes, _, _, gpu_ms = rf.build_bvh_gpu(tris)
+            out["bvh_build"] = {"triangles": int(len(tris)), "nodes": int(len(host_nodes)), "host_ms_1_thread": round(host_ms, 2),
+                                "gpu_ms": round(float(gpu_ms), 3), "node_bytes_identical": bool(host_nodes.tobytes() == gpu_nodes.tobytes())}
         print(json.dumps(out), flush=True)
     r.close()
     if dist is not None:
