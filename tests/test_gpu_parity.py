@@ -372,6 +372,28 @@ def test_atrium_crops_vs_oracle_1080p_8_bounces(atrium):
     assert s["closest_node_visits"] > 30 * s["closest_rays"]
 
 
+def test_atrium_config5_4k_16_bounces_crops_and_queue_occupancy(atrium):
+    """BASELINE.json config 5 geometry (3840x2160, 16 bounces; NEE is always on): oracle parity on crops and
+    the per-bounce queue statistics (queue occupancy per bounce)."""
+    W, H, spp, bounces = 3840, 2160, 2, 16
+    r, params = _renderer(atrium, W, H, spp, bounces)
+    r.reset_stats()
+    r.render(spp)
+    img, _ = r.read_accumulation()
+    s, bs = r.stats(), r.bounce_stats()
+    sc, _ = oracle_scene_from_pt(atrium)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    for (x0, y0) in [(1900, 1060), (3800, 2120), (16, 1200)]:
+        ref, _ = orc.render(sc, rp, 0, spp, x0, y0, x0 + 24, y0 + 24)
+        _compare(img[y0:y0 + 24, x0:x0 + 24], ref[y0:y0 + 24, x0:x0 + 24], spp)
+    assert not np.isnan(img).any()
+    # occupancy: bounce 1 traces every path, a path enters bounce b+1 iff it hit something at bounce b, totals add up
+    cr, sr = bs["closest_rays"].astype(np.int64), bs["shadow_rays"].astype(np.int64)
+    assert len(cr) == bounces and cr[0] == W * H * spp
+    assert np.array_equal(cr[1:], sr[:-1]) and (sr <= cr).all() and (np.diff(cr) <= 0).all()
+    assert cr.sum() == s["closest_rays"] and sr.sum() == s["shadow_rays"]
+
+
 def test_atrium_idempotent_and_shard_union_at_full_size(atrium):
     W, H, spp, bounces = 1920, 1080, 2, 8
     a, params = _renderer(atrium, W, H, spp, bounces)
