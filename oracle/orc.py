@@ -226,6 +226,19 @@ def wgsl_sky_radiance(sky40, theta, gamma, channel):
     return np.float32(lib().orc_wgsl_sky_radiance(_p(f32(sky40)), np.float32(theta), np.float32(gamma), channel))
 
 
+_REF_BLUE_NOISE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "libbluenoise_ref.so")
+
+
+def ref_blue_noise_table():
+    """The reference's own src/pt/blue_noise.c, compiled unmodified (oracle/_ref): (bytes[32768], width, height), or None."""
+    if not os.path.exists(_REF_BLUE_NOISE_PATH):
+        return None
+    lib_ = C.CDLL(_REF_BLUE_NOISE_PATH)
+    arr = (C.c_uint8 * 32768).in_dll(lib_, "blueNoiseValues")
+    return (np.frombuffer(bytes(arr), np.uint8).copy(), C.c_size_t.in_dll(lib_, "blueNoiseWidth").value,
+            C.c_size_t.in_dll(lib_, "blueNoiseHeight").value)
+
+
 class RefSky:
     """The reference's own hw_skymodel.c, compiled unmodified (oracle/_ref)."""
 

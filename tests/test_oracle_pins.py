@@ -196,6 +196,22 @@ def test_solar_constants_bit_patterns():
     assert struct.unpack("<I", struct.pack("<f", inv))[0] == 0x38826048
 
 
+def test_blue_noise_table_is_the_references():
+    """The 128x128 RG8 table (src/pt/blue_noise.c): pinned by digest always, and against the reference's own
+    blue_noise.c compiled unmodified (oracle/_ref/libbluenoise_ref.so) when that was built."""
+    import hashlib
+    import rayfinder_amd as rf
+    table = np.asarray(orc.blue_noise_table(), np.uint8).reshape(-1)
+    assert table.size == 128 * 128 * 2
+    assert hashlib.sha256(table.tobytes()).hexdigest() == "49394f182237718fd4d0927f879d213f176c6f93db9afea7ecb4cbfee68075fd"
+    with open(os.path.join(os.path.dirname(rf.__file__), "data", "blue_noise_128x128_rg8.bin"), "rb") as f:
+        assert f.read() == table.tobytes()          # the product embeds the same bytes
+    ref = orc.ref_blue_noise_table()
+    if ref is not None:
+        values, w, h = ref
+        assert (w, h) == (128, 128) and np.array_equal(values, table)
+
+
 def test_animated_blue_noise_definition():
     table = orc.blue_noise_table()
     # sample 0 is the raw table texel; 255 -> 1.0 -> fract -> 0 (H18)
