@@ -1427,7 +1427,11 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     // the paths, and a traversal launch needs millions of rays to fill 6144 persistent waves
     // (measured on the atrium: 8 Mi paths 3234, 32 Mi 3690, 64 Mi 3752 Mrays/s).
     const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (64ull << 20);
-    m.maxPaths = std::max<uint64_t>(want, maxTiles * 1024);
+    // path slots and queue indices are 32-bit: at most 2^31 paths per batch, and one sample of the whole
+    // (padded) frame must fit in a batch
+    constexpr uint64_t kMaxPathsPerBatch = 1ull << 31;
+    if (maxTiles * 1024 > kMaxPathsPerBatch) throw std::runtime_error("framebuffer too large: more than 2^31 pixels per rank");
+    m.maxPaths = std::min(std::max<uint64_t>(want, maxTiles * 1024), kMaxPathsPerBatch);
 
     m.params = desc.renderParams;
     if (alignedSkyState(m.params.sky, m.sky) != SkyResult::Success) throw std::runtime_error("sky parameters out of range");
