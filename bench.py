@@ -172,7 +172,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warm-up: W untimed steps (+ one gather so RCCL is connected)
+    # warm-up: W untimed steps (+ one gather so RCCL is connected); path state for the timed batches is
+    # allocated here, whatever W is, so that the timed region never calls hipMalloc
+    r.set_option("reserve_samples", K)
     r.render(WU)
     r.synchronize()
     if dist is not None:

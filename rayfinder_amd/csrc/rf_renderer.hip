@@ -1614,6 +1614,14 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
+    else if (name == "reserve_samples")
+    {
+        // allocate path state for batches of up to `value` samples now (otherwise it grows on first use)
+        Impl&          m = *mImpl;
+        const uint64_t pixelsPadded = static_cast<uint64_t>(m.tiles.size()) * 1024;
+        RF_HIP(hipSetDevice(m.device));
+        if (pixelsPadded) m.ensurePathState(std::min<uint64_t>(std::max<uint64_t>(static_cast<uint64_t>(value), 1) * pixelsPadded, std::max(m.maxPaths / pixelsPadded, uint64_t{1}) * pixelsPadded));
+    }
     else if (name == "query_variant") mImpl->queryVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
     else if (name == "persistent_blocks") mImpl->wideBlocks = static_cast<uint32_t>(value);
     else throw std::invalid_argument("unknown option " + name);
