@@ -84,6 +84,10 @@ def lib():
         _lib.orc_pixel_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.orc_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
         _lib.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
+        _lib.orc_pixar_onb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_direction_in_cone.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+        _lib.orc_direction_in_cosine_weighted_hemisphere.argtypes = [C.c_float, C.c_float, C.c_void_p]
+        _lib.orc_offset_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_reorder_attributes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
         _lib.orc_build_bvh.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         assert _lib.orc_sizeof_stats() == C.sizeof(Stats)
@@ -330,6 +334,30 @@ def texture_lookup(scene, desc_idx, u, v):
     rgb = np.zeros(3, np.float32)
     lib().orc_texture_lookup(C.byref(scene.c), desc_idx, np.float32(u), np.float32(v), _p(rgb))
     return rgb
+
+
+def pixar_onb(n):
+    n = f32(n); u = np.zeros(3, np.float32); v = np.zeros(3, np.float32)
+    lib().orc_pixar_onb(_p(n), _p(u), _p(v))
+    return u, v
+
+
+def direction_in_cone(ux, uy, cos_theta_max):
+    d = np.zeros(3, np.float32)
+    lib().orc_direction_in_cone(C.c_float(ux), C.c_float(uy), C.c_float(cos_theta_max), _p(d))
+    return d
+
+
+def direction_in_cosine_weighted_hemisphere(ux, uy):
+    d = np.zeros(3, np.float32)
+    lib().orc_direction_in_cosine_weighted_hemisphere(C.c_float(ux), C.c_float(uy), _p(d))
+    return d
+
+
+def offset_ray(p, n):
+    p = f32(p); n = f32(n); o = np.zeros(3, np.float32)
+    lib().orc_offset_ray(_p(p), _p(n), _p(o))
+    return o
 
 
 def tonemap(image, acc, exposure):

@@ -1037,6 +1037,30 @@ ORC_API void orc_tonemap(const float* image, uint32_t numPixels, uint32_t accumu
     }
 }
 
+/* exported for tests: the sampling helpers of the integrator, one call each */
+ORC_API void orc_pixar_onb(const float* n3, float* u3, float* v3out)
+{
+    v3 u, v;
+    pixar_onb(V3(n3[0], n3[1], n3[2]), &u, &v);
+    u3[0] = u.x; u3[1] = u.y; u3[2] = u.z;
+    v3out[0] = v.x; v3out[1] = v.y; v3out[2] = v.z;
+}
+ORC_API void orc_direction_in_cone(float ux, float uy, float cosThetaMax, float* d3)
+{
+    const v3 d = direction_in_cone(ux, uy, cosThetaMax);
+    d3[0] = d.x; d3[1] = d.y; d3[2] = d.z;
+}
+ORC_API void orc_direction_in_cosine_weighted_hemisphere(float ux, float uy, float* d3)
+{
+    const v3 d = direction_in_cosine_weighted_hemisphere(ux, uy);
+    d3[0] = d.x; d3[1] = d.y; d3[2] = d.z;
+}
+ORC_API void orc_offset_ray(const float* p3, const float* n3, float* o3)
+{
+    const v3 o = offset_ray(V3(p3[0], p3[1], p3[2]), V3(n3[0], n3[1], n3[2]));
+    o3[0] = o.x; o3[1] = o.y; o3[2] = o.z;
+}
+
 ORC_API uint32_t orc_sizeof_stats(void) { return (uint32_t)sizeof(OrcStats); }
 ORC_API uint32_t orc_sizeof_scene(void) { return (uint32_t)sizeof(OrcScene); }
 ORC_API uint32_t orc_sizeof_render_params(void) { return (uint32_t)sizeof(OrcRenderParams); }

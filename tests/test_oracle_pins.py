@@ -8,6 +8,7 @@
    sums): reproduced exactly.
 """
 import hashlib
+import struct
 import os
 
 import numpy as np
@@ -283,3 +284,71 @@ def test_texture_lookup_semantics(duck_oracle):
         want = np.array([np.float32(float(c) ** float(np.float32(2.2))) for c in srgb], np.float32)
         got = orc.texture_lookup(d.scene, 0, u, v)
         assert np.allclose(got, want, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- sampling helpers: analytic pins
+# (nothing under src/pt is tested by the reference; these are the properties its
+#  WGSL helpers must have, checked on the restatement)
+def test_pixar_onb_is_orthonormal_and_right_handed():
+    """wgsl:309-319 (Duff et al.): for unit n, (u, v, n) is an orthonormal right-handed frame, including
+    the n.z < 0 branch and the poles."""
+    rng = np.random.default_rng(3)
+    ns = rng.normal(size=(300, 3))
+    ns /= np.linalg.norm(ns, axis=1, keepdims=True)
+    ns = np.concatenate([ns, [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, -1, 0], [0.6, 0.8, 0.0], [0.0, 0.6, -0.8]]]).astype(np.float32)
+    for n in ns:
+        u, v = orc.pixar_onb(n)
+        u64, v64, n64 = u.astype(np.float64), v.astype(np.float64), n.astype(np.float64)
+        assert abs(np.dot(u64, u64) - 1) < 1e-5 and abs(np.dot(v64, v64) - 1) < 1e-5
+        assert abs(np.dot(u64, v64)) < 1e-5 and abs(np.dot(u64, n64)) < 1e-5 and abs(np.dot(v64, n64)) < 1e-5
+        assert np.allclose(np.cross(u64, v64), n64, atol=1e-5)
+
+
+def test_cosine_hemisphere_and_cone_samples():
+    """wgsl:582-592: (cos 2 pi u.y sqrt(1-u.x), sin 2 pi u.y sqrt(1-u.x), sqrt(u.x)) is unit with z = sqrt(u.x);
+    wgsl:568-579: the cone sample is unit with cos(theta) = 1 - u.x (1 - cosThetaMax) >= cosThetaMax."""
+    rng = np.random.default_rng(4)
+    cmax = struct.unpack("<f", struct.pack("<I", 0x3F7FFF5A))[0]
+    for ux, uy in np.concatenate([rng.uniform(0, 1, (200, 2)), [[0, 0], [0, 0.25], [0.999999, 0.5], [0.5, 0.999999]]]).astype(np.float32):
+        d = orc.direction_in_cosine_weighted_hemisphere(ux, uy).astype(np.float64)
+        assert abs(np.dot(d, d) - 1) < 2e-6
+        assert d[2] == np.float64(np.sqrt(np.float32(ux)))
+        c = orc.direction_in_cone(ux, uy, cmax).astype(np.float64)
+        assert abs(np.dot(c, c) - 1) < 2e-6
+        assert c[2] == np.float64(np.float32(1) - np.float32(ux) * (np.float32(1) - np.float32(cmax))) and c[2] >= cmax - 1e-7
+    # u.x = 0 (blue-noise byte 255 on sample 0, Appendix A H18): a grazing bounce direction, z exactly 0
+    assert orc.direction_in_cosine_weighted_hemisphere(0.0, 0.3)[2] == 0.0
+
+
+def test_offset_ray_known_answers():
+    """ray_intersection.cpp:17-35 == wgsl:523-544 (Ray Tracing Gems ch. 6): away from the origin the float's bit
+    pattern moves by int(256 n) ulps, away from zero when the offset points outwards; within 1/32 of the origin
+    the offset is n / 65536 instead; per component."""
+    def ulps(a, b):
+        return int(np.float32(b).view(np.int32)) - int(np.float32(a).view(np.int32))
+    p = np.array([2.0, -3.5, 0.01], np.float32)
+    n = np.array([1.0, 0.0, 0.0], np.float32)
+    o = orc.offset_ray(p, n)
+    assert ulps(p[0], o[0]) == 256 and o[1] == p[1] and o[2] == p[2] + np.float32(0.0) / 65536
+    o = orc.offset_ray(p, np.array([0.0, 1.0, 0.0], np.float32))
+    assert ulps(p[1], o[1]) == -256 and o[1] > p[1]             # negative coordinate: the bit pattern decreases, the value moves up
+    o = orc.offset_ray(p, np.array([0.0, -0.5, 1.0], np.float32))
+    assert ulps(p[1], o[1]) == 128 and o[1] < p[1]
+    assert o[2] == np.float32(p[2] + np.float32(1.0 / 65536.0) * np.float32(1.0))   # |p.z| < 1/32
+    # int() truncates toward zero: |256 n| < 1 moves nothing
+    o = orc.offset_ray(p, np.array([0.003, 0.0, 0.0], np.float32))
+    assert o[0] == p[0]
+
+
+def test_aces_tonemap_known_answers():
+    """wgsl:277-285 + 59-63: acesFilmic(x) = x(2.51x+0.03)/(x(2.43x+0.59)+0.14) clamped to [0,1], then ^(1/2.2)."""
+    img = np.array([[0, 0, 0, 0], [1, 1, 1, 0], [4, 0.5, 100, 0], [0.18, 0.18, 0.18, 0]], np.float32)
+    out = orc.tonemap(img, 1, 1.0)
+    assert np.array_equal(out[0], [0, 0, 0])
+    x = np.float64([1, 4, 0.5, 100, 0.18])
+    want = np.clip(x * (2.51 * x + 0.03) / (x * (2.43 * x + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
+    got = np.float64([out[1][0], out[2][0], out[2][1], out[2][2], out[3][0]])
+    assert np.allclose(got, want, rtol=2e-6)
+    assert out[2][2] == 1.0                                   # saturates
+    # exposure and sample count enter as exposure * sum / n
+    assert np.array_equal(orc.tonemap(img * 8, 4, 0.5), orc.tonemap(img, 1, 1.0))
