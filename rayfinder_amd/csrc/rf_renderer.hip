@@ -67,6 +67,15 @@ struct PathStreams
     float4* noise;   // {u.x, cos(2 pi u.y), sin(2 pi u.y), -}: the path's one blue-noise pair
 };
 
+// 12-byte load of the xyz part of a float4 stream element (global_load_dwordx3): the L1 -> VGPR return path
+// bounds the traversal kernels, so the unused .w lanes are not fetched
+typedef float v3f __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ Vec3 load3(const float4* p)
+{
+    const v3f v = *reinterpret_cast<const v3f*>(p);
+    return vec3(v.x, v.y, v.z);
+}
+
 struct DeviceCounters
 {
     unsigned long long primaryRays, closestRays, shadowRays;
@@ -236,10 +245,8 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
 // p = p0 + u*e1 + v*e2 offset along normalize(e1 x e2) (wgsl:511-519,523-544)
 __device__ __forceinline__ Vec3 hitPoint(const DeviceScene& scene, uint32_t tri, float u, float v)
 {
-    const float4 a = scene.triangles[kTriStride * tri];
-    const float4 b = scene.triangles[kTriStride * tri + 1];
-    const float4 c = scene.triangles[kTriStride * tri + 2];
-    const Vec3   p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
+    const Vec3 p0 = load3(scene.triangles + kTriStride * tri), p1 = load3(scene.triangles + kTriStride * tri + 1),
+               p2 = load3(scene.triangles + kTriStride * tri + 2);
     const Vec3   e1 = p1 - p0, e2 = p2 - p0;
     const Vec3   p = p0 + u * e1 + v * e2;
     return offsetRay(p, normalize(cross(e1, e2)));
@@ -296,10 +303,9 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             const Vec3 hp = hitPoint(scene, tri, h.y, h.z);
             ps.rayO[slot] = make_float4(hp.x, hp.y, hp.z, 0.0f);
         }
-        const float4            thr4 = ps.thr[slot];
-        const float4            nz = ps.noise[slot];
-        const Vec3              throughput = vec3(thr4.x, thr4.y, thr4.z);
-        const float             nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
+        const Vec3  throughput = load3(ps.thr + slot);
+        const Vec3  nz = load3(ps.noise + slot);
+        const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
         // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
         const float4* va = scene.attributes + 4 * static_cast<size_t>(tri);
         const float4  a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
@@ -537,19 +543,15 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             if (node == kNodeIdle && rankInIdle < take)
             {
                 slot = queue[chunkPos + rankInIdle];
-                const float4 o = ps.rayO[slot];
-                Vec3         dir;
+                const Vec3 o = load3(ps.rayO + slot);
+                Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
                 {
-                    const float4 nz = ps.noise[slot];
+                    const Vec3 nz = load3(ps.noise + slot);
                     dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
-                else
-                {
-                    const float4 d = ps.rayD[slot];
-                    dir = vec3(d.x, d.y, d.z);
-                }
-                const RayPrep ray = prepareRay(vec3(o.x, o.y, o.z), dir);
+                else dir = load3(ps.rayD + slot);
+                const RayPrep ray = prepareRay(o, dir);
                 pr = packRay(ray);
                 rayDir = dir;
                 const uint32_t rayClass = classifyRay(ray);
@@ -582,8 +584,16 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             {
                 if (COUNT) ++recordFetches;
                 const float4*  n = wide.nodes + 4 * static_cast<size_t>(node);
-                const float4   q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                const uint32_t word0 = __float_as_uint(q3.x), word1 = __float_as_uint(q3.y), axis = __float_as_uint(q3.z);
+                // 56 of the record's 64 bytes: the L1 -> VGPR return path (64 B/clk/CU, TD_TD_BUSY > 85 % in every
+                // bounce) is what bounds this kernel, so nothing is loaded that is not used
+                const float4   q0 = n[0], q1 = n[1], q2 = n[2];
+                // (the pointer goes through an empty asm so that the compiler forgets its 16-byte alignment and
+                // cannot widen the 8-byte load back to a dwordx4)
+                const uint2* wordPtr = reinterpret_cast<const uint2*>(n + 3);
+                asm volatile("" : "+v"(wordPtr));
+                const uint2 words = *wordPtr;
+                const uint32_t axis = (words.x >> kWideAxisShift) & 3u;
+                const uint32_t word0 = words.x & ~(3u << kWideAxisShift), word1 = words.y;
                 float          t0, t1;
                 bool           ok0, ok1;
                 slabPair(pr, q0, q1, q2, ok0, t0, ok1, t1);
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
         // ---- leaves
         if (node - kWideLeafBit < kNodeDone - kWideLeafBit)
         {
-            uint32_t first = node & 0x0FFFFFFFu, n = ((node >> 28) & 7u) + 1u;
+            uint32_t first = node & ((1u << kWideIndexBits) - 1u), n = ((node >> kWideIndexBits) & 7u) + 1u;
             if (n == 8u)
             {
                 const uint2 big = wide.bigLeaves[first];
@@ -674,9 +684,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             {
                 if (COUNT) ++wLeaf;
                 const uint32_t tri = first + i;
-                const float4   a = scene.triangles[kTriStride * tri];
-                const float4   b = scene.triangles[kTriStride * tri + 1];
-                const float4   c = scene.triangles[kTriStride * tri + 2];
+                const v3f      a = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri);
+                const v3f      b = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 1);
+                const v3f      c = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 2);
                 if (COUNT) ++rayTris;
                 TriangleHit th;
                 const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
@@ -724,10 +734,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             if (ANY_HIT)
             {
                 const float  visibility = occluded ? 0.0f : 1.0f;
-                const float4 pend = ps.pending[slot];
-                const float4 rad4 = ps.rad[slot];
-                const Vec3   add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
-                const Vec3   radiance = vec3(rad4.x, rad4.y, rad4.z) + add;
+                const Vec3   add = (load3(ps.pending + slot) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3   radiance = load3(ps.rad + slot) + add;
                 ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
             }
             else

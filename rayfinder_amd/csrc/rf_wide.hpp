@@ -9,16 +9,18 @@
 //
 //   * one record per INTERIOR node holding BOTH children's boxes (16 dwords = 64 B, 64-B aligned:
 //     one cache line, four dwordx4 loads, one dependent fetch per two box tests), laid out
-//     {c0.lo.xyz c0.hi.xyz c1.lo.xyz c1.hi.xyz | word0 word1 axis -} so that consecutive float
+//     {c0.lo.xyz c0.hi.xyz c1.lo.xyz c1.hi.xyz | word0 word1 - -} so that consecutive float
 //     pairs are (x,y) (z,x) (y,z): six v_pk_add_f32 + six v_pk_mul_f32 do all twelve slab planes;
 //   * the near child (reference order: dirNeg[splitAxis], wgsl:409-417) is handled at once; the
 //     far child is pushed together with its tmin only if P holds, and when popped it is accepted
 //     iff tmin < rayTMax *then* -- exactly the test the reference performs at pop time;
 //   * a leaf is described by its parent's child word, so leaf nodes are never fetched.
 //
-// Child word: bit 31 = leaf.  Interior: index of the child's wide record.  Leaf: bits 30..28 =
-// min(count-1, 7), bits 27..0 = first triangle (count <= 7) or index into the big-leaf table
-// {first triangle, count} (count >= 8, or offsets >= 2^28).
+// Child word: bit 31 = leaf; bits 30..29 = split axis of the record's node (first child word only);
+// interior: bits 25..0 = index of the child's wide record.  Leaf: bits 28..26 = min(count-1, 7),
+// bits 25..0 = first triangle (count <= 7) or index into the big-leaf table {first triangle, count}
+// (count >= 8, or offsets >= 2^26).  A tree with 2^26 or more interior nodes is not representable
+// (WideBuild::boxesRegular is cleared: the renderer then uses the 32-byte node kernels).
 //
 // nodesVisited bookkeeping (the counting build): the reference counts a node when it is visited,
 // i.e. root once, the near child at its parent's step, the far child when popped -- also when its
@@ -34,6 +36,8 @@
 namespace rf
 {
 constexpr uint32_t kWideLeafBit = 0x80000000u;
+constexpr uint32_t kWideIndexBits = 26;  // record / first-triangle / big-leaf index
+constexpr uint32_t kWideAxisShift = 29;  // bits 30..29 of the FIRST child word carry the node's split axis
 constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is interior
 constexpr int      kWideLdsStack = 12;      // (child word, tmin) pairs per lane, all in LDS; deeper rays are redone by the scalar traversal
 
@@ -64,12 +68,13 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
     uint32_t              numInterior = 0;
     for (size_t i = 0; i < count; ++i)
         if (nodes[i].triangleCount == 0) wideIndex[i] = numInterior++;
+    if (numInterior >= (1u << kWideIndexBits)) out.boxesRegular = false; // index field too narrow: not usable
     auto childWord = [&](size_t idx) -> uint32_t {
         const BvhNode& n = nodes[idx];
         if (n.triangleCount == 0) return wideIndex[idx];
-        if (n.triangleCount <= 7 && n.trianglesOffset < (1u << 28)) return kWideLeafBit | ((n.triangleCount - 1) << 28) | n.trianglesOffset;
+        if (n.triangleCount <= 7 && n.trianglesOffset < (1u << kWideIndexBits)) return kWideLeafBit | ((n.triangleCount - 1) << kWideIndexBits) | n.trianglesOffset;
         out.bigLeaves.push_back(make_uint2(n.trianglesOffset, n.triangleCount));
-        return kWideLeafBit | (7u << 28) | static_cast<uint32_t>(out.bigLeaves.size() - 1);
+        return kWideLeafBit | (7u << kWideIndexBits) | static_cast<uint32_t>(out.bigLeaves.size() - 1);
     };
     out.rootLo = make_float4(nodes[0].aabb.min.x, nodes[0].aabb.min.y, nodes[0].aabb.min.z, 0.0f);
     out.rootHi = make_float4(nodes[0].aabb.max.x, nodes[0].aabb.max.y, nodes[0].aabb.max.z, 0.0f);
@@ -86,7 +91,8 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         w[0] = make_float4(a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, a.aabb.max.x);
         w[1] = make_float4(a.aabb.max.y, a.aabb.max.z, b.aabb.min.x, b.aabb.min.y);
         w[2] = make_float4(b.aabb.min.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z);
-        w[3] = make_float4(bitsFloat(childWord(c0)), bitsFloat(childWord(c1)), bitsFloat(n.splitAxis & 3u), 0.0f);
+        // 14 dwords are read per step: 12 box floats + the two child words (the split axis rides in the first word)
+        w[3] = make_float4(bitsFloat(childWord(c0) | ((n.splitAxis & 3u) << kWideAxisShift)), bitsFloat(childWord(c1)), 0.0f, 0.0f);
         // the packed slab test assumes ordered, finite boxes (always true for boxes of real triangles)
         const float lo[6] = {a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, b.aabb.min.x, b.aabb.min.y, b.aabb.min.z};
         const float hi[6] = {a.aabb.max.x, a.aabb.max.y, a.aabb.max.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z};
