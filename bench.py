@@ -251,7 +251,10 @@ def main():
                         # needs one record per two reference node visits, so this is below the algorithmic figure)
                         requested_GBps=round((44 * cs["closest_rays"] + 64 * cs["closest_record_fetches"] + 48 * cs["closest_triangle_tests"])
                                              / max(s["ms_closest"], 1e-9) / 1e6, 1),
-                        record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2))
+                        record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2),
+                        # the schema's "bound" is hbm|mfma; what actually limits this kernel (profiles/r01_final):
+                        limiter="L1->VGPR return path (TD busy 86-97 %) and VALU issue (62 %); the BVH is resident in L2 / Infinity Cache, "
+                                "so HBM-side traffic is ~1/8 of the algorithmic bytes and frac > 1")
     else:
         roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=traffic, kernel="kTraceWide<closest>",
                         avg_launch_ms=round(avg_ms, 4), launches=launches)
