@@ -558,3 +558,68 @@ def test_deep_tree_uses_the_scratch_part_of_the_stack():
     st, cpu = _check_scene_against_oracle(pt, rays, render_wh=(48, 32), cam=cam)
     assert 24 < cpu["stackHigh"].max() < 32, int(cpu["stackHigh"].max())
     assert 12 < st.stackHigh < 32, st.stackHigh
+
+
+# ------------------------------------------------------------------ randomized differential test
+def _random_scene(rng, kind):
+    """Triangle soups that stress different corners: axis-aligned boxes (zero direction components after
+    bounces, rays starting exactly on box planes), slivers and degenerate triangles, clustered duplicates
+    (multi-triangle leaves), a large ground plane with small clutter."""
+    if kind == "boxes":
+        tris = []
+        for _ in range(int(rng.integers(3, 12))):
+            c = rng.uniform(-2, 2, 3); e = rng.uniform(0.1, 0.8, 3)
+            lo, hi = c - e, c + e
+            v = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+            for a, b, c2, d in ((0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)):
+                tris += [[v[a], v[b], v[c2]], [v[a], v[c2], v[d]]]
+        tris += [[[-6, -2.5, -6], [6, -2.5, -6], [6, -2.5, 6]], [[-6, -2.5, -6], [6, -2.5, 6], [-6, -2.5, 6]]]
+        tris = np.array(tris, np.float32)
+    elif kind == "slivers":
+        c = rng.uniform(-2, 2, (400, 1, 3)); tris = (c + rng.normal(0, 0.4, (400, 3, 3)) * np.array([1.0, 0.02, 1.0])).astype(np.float32)
+        tris[:20, 2] = tris[:20, 1]                               # degenerate (zero area)
+    elif kind == "duplicates":
+        base = (rng.uniform(-2, 2, (30, 1, 3)) + rng.normal(0, 0.5, (30, 3, 3))).astype(np.float32)
+        tris = base[rng.integers(0, 30, 900)]
+    else:
+        c = rng.uniform(-3, 3, (1500, 1, 3)) * np.array([1, 0.3, 1]); tris = (c + rng.normal(0, 0.15, (1500, 3, 3))).astype(np.float32)
+        tris = np.concatenate([tris, np.array([[[-8, -1.2, -8], [8, -1.2, -8], [8, -1.2, 8]], [[-8, -1.2, -8], [8, -1.2, 8], [-8, -1.2, 8]]], np.float32)])
+    n = len(tris)
+    e1, e2 = tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]
+    gn = np.cross(e1, e2); ln = np.linalg.norm(gn, axis=1, keepdims=True)
+    gn = np.where(ln > 0, gn / np.maximum(ln, 1e-30), np.array([0.0, 1.0, 0.0]))
+    normals = (np.repeat(gn[:, None, :], 3, 1) + rng.normal(0, 0.1, (n, 3, 3))).astype(np.float32)   # not unit: the reference does not care
+    uvs = rng.uniform(-2, 3, (n, 3, 2)).astype(np.float32)
+    ntex = int(rng.integers(1, 4))
+    textures = []
+    for _ in range(ntex):
+        w, h = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        rgb = rng.integers(0, 256, (h * w, 3), dtype=np.uint32)
+        textures.append(((rgb[:, 2] | (rgb[:, 1] << 8) | (rgb[:, 0] << 16) | np.uint32(255 << 24)).astype(np.uint32), w, h))
+    return rf.PtFormat.from_triangles(tris.reshape(n, 9), normals.reshape(n, 9), uvs.reshape(n, 6), rng.integers(0, ntex, n).astype(np.uint32), textures)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["boxes", "slivers", "duplicates", "clutter"][seed % 4]
+    pt = _random_scene(rng, kind)
+    W, H = int(rng.integers(5, 13)) * 8 - int(rng.integers(0, 7)), int(rng.integers(4, 10)) * 8 - int(rng.integers(0, 7))
+    spp, bounces = int(rng.integers(1, 6)), int(rng.integers(1, 8))
+    pos = rng.uniform(-3, 3, 3); pos[1] = abs(pos[1]) + 0.3
+    cam = rf.create_camera(pos, rng.uniform(-1, 1, 3), float(rng.choice([0.0, 0.05, 0.3])), float(rng.uniform(1, 6)),
+                           orc.degrees_to_radians(float(rng.uniform(30, 100))), W / H)
+    sky = rf.make_sky(turbidity=float(rng.uniform(1, 10)), albedo=tuple(rng.uniform(0, 1, 3)), sun_zenith_degrees=float(rng.uniform(0, 89)),
+                      sun_azimuth_degrees=float(rng.uniform(0, 360)))
+    r, params = _renderer(pt, W, H, spp, bounces, cam=cam, sky=sky, exposure=0.5)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    assert acc == spp
+    sc, _ = oracle_scene_from_pt(pt)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.5, rf.aligned_sky_state(sky))
+    with np.errstate(all="ignore"):
+        ref, _ = orc.render(sc, rp, 0, spp)
+    g, c = img[..., :3], ref[..., :3]
+    assert np.array_equal(np.isnan(g), np.isnan(c)), (kind, "NaN pixels differ")
+    same = (bits(g) == bits(c)) | np.isnan(g)
+    assert same.all(), (kind, W, H, spp, bounces, int((~same).sum()), float(np.nanmax(np.abs(g - c))))
