@@ -49,7 +49,7 @@ public:
     void raw(void* dst, std::size_t n)
     {
         if (n > mLeft) throw std::runtime_error("Unexpected end of PtFormat data.");
-        std::memcpy(dst, mPtr, n);
+        if (n) std::memcpy(dst, mPtr, n); // (an empty vector's data() may be null)
         mPtr += n;
         mLeft -= n;
     }
