@@ -1,0 +1,51 @@
+"""Corrupted JPEG / GLB / .pt files for tools/sanitize/run.sh."""
+import io, os, sys
+import numpy as np
+from PIL import Image
+root, out = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+import rayfinder_amd as rf
+rng = np.random.default_rng(5)
+yy, xx = np.mgrid[0:40, 0:56]
+img = np.stack([128 + 100 * np.sin(xx / 9.0), 128 + 90 * np.cos(yy / 7.0), 128 + 60 * np.sin((xx + yy) / 11.0)], -1).clip(0, 255).astype(np.uint8)
+def enc(im=img, mode="RGB", **kw):
+    b = io.BytesIO(); Image.fromarray(im, mode).save(b, "JPEG", **kw); return b.getvalue()
+bases = [enc(quality=85), enc(quality=85, progressive=True), enc(quality=60, subsampling=0, restart_marker_blocks=2),
+         enc(quality=85, subsampling=1, optimize=True), enc(img[..., 0], "L", quality=70), enc(img[:1, :1], quality=90), enc(quality=3)]
+for i, b in enumerate(bases):
+    open(f"{out}/jpeg/base{i}.jpg", "wb").write(b)
+for i in range(3000):
+    b = bytearray(bases[i % len(bases)]); m = i % 4
+    if m == 0:
+        for _ in range(int(rng.integers(1, 8))): b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+    elif m == 1:
+        b = b[:int(rng.integers(2, len(b)))]
+    elif m == 2:
+        pos = int(rng.integers(2, max(3, len(b) - 4))); b[pos:pos + 2] = bytes([0xFF, int(rng.integers(0xC0, 0xFF))])
+    else:
+        k = bytes(b).find(b"\xff\xc0"); k = k if k >= 0 else bytes(b).find(b"\xff\xc2")
+        if k >= 0:
+            b[k + 5 + int(rng.integers(0, 4))] = int(rng.integers(0, 256)); b[k + 11] = int(rng.integers(0, 256))
+    open(f"{out}/jpeg/f{i}.jpg", "wb").write(bytes(b))
+glb = open(os.path.join(root, "tests", "golden", "Duck.glb"), "rb").read()
+pt = rf.PtFormat.from_gltf(os.path.join(root, "tests", "golden", "Duck.glb")).serialize()
+for i in range(400):
+    b = bytearray(glb); m = i % 4
+    if m == 0:
+        for _ in range(int(rng.integers(1, 5))): b[int(rng.integers(12, 2088))] = int(rng.integers(32, 127))
+    elif m == 1:
+        b = b[:int(rng.integers(0, len(b)))]
+    elif m == 2:
+        for _ in range(int(rng.integers(1, 30))): b[int(rng.integers(2088, len(b)))] = int(rng.integers(0, 256))
+    else:
+        b[int(rng.integers(2088 + 102040, len(b)))] ^= 0xFF
+    open(f"{out}/ingest/g{i}.glb", "wb").write(bytes(b))
+for i in range(300):
+    b = bytearray(pt); m = i % 3
+    if m == 0:
+        b = b[:int(rng.integers(0, len(b)))]
+    elif m == 1:
+        b[9 + int(rng.integers(0, 8))] = int(rng.integers(0, 256))
+    else:
+        for _ in range(4): b[int(rng.integers(9, len(b)))] = int(rng.integers(0, 256))
+    open(f"{out}/ingest/p{i}.pt", "wb").write(bytes(b))
