@@ -294,7 +294,8 @@ __device__ __forceinline__ float skyRadiance(const SkyStateGpu& sky, float theta
 
 // wgsl:303-307,552-565.  An index past the end of the texel array (fract()*w rounding up on the
 // last row of the last texture) is clamped into the array, as WGSL robust buffer access does.
-__device__ __forceinline__ Vec3 evalTexture(const DeviceScene& scene, uint32_t descriptorIdx, float uvx, float uvy)
+// `lut`: the 256-entry sRGB -> linear table, in LDS in kShade (three look-ups per hit that then bypass the vector L1)
+__device__ __forceinline__ Vec3 evalTexture(const DeviceScene& scene, const float* lut, uint32_t descriptorIdx, float uvx, float uvy)
 {
     const TextureDescriptor d = scene.textureDescriptors[descriptorIdx];
     const float             u = wFract(uvx);
@@ -304,7 +305,7 @@ __device__ __forceinline__ Vec3 evalTexture(const DeviceScene& scene, uint32_t d
     uint64_t                idx = static_cast<uint64_t>(d.offset) + static_cast<uint64_t>(i * d.width + j);
     if (idx >= scene.numTexels) idx = scene.numTexels - 1;
     const uint32_t bgra = scene.texels[idx];
-    return vec3(scene.albedoLut[(bgra >> 16) & 0xffu], scene.albedoLut[(bgra >> 8) & 0xffu], scene.albedoLut[bgra & 0xffu]);
+    return vec3(lut[(bgra >> 16) & 0xffu], lut[(bgra >> 8) & 0xffu], lut[bgra & 0xffu]);
 }
 
 // wgsl:602-616; table texel = u8 / 255.0f (reference_path_tracer.cpp:174-178)

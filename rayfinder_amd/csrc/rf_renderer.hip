@@ -276,8 +276,12 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
                                                   uint32_t* missCount, uint32_t isLastBounce)
 {
     __shared__ uint32_t sScratch[8];
+    __shared__ float    sLut[256];
     const uint32_t      count = *queueCount;
     if (blockIdx.x * kItems * kBlock >= count) return; // whole block out of range (uniform)
+    static_assert(kBlock == 256, "one table entry per thread");
+    sLut[threadIdx.x] = scene.albedoLut[threadIdx.x];
+    __syncthreads();
     bool     isHit[kItems], isMiss[kItems];
     uint32_t slots[kItems];
 #pragma unroll 1
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         const Vec3    n = (b0 * n0 + b1 * n1) + b2 * n2;         // not normalised, wgsl:396
         const float   uvx = (b0 * a2.y + b1 * a2.w) + b2 * a3.y;
         const float   uvy = (b0 * a2.z + b1 * a3.x) + b2 * a3.z;
-        const Vec3    albedo = evalTexture(scene, __float_as_uint(a3.w), uvx, uvy);
+        const Vec3    albedo = evalTexture(scene, sLut, __float_as_uint(a3.w), uvx, uvy);
 
         // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
         const Vec3 lightDirection = sunSample(sky, sunBasis, nx, cosPhi, sinPhi);
