@@ -197,9 +197,10 @@ RF_API int rf_renderer_occluded_rays(rf_renderer* r, const float* rays6, uint64_
 RF_API int rf_build_bvh(const float* positions36, uint64_t num_triangles, void* nodes_out, uint64_t* num_nodes_out,
                         uint64_t* triangle_indices_out, int32_t* depth_out /* NULL ok */);
 
-/* The same build on the GPU (device_ordinal): identical node bytes; the triangle order inside
- * multi-triangle leaves is the builder's own stable order (the reference's is whatever its
- * standard library's std::partition leaves), so leaves hold the same triangle SETS.  Replaces the
+/* The same build on the GPU (device_ordinal): identical node bytes and identical triangle_indices_out
+ * (the order inside multi-triangle leaves decides closest-hit ties between coincident triangles; the
+ * reference's is whatever its standard library's std::partition leaves -- rf_build_bvh uses libstdc++'s,
+ * and the GPU builder reproduces that permutation).  Replaces the
  * single-threaded recursion of src/common/bvh.cpp:81-260 for large scenes.
  * build_ms_out (NULL ok): device time of the build, triangles already resident.  Fails without a
  * GPU (no CPU fallback: call rf_build_bvh). */

@@ -237,7 +237,9 @@ static size_t build_recursive(BuildCtx* c, Prim* prims, size_t count, size_t ord
         }
         const float leafCost = intersectionCost * (float)count;                     /* :203 */
         const float totalCost = traversalCost + minCost / box_surface_area(nodeAabb); /* :204 */
-        if (count > maxTrianglesInNode || totalCost < leafCost) {
+        /* every cost non-finite (areas overflow to inf): the reference asserts 0 < splitIdx < size (:215-216) and would
+         * recurse forever in a release build; documented choice (same in the product's two builders): a leaf */
+        if (splitBucketIdx != (size_t)-1 && (count > maxTrianglesInNode || totalCost < leafCost)) {
             /* :208-217 std::partition, bidirectional-iterator algorithm of libstdc++ */
             size_t first = 0, last = count;
             for (;;) {

@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <limits>
+#include <stdexcept>
+#include <string>
 
 namespace rf
 {
@@ -164,10 +166,24 @@ Bvh buildBvh(std::span<const Positions> triangles)
                 makeLeaf();
                 continue;
             }
+            // Every SAH cost non-finite (e.g. coordinates around 1e20: surface areas overflow to inf, inf - inf
+            // and 0 * inf give NaN, and no cost passes `<`): the reference asserts 0 < split < count
+            // (bvh.cpp:215-216) and would recurse forever in a release build.  Defined behaviour here, in the GPU
+            // builder: such a node becomes a leaf, whatever its size.
+            if (bestBucket >= kSplits)
+            {
+                makeLeaf();
+                continue;
+            }
             Primitive* mid = std::partition(p, p + count, [&](const Primitive& q) {
                 return bucketIndex(q, axis, centerBox) <= bestBucket;
             });
             split = static_cast<std::size_t>(mid - p);
+            if (split == 0 || split == count) // cannot happen with a finite best cost (both sides of its split are non-empty)
+            {
+                makeLeaf();
+                continue;
+            }
         }
 
         BvhNode& node = out.nodes[nodeIdx];
@@ -182,5 +198,34 @@ Bvh buildBvh(std::span<const Positions> triangles)
         work.push_back(Task{task.first, split, task.leafOffset, nodeIdx, false, task.depth + 1});
     }
     return out;
+}
+
+void validateScene(std::span<const BvhNode> nodes, std::size_t numTriangles, std::span<const VertexAttributes> vertexAttributes,
+                   std::size_t numTextures)
+{
+    const std::size_t count = nodes.size();
+    if (count == 0) throw std::runtime_error("scene has no BVH nodes");
+    if (count > 0xFFFFFFFFull) throw std::runtime_error("more than 2^32 BVH nodes");
+    for (std::size_t i = 0; i < count; ++i)
+    {
+        const BvhNode& n = nodes[i];
+        if (n.triangleCount > 0)
+        {
+            if (static_cast<uint64_t>(n.trianglesOffset) + n.triangleCount > numTriangles)
+                throw std::runtime_error("BVH leaf " + std::to_string(i) + " references triangles past the end of the triangle array");
+        }
+        else
+        {
+            if (n.splitAxis > 2) throw std::runtime_error("interior BVH node " + std::to_string(i) + " has an invalid split axis");
+            if (!(i + 1 < n.secondChildOffset && n.secondChildOffset < count))
+                throw std::runtime_error("interior BVH node " + std::to_string(i) + " has a second child that is not strictly ahead of its first child");
+        }
+    }
+    if (!vertexAttributes.empty() && vertexAttributes.size() != numTriangles) throw std::runtime_error("position and vertex attribute counts differ");
+    const std::size_t textures = std::max<std::size_t>(numTextures, 1);
+    for (std::size_t i = 0; i < vertexAttributes.size(); ++i)
+        if (vertexAttributes[i].textureIdx >= textures)
+            throw std::runtime_error("triangle " + std::to_string(i) + " references texture " + std::to_string(vertexAttributes[i].textureIdx) + " of " +
+                                     std::to_string(numTextures));
 }
 } // namespace rf

@@ -15,19 +15,30 @@
 //                 bounds with integer atomics on order-preserving float encodings (aggregated per
 //                 workgroup or per wave in LDS when the lanes share a node), one thread per node runs
 //                 the SAH sweep and derives both children's boxes from the bucket boxes, and a global
-//                 exclusive scan turns the split predicate into a STABLE partition (deterministic
-//                 triangle order: the output does not depend on scheduling).
+//                 exclusive scan turns the split predicate into the permutation libstdc++'s
+//                 std::partition performs (see "partition order" below; deterministic: the output
+//                 does not depend on scheduling).
 //   small phase   one wave per subtree of at most 64 triangles: a triangle per lane in registers,
-//                 bucket reductions through wave-private LDS atomics, in-wave stable partition by
-//                 ballot ranks, explicit LIFO so that the subtree comes out in preorder.
+//                 bucket reductions through wave-private LDS atomics, the same partition permutation
+//                 from ballot ranks, explicit LIFO so that the subtree comes out in preorder.
 //   numbering     subtree sizes bottom-up, preorder indices top-down (first child = index + 1, second
 //                 child = index + 1 + size(first)), then every node is written to its final place.
 //
-// Differences from the host builder that remain: the order of triangles
-// INSIDE a multi-triangle leaf (the host inherits libstdc++'s std::partition / std::nth_element
-// permutation, here the partition is stable), and the sign of a zero box coordinate when a node
-// holds both -0.0f and +0.0f (the host keeps whichever its merge order met first).  Node bytes are
-// otherwise identical; tests/test_gpu_bvh_build.py compares them with memcmp.
+// Partition order.  Closest-hit ties in t go to the first triangle tested (`t < tmax` is strict,
+// wgsl:508), so the order of triangles INSIDE a multi-triangle leaf is observable when coincident
+// triangles carry different attributes.  The host builder (rf_bvh.cpp) calls std::partition, i.e. on
+// Linux libstdc++'s bidirectional algorithm: scan forward to the first element failing the predicate,
+// backward to the last one passing it, swap, repeat.  Its net effect on a range with m passing
+// elements is closed-form: the k-th failing element among the first m positions (ascending) trades
+// places with the k-th passing element among the remaining positions (descending); everything else
+// stays.  Both phases apply exactly that permutation (ranks from the scan / from ballots, the
+// "k-th passing / failing element" looked up through the inverse of the stable order), and the
+// 2-triangle case reproduces std::nth_element's insertion sort (swap iff the second centroid is
+// smaller).  Result: triangleIndices -- and therefore a whole baked .pt -- equals the host builder's
+// byte for byte (tests/test_gpu_bvh_build.py), coincident triangles included.
+//
+// Difference from the host builder that remains: the sign of a zero box coordinate when a node holds
+// both -0.0f and +0.0f (the host keeps whichever its merge order met first).
 #include "rf_bvh_gpu.hpp"
 
 #include "rf_aabb.hpp"
@@ -188,6 +199,9 @@ __device__ __forceinline__ bool chooseSplit(const uint32_t (&bucketCount)[kBucke
             bestBucket = i;
         }
     }
+    // no finite cost (coordinates so large that the areas overflow): the reference asserts; defined here, in the host
+    // builder (rf_bvh.cpp) as "the node becomes a leaf, whatever its size"
+    if (bestBucket == kNone) return false;
     const float leafCost = 1.0f * static_cast<float>(count);
     const float splitCost = kTraversalCost + best / surfaceArea(nodeBox);
     return count > kMaxLeaf || splitCost < leafCost;
@@ -531,9 +545,23 @@ __global__ __launch_bounds__(kThreads) void kScanAdd(uint32_t* out, uint32_t n, 
         if (base + k < n) out[base + k] += add;
 }
 
-// Stable partition of every splitting node + routing of the triangles to the next level's nodes.
+// inv[stable-partition destination of i] = i for every triangle of a splitting node: position first + r holds the
+// left-going triangle with r left-going ones before it, first + leftCount + r the right-going one of rank r
+__global__ void kInverse(uint32_t n, const int32_t* nodeOf, const LevelNode* level, const uint32_t* flags, const uint32_t* scan, uint32_t* inv)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t nd = nodeOf[i];
+    if (nd < 0 || !level[nd].split) return;
+    const LevelNode& l = level[nd];
+    const uint32_t   leftBefore = scan[i] - scan[l.first];
+    inv[flags[i] ? l.first + leftBefore : l.first + l.leftCount + ((i - l.first) - leftBefore)] = i;
+}
+
+// libstdc++'s std::partition permutation of every splitting node (see the file header) + routing of the
+// triangles to the next level's nodes.
 __global__ void kScatter(uint32_t n, PrimStreams src, PrimStreams dst, const int32_t* nodeOf, int32_t* nodeOfNext, const LevelNode* level,
-                         const uint32_t* flags, const uint32_t* scan)
+                         const uint32_t* flags, const uint32_t* scan, const uint32_t* inv)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -544,14 +572,19 @@ __global__ void kScatter(uint32_t n, PrimStreams src, PrimStreams dst, const int
     {
         const LevelNode& l = level[nd];
         const uint32_t   leftBefore = scan[i] - scan[l.first];
+        const uint32_t   p = i - l.first, m = l.leftCount;
         if (flags[i])
         {
-            to = l.first + leftBefore;
+            // a left-going triangle in the right part swaps with the k-th right-going one of the left part,
+            // k = left-going triangles behind it
+            if (p >= m) to = inv[l.first + m + (m - 1u - leftBefore)];
             next = l.leftNext == kNone ? -1 : static_cast<int32_t>(l.leftNext);
         }
         else
         {
-            to = l.first + l.leftCount + ((i - l.first) - leftBefore);
+            // a right-going triangle in the left part swaps with the k-th left-going one counted from the end,
+            // k = right-going triangles before it
+            if (p < m) to = inv[l.first + (m - 1u - (p - leftBefore))];
             next = l.rightNext == kNone ? -1 : static_cast<int32_t>(l.rightNext);
         }
     }
@@ -579,6 +612,7 @@ __global__ __launch_bounds__(64 * kSmallWaves) void kSmall(uint32_t numTasks, co
     __shared__ uint32_t  sCells[kSmallWaves][kBuckets * 7 + 12]; // per bucket: count + bounds; then node box + centre box
     __shared__ LocalTask sStack[kSmallWaves][kSmallMax];
     __shared__ float     sStage[kSmallWaves][10][kSmallMax];
+    __shared__ uint32_t  sInv[kSmallWaves][kSmallMax];
     const uint32_t       wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t       t = blockIdx.x * kSmallWaves + wave;
     if (t >= numTasks) return;
@@ -706,11 +740,22 @@ __global__ __launch_bounds__(64 * kSmallWaves) void kSmall(uint32_t numTasks, co
             out.trianglesOffset = 0;
             out.triangleCount = 0;
             out.splitAxis = static_cast<uint32_t>(axis);
-            // stable in-wave partition of the range: ranks from ballots, data through LDS
+            // in-wave std::partition permutation of the range (file header): ranks from ballots, the inverse of
+            // the stable order and the data through LDS
             const unsigned long long leftMask = __ballot(left), inMask = __ballot(in);
             const unsigned long long below = (1ull << lane) - 1ull;
-            uint32_t                 to = lane;
-            if (in) to = left ? first + __popcll(leftMask & below) : first + leftCount + __popcll(inMask & ~leftMask & below);
+            const uint32_t           leftRank = __popcll(leftMask & below), rightRank = __popcll(inMask & ~leftMask & below);
+            uint32_t*                inv = sInv[wave];
+            if (in) inv[left ? first + leftRank : first + leftCount + rightRank] = lane;
+            waveSync();
+            uint32_t to = lane;
+            if (in)
+            {
+                const uint32_t p = lane - first;
+                if (left && p >= leftCount) to = inv[first + leftCount + (leftCount - 1u - leftRank)];
+                else if (!left && p < leftCount) to = inv[first + (leftCount - 1u - rightRank)];
+            }
+            waveSync();
             float* stage = &sStage[wave][0][0]; // [value][lane]
             for (int k = 0; k < 3; ++k)
             {
@@ -864,7 +909,7 @@ Bvh buildBvhGpu(std::span<const Positions> triangles, int deviceOrdinal, float* 
     Dev<float4>    a0, b0, a1, b1;
     Dev<float2>    c0, c1;
     Dev<int32_t>   nodeOf0, nodeOf1;
-    Dev<uint32_t>  flags, scan, blockSums;
+    Dev<uint32_t>  flags, scan, blockSums, inv;
     Dev<EncBox>    rootBoxes;
     Dev<GNode>     gnodes;
     Dev<LevelNode> levelA, levelB;
@@ -877,7 +922,7 @@ Bvh buildBvhGpu(std::span<const Positions> triangles, int deviceOrdinal, float* 
     dTris.alloc(n);
     a0.alloc(n), b0.alloc(n), c0.alloc(n), a1.alloc(n), b1.alloc(n), c1.alloc(n);
     nodeOf0.alloc(n), nodeOf1.alloc(n);
-    flags.alloc(n), scan.alloc(n);
+    flags.alloc(n), scan.alloc(n), inv.alloc(n);
     const uint32_t scanBlocks = (n + kThreads * kScanItems - 1) / (kThreads * kScanItems);
     blockSums.alloc(scanBlocks);
     rootBoxes.alloc(2);
@@ -933,7 +978,8 @@ Bvh buildBvhGpu(std::span<const Positions> triangles, int deviceOrdinal, float* 
         hipLaunchKernelGGL(kScanBlocks, dim3(scanBlocks), dim3(kThreads), 0, stream, flags.p, scan.p, n, blockSums.p);
         hipLaunchKernelGGL(kScanSums, dim3(1), dim3(1024), 0, stream, blockSums.p, scanBlocks);
         hipLaunchKernelGGL(kScanAdd, dim3(scanBlocks), dim3(kThreads), 0, stream, scan.p, n, blockSums.p);
-        hipLaunchKernelGGL(kScatter, gridFor(n), dim3(kThreads), 0, stream, n, cur, nxt, nodeOf, nodeOfNext, level, flags.p, scan.p);
+        hipLaunchKernelGGL(kInverse, gridFor(n), dim3(kThreads), 0, stream, n, nodeOf, level, flags.p, scan.p, inv.p);
+        hipLaunchKernelGGL(kScatter, gridFor(n), dim3(kThreads), 0, stream, n, cur, nxt, nodeOf, nodeOfNext, level, flags.p, scan.p, inv.p);
         RF_HIP(hipMemcpyAsync(&h, ctr.p, sizeof h, hipMemcpyDeviceToHost, stream));
         RF_HIP(hipStreamSynchronize(stream));
         if (h.numNodes > maxGNodes || h.smallCount > maxSmall) throw std::runtime_error("buildBvhGpu: node pool overflow");

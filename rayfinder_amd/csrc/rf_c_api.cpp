@@ -647,6 +647,9 @@ int rf_pt_format_scene(const rf_pt_format* f, rf_scene* scene, rf_texture* textu
         scene->vertex_attributes = p.triangleVertexAttributes.data();
         scene->num_triangles = p.trianglePositionAttributes.size();
         for (size_t i = 0; i < p.baseColorTextures.size(); ++i)
+            require(p.baseColorTextures[i].pixels.size() == static_cast<size_t>(p.baseColorTextures[i].width) * p.baseColorTextures[i].height,
+                    "texture pixel count differs from width * height");
+        for (size_t i = 0; i < p.baseColorTextures.size(); ++i)
             textures[i] = rf_texture{p.baseColorTextures[i].pixels.data(), p.baseColorTextures[i].width, p.baseColorTextures[i].height};
         scene->base_color_textures = textures;
         scene->num_textures = p.baseColorTextures.size();

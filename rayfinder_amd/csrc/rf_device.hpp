@@ -44,6 +44,7 @@ struct DeviceScene
     const float*             albedoLut; // 256 entries: pow(i/255, 2.2)
 };
 
+#if defined(__HIPCC__) // device code below; the host only needs the layout constants above (tools/sanitize builds rf_wide.hpp with g++)
 struct RayPrep
 {
     Vec3     origin;
@@ -321,4 +322,5 @@ __device__ __forceinline__ void animatedBlueNoise(const uint8_t* table, uint32_t
     nx = wFract(bx + wFract(a1 * static_cast<float>(n)));
     ny = wFract(by + wFract(a2 * static_cast<float>(n)));
 }
+#endif // __HIPCC__
 } // namespace rf

@@ -455,19 +455,33 @@ struct MeshTransform
 
 Mat4 localMatrix(const Json& node)
 {
+    // fixed-size arrays of an untrusted file: checked, not assumed
+    auto fixed = [](const Json* j, std::size_t n, const char* what) {
+        if (j->array.size() != n) throw std::runtime_error(std::string("glTF: node.") + what + " must have " + std::to_string(n) + " elements");
+    };
     if (const Json* m = node.find("matrix"))
     {
+        fixed(m, 16, "matrix");
         Mat4 r;
         for (int c = 0; c < 4; ++c) r.c[c] = {m->array[4 * c].f32(), m->array[4 * c + 1].f32(), m->array[4 * c + 2].f32(), m->array[4 * c + 3].f32()};
         return r;
     }
     float s[3] = {1, 1, 1}, q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
     if (const Json* j = node.find("scale"))
+    {
+        fixed(j, 3, "scale");
         for (int i = 0; i < 3; ++i) s[i] = j->array[i].f32();
+    }
     if (const Json* j = node.find("rotation"))
+    {
+        fixed(j, 4, "rotation");
         for (int i = 0; i < 4; ++i) q[i] = j->array[i].f32();
+    }
     if (const Json* j = node.find("translation"))
+    {
+        fixed(j, 3, "translation");
         for (int i = 0; i < 3; ++i) t[i] = j->array[i].f32();
+    }
     return mul(mul(translateMatrix(t[0], t[1], t[2]), rotationMatrix(q[0], q[1], q[2], q[3])), scaleMatrix(s[0], s[1], s[2]));
 }
 
@@ -652,6 +666,7 @@ Rgba8Image decodePng(std::span<const uint8_t> data)
         if (off + 12 + len > data.size()) throw std::runtime_error("PNG: truncated chunk");
         if (!std::memcmp(type, "IHDR", 4))
         {
+            if (len != 13) throw std::runtime_error("PNG: IHDR chunk is not 13 bytes long");
             width = be32(body);
             height = be32(body + 4);
             depth = body[8];
@@ -667,6 +682,12 @@ Rgba8Image decodePng(std::span<const uint8_t> data)
     if (width == 0 || height == 0) throw std::runtime_error("PNG: missing IHDR");
     const int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
     if (channels == 0) throw std::runtime_error("PNG: bad colour type");
+    // PNG spec table 11.1: grey 1/2/4/8/16, truecolour and the alpha types 8/16, palette 1/2/4/8
+    const bool depthOk = colorType == 0   ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                         : colorType == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                          : (depth == 8 || depth == 16);
+    if (!depthOk) throw std::runtime_error("PNG: bit depth " + std::to_string(depth) + " is not allowed for colour type " + std::to_string(colorType));
+    if (interlace > 1) throw std::runtime_error("PNG: unknown interlace method");
 
     const std::size_t bitsPerPixel = static_cast<std::size_t>(channels) * static_cast<std::size_t>(depth);
     const std::size_t bpp = std::max<std::size_t>(1, bitsPerPixel / 8);

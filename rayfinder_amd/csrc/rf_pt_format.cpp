@@ -1,5 +1,7 @@
 #include "rf_pt_format.hpp"
 
+#include "rf_bvh.hpp"
+
 #include <cctype>
 #include <cstdio>
 #include <cstring>
@@ -76,7 +78,7 @@ public:
         {
             x.offset = u64();
             x.count = u64();
-            if (x.offset + x.count > bufferSize) throw std::runtime_error("PtFormat slice exceeds its buffer.");
+            if (x.count > bufferSize || x.offset > bufferSize - x.count) throw std::runtime_error("PtFormat slice exceeds its buffer.");
         }
     }
 
@@ -154,8 +156,16 @@ void deserializePt(const uint8_t* data, std::size_t size, PtFormat& f)
         t.width = dims[0];
         t.height = dims[1];
         r.array(t.pixels);
+        if (t.pixels.size() != static_cast<uint64_t>(t.width) * t.height)
+            throw std::runtime_error("PtFormat texture " + std::to_string(i) + " declares " + std::to_string(t.width) + "x" + std::to_string(t.height) +
+                                     " but holds " + std::to_string(t.pixels.size()) + " pixels.");
         f.baseColorTextures.push_back(std::move(t));
     }
+    // a file's hot-path arrays are checked once here; the renderer checks what it is handed again (rf_bvh.hpp)
+    if (f.trianglePositionAttributes.size() != f.triangleVertexAttributes.size())
+        throw std::runtime_error("PtFormat position and vertex attribute arrays differ in length.");
+    if (!f.bvhNodes.empty())
+        validateScene(f.bvhNodes, f.trianglePositionAttributes.size(), f.triangleVertexAttributes, f.baseColorTextures.size());
 }
 
 void writePtFile(const std::string& path, const PtFormat& format)

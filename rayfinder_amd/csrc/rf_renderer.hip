@@ -22,6 +22,7 @@
 // device memory, so a whole batch is enqueued without any host round trip.
 #include "rf_renderer.hpp"
 
+#include "rf_bvh.hpp"
 #include "rf_camera.hpp"
 #include "rf_data.hpp"
 #include "rf_device.hpp"
@@ -1326,6 +1327,8 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     if (sceneView.bvhNodes.empty()) throw std::runtime_error("scene has no BVH nodes");
     if (sceneView.positionAttributes.size() != sceneView.vertexAttributes.size())
         throw std::runtime_error("position and vertex attribute counts differ");
+    // child links, leaf ranges and texture indices are followed blindly on the device: check them once here
+    validateScene(sceneView.bvhNodes, sceneView.positionAttributes.size(), sceneView.vertexAttributes, sceneView.baseColorTextures.size());
 
     // 48-B reference nodes -> 32-B device nodes
     {

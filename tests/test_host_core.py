@@ -399,3 +399,71 @@ def test_untile_inverts_the_tile_major_layout():
                 expect[y, x] = (x, y, tid, 1)
     img = rf.untile(compact, tiles, w, h)
     assert np.array_equal(img, expect)
+
+
+# ---------------------------------------------------------------- untrusted input (round-1 advisor findings)
+def test_build_bvh_without_any_finite_sah_cost_terminates_as_one_leaf():
+    """Coordinates around 1e20: every surface area overflows, no split cost passes `<`; the reference asserts
+    (bvh.cpp:215-216) and its release build would recurse forever.  Documented choice: the node becomes a leaf."""
+    rng = np.random.default_rng(3)
+    P = (rng.uniform(-1, 1, (600, 9)) * 1e20).astype(np.float32)
+    a, ai, _ = rf.build_bvh(P)
+    b, bi, _ = orc.build_bvh(P)
+    assert len(a) == 1 and a[0]["triangleCount"] == 600
+    assert a.tobytes() == np.ascontiguousarray(b).tobytes() and np.array_equal(ai, bi)
+    # mixed: a sane cluster plus far-away giants still builds and matches
+    P2 = np.concatenate([rng.uniform(-1, 1, (500, 9)), rng.uniform(-1, 1, (300, 9)) * 3e19]).astype(np.float32)
+    a, ai, _ = rf.build_bvh(P2)
+    b, bi, _ = orc.build_bvh(P2)
+    assert a.tobytes() == np.ascontiguousarray(b).tobytes() and np.array_equal(ai, bi)
+
+
+def _duck_offsets(data):
+    n_nodes = struct.unpack_from("<Q", data, 9)[0]
+    return n_nodes, 17
+
+
+@pytest.mark.parametrize("what", ["self_link", "backward_link", "link_past_end", "leaf_range", "split_axis", "texture_index", "texture_size", "slice_wrap"])
+def test_corrupted_pt_is_rejected_before_it_reaches_the_device(duck_pt, what):
+    data = bytearray(duck_pt.serialize())
+    n_nodes, at = _duck_offsets(data)
+    nodes = np.frombuffer(bytes(data[at:at + 48 * n_nodes]), np.uint32).reshape(-1, 12)
+    interior = int(np.nonzero(nodes[:, 10] == 0)[0][5]); leaf = int(np.nonzero(nodes[:, 10] > 0)[0][5])
+    f = lambda k: at + 48 * k + 32   # trianglesOffset, secondChildOffset, triangleCount, splitAxis
+    if what == "self_link":
+        struct.pack_into("<I", data, f(interior) + 4, interior)
+    elif what == "backward_link":
+        struct.pack_into("<I", data, f(interior) + 4, interior + 1)     # second child == first child
+    elif what == "link_past_end":
+        struct.pack_into("<I", data, f(interior) + 4, n_nodes)
+    elif what == "leaf_range":
+        struct.pack_into("<I", data, f(leaf), 4212)                      # offset == numTriangles, count >= 1
+    elif what == "split_axis":
+        struct.pack_into("<I", data, f(interior) + 12, 7)
+    elif what == "texture_index":
+        va_at = at + 48 * n_nodes + 8 + 36 * 4212 + 8 + 48 * 4212 + 8
+        struct.pack_into("<I", data, va_at + 80 * 100 + 72, 3)
+    elif what == "texture_size":
+        struct.pack_into("<II", data, len(data) - 4 * 512 * 512 - 16, 4096, 4096)   # declares 16 Mi texels, holds 256 Ki
+    else:
+        # first slice table follows the 8 arrays: offset = 2^64 - 1, count = 2 wrapped past the old check
+        off = 9
+        for s in [48, 36, 48, 80, 16, 16, 8, 4]:
+            off += 8 + struct.unpack_from("<Q", data, off)[0] * s
+        assert struct.unpack_from("<Q", data, off)[0] >= 1
+        struct.pack_into("<QQ", data, off + 8, 2**64 - 1, 2)
+    with pytest.raises(rf.RayfinderError):
+        rf.PtFormat.deserialize(bytes(data))
+
+
+def test_png_header_checks():
+    """IHDR must be 13 bytes and the (colour type, bit depth) pair one the PNG specification allows."""
+    import zlib
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+    def png(depth, ctype, ihdr_len=13):
+        ihdr = struct.pack(">IIBBBBB", 2, 2, depth, ctype, 0, 0, 0)[:ihdr_len]
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b"")
+    for depth, ctype, n in [(3, 0, 13), (32, 0, 13), (200, 2, 13), (4, 2, 13), (16, 3, 13), (8, 6, 9), (8, 5, 13)]:
+        with pytest.raises(rf.RayfinderError):
+            rf.texture_from_memory(png(depth, ctype, n))

@@ -49,3 +49,50 @@ for i in range(300):
     else:
         for _ in range(4): b[int(rng.integers(9, len(b)))] = int(rng.integers(0, 256))
     open(f"{out}/ingest/p{i}.pt", "wb").write(bytes(b))
+# targeted corruptions of the hot-path arrays of a .pt (child links, leaf ranges, texture indices, texture sizes)
+import struct
+n_nodes = struct.unpack_from("<Q", pt, 9)[0]
+nodes_at = 17
+n_tris = struct.unpack_from("<Q", pt, nodes_at + 48 * n_nodes)[0]
+for i in range(300):
+    b = bytearray(pt); m = i % 4
+    k = int(rng.integers(0, n_nodes)); field = nodes_at + 48 * k + 32
+    if m == 0:
+        struct.pack_into("<I", b, field + 4, int(rng.integers(0, 2**32)))             # secondChildOffset
+    elif m == 1:
+        struct.pack_into("<II", b, field, int(rng.integers(0, 2**32)), int(rng.integers(0, 2**31)))  # trianglesOffset (+ link)
+        struct.pack_into("<I", b, field + 8, int(rng.integers(0, 2**20)))             # triangleCount
+    elif m == 2:
+        struct.pack_into("<I", b, field + 4, k)                                       # self link (cycle)
+        struct.pack_into("<I", b, field + 8, 0)
+    else:
+        # texture header: last texture's {w, h} sits 8 + 8 bytes before its pixel array
+        tex = rf.PtFormat.from_gltf(os.path.join(root, "tests", "golden", "Duck.glb")).arrays()["baseColorTextures"][-1]
+        at = len(b) - 4 * tex[0].size - 8 - 8
+        struct.pack_into("<II", b, at, int(rng.integers(1, 2**16)), int(rng.integers(1, 2**16)))
+    open(f"{out}/ingest/q{i}.pt", "wb").write(bytes(b))
+# PNG header corruptions inside the GLB (bit depth / colour type / IHDR length); the PNG starts at BIN + 102040
+png_at = 2088 + 102040
+assert glb[png_at:png_at + 8] == b"\x89PNG\r\n\x1a\n"
+for i in range(200):
+    b = bytearray(glb); m = i % 3
+    if m == 0:
+        b[png_at + 8 + 8 + 8] = int(rng.integers(0, 256))          # bit depth
+    elif m == 1:
+        b[png_at + 8 + 8 + 9] = int(rng.integers(0, 256))          # colour type
+    else:
+        struct.pack_into(">I", b, png_at + 8, int(rng.integers(0, 13)))   # IHDR length < 13
+    open(f"{out}/ingest/h{i}.glb", "wb").write(bytes(b))
+# node transform arrays that are too short
+import json
+jlen = struct.unpack_from("<I", glb, 12)[0]
+js = json.loads(glb[20:20 + jlen])
+for i, (key, val) in enumerate([("matrix", [1.0] * 7), ("scale", [1.0]), ("rotation", [0.0, 0.0]), ("translation", [])]):
+    j2 = json.loads(json.dumps(js)); node = j2["nodes"][0]
+    for k in ("matrix", "scale", "rotation", "translation"): node.pop(k, None)
+    node[key] = val
+    body = json.dumps(j2).encode(); body += b" " * (-len(body) % 4)
+    rest = glb[20 + jlen:]
+    out_b = bytearray(glb[:12]) + struct.pack("<I", len(body)) + b"JSON" + body + rest
+    struct.pack_into("<I", out_b, 8, len(out_b))
+    open(f"{out}/ingest/t{i}.glb", "wb").write(bytes(out_b))
