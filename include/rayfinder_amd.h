@@ -113,6 +113,11 @@ typedef struct rf_stats
     double   ms_raygen, ms_closest, ms_shade, ms_shadow, ms_accumulate; /* while timing is enabled */
     uint32_t launches_raygen, launches_closest, launches_shade, launches_shadow, launches_accumulate, reserved2;
     uint64_t closest_record_fetches, shadow_record_fetches; /* 64-byte BVH records fetched (counting build) */
+    /* Always counted.  abandoned_rays: traversals that needed more than 96 stack entries and were cut short (the
+     * reference's 32-entry stack, ray_intersection.cpp:148,194 / wgsl:327,375, is overrun long before: undefined
+     * there); 0 on every scene tested.  scalar_redo_rays: rays the packed traversal handed to the reference-ordered
+     * scalar one (axis-parallel / non-finite rays, more than 12 pending far children) -- results are identical. */
+    uint64_t abandoned_rays, scalar_redo_rays;
 } rf_stats;
 
 typedef struct rf_renderer rf_renderer;
@@ -163,12 +168,40 @@ RF_API int rf_renderer_get_bounce_stats(rf_renderer* r, uint32_t capacity, uint6
 
 /* Multi-GPU tile sharding (no reference counterpart: the reference is single-device).  The image
  * is cut into 32x32 tiles dealt to ranks in a scrambled round-robin; each rank renders its tiles
- * into a compact tile-major float4 buffer that the caller gathers (RCCL) and un-tiles. */
+ * into a compact tile-major float4 buffer; rf_renderer_gather_frame (below) brings the shards to one rank. */
 RF_API int rf_renderer_set_tile_shard(rf_renderer* r, uint32_t rank, uint32_t world_size);
 RF_API int rf_renderer_shard_tiles(rf_renderer* r, uint32_t* tile_ids /* may be NULL */, uint32_t* num_tiles);
 RF_API int rf_renderer_accumulation_device_buffer(rf_renderer* r, void** device_ptr, uint64_t* bytes);
 RF_API int rf_renderer_bind_accumulation_buffer(rf_renderer* r, void* device_ptr, uint64_t bytes);
+
+/* Frame-end exchange behind the C ABI (no reference counterpart): one RCCL communicator per rank
+ * (one process or host thread per GPU).  Rank 0 calls rf_comm_unique_id and hands the 128 bytes to the other ranks
+ * through the host application's own channel; then every rank calls rf_comm_create (collective).
+ * rf_renderer_gather_frame (collective, enqueued on the handle's stream behind the frame's kernels): every rank
+ * ncclSend()s its compact tile buffer to `root`, the root posts all ncclRecv()s in one group (all xGMI ingress
+ * links at once; no reduction, no ring) and un-tiles the shards into a row-major width*height float4 image in
+ * device memory (*image_device_out on the root, NULL elsewhere; owned by the comm, valid until the next gather).
+ * The renderer's tile shard must be (rank, world_size) of the comm.  RF_GATHER_LOOPBACK: the root's own shard also
+ * goes through ncclSend/ncclRecv instead of being read in place (self-test of the RCCL path at world size 1). */
+typedef struct rf_comm rf_comm;
+#define RF_COMM_ID_BYTES 128
+#define RF_GATHER_LOOPBACK 1u
+RF_API int  rf_comm_unique_id(uint8_t id_out[RF_COMM_ID_BYTES]);
+RF_API int  rf_comm_create(const uint8_t id[RF_COMM_ID_BYTES], uint32_t rank, uint32_t world_size, int32_t device_ordinal, rf_comm** out);
+RF_API void rf_comm_destroy(rf_comm* c);
+RF_API int  rf_renderer_gather_frame(rf_renderer* r, rf_comm* c, uint32_t root, uint32_t flags, void** image_device_out /* NULL ok */);
+/* fsMain's display transform (wgsl:59-63) for a row-major float4 SUM image in device memory -- the frame
+ * rf_renderer_gather_frame left on the root: num_pixels BGRA8 texels to the host, with the handle's exposure. */
+RF_API int  rf_renderer_tonemap_device_image(rf_renderer* r, const void* image_device, uint64_t num_pixels, uint32_t samples, uint32_t* dst_bgra8);
+/* Root: wait for the exchange and copy the gathered image to the host (width*height*4 floats, row-major, the
+ * layout of rf_renderer_read_accumulation). */
+RF_API int  rf_comm_read_frame(rf_comm* c, rf_renderer* r, float* dst);
+/* Max over ranks of *value (timing plumbing for hosts without another collective layer; also a barrier). */
+RF_API int  rf_comm_all_reduce_max(rf_comm* c, rf_renderer* r /* NULL: default stream */, double* value);
 /* Host helpers (no GPU needed). */
+/* The staging layout the gather uses: shards rank after rank, each rank's tiles in ascending tile id.
+ * rank_first_tile[world_size + 1], tile_slot[tiles] (staging position of a tile, in tiles), tile_owner[tiles]. */
+RF_API int rf_gather_layout(uint32_t width, uint32_t height, uint32_t world_size, uint32_t* rank_first_tile, uint32_t* tile_slot, uint32_t* tile_owner);
 RF_API int rf_tiles_for_rank(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size, uint32_t* tile_ids, uint32_t* num_tiles);
 RF_API int rf_untile(const float* compact, const uint32_t* tile_ids, uint32_t num_tiles, uint32_t width, uint32_t height, float* image);
 

@@ -267,6 +267,55 @@ def scene_from_arrays(nodes, positions48, attrs80, textures):
     return sc
 
 
+# ------------------------------------------------------------------------------------- multi-GPU frame exchange
+RF_GATHER_LOOPBACK = 1
+
+
+def gather_layout(width, height, world_size):
+    """Staging layout of the frame-end gather: (rank_first_tile[world+1], tile_slot[tiles], tile_owner[tiles])."""
+    n = ((width + 31) // 32) * ((height + 31) // 32)
+    first = np.zeros(world_size + 1, np.uint32); slot = np.zeros(n, np.uint32); owner = np.zeros(n, np.uint32)
+    check(lib.rf_gather_layout(width, height, world_size, _ptr(first), _ptr(slot), _ptr(owner)))
+    return first, slot, owner
+
+
+def comm_unique_id():
+    """ncclGetUniqueId: 128 bytes that rank 0 hands to the other ranks before TileComm(...)."""
+    buf = np.zeros(128, np.uint8)
+    check(lib.rf_comm_unique_id(_ptr(buf)))
+    return buf.tobytes()
+
+
+class TileComm:
+    """One RCCL communicator per rank (one process per GPU); collective constructor."""
+
+    def __init__(self, unique_id, rank, world_size, device_ordinal=0):
+        buf = np.frombuffer(bytes(unique_id), np.uint8).copy()
+        assert buf.size == 128
+        self._h = C.c_void_p()
+        self.rank, self.world_size = rank, world_size
+        check(lib.rf_comm_create(_ptr(buf), rank, world_size, device_ordinal, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.rf_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def read_frame(self, renderer, width, height):
+        """Root: the gathered row-major (H, W, 4) float image."""
+        img = np.zeros((height, width, 4), np.float32)
+        check(lib.rf_comm_read_frame(self._h, renderer._h, _ptr(img)))
+        return img
+
+    def all_reduce_max(self, value, renderer=None):
+        v = C.c_double(value)
+        check(lib.rf_comm_all_reduce_max(self._h, renderer._h if renderer is not None else None, C.byref(v)))
+        return v.value
+
+
 # ------------------------------------------------------------------------------------- renderer
 class ReferencePathTracer:
     """Host-side mirror of nlrs::ReferencePathTracer (src/pt/reference_path_tracer.hpp:59-76).
@@ -359,6 +408,18 @@ class ReferencePathTracer:
         n = C.c_uint64(0)
         check(lib.rf_renderer_accumulation_device_buffer(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def gather_frame(self, comm, root=0, loopback=False):
+        """Frame-end RCCL exchange (collective; enqueued on the handle's stream).  Root: device pointer of the
+        row-major W*H float4 image; other ranks: None."""
+        p = C.c_void_p()
+        check(lib.rf_renderer_gather_frame(self._h, comm._h, root, RF_GATHER_LOOPBACK if loopback else 0, C.byref(p)))
+        return p.value
+
+    def tonemap_device_image(self, device_ptr, width, height, samples):
+        out = np.zeros((height, width), np.uint32)
+        check(lib.rf_renderer_tonemap_device_image(self._h, C.c_void_p(device_ptr), width * height, samples, _ptr(out)))
+        return out
 
     def bind_accumulation_buffer(self, device_ptr, nbytes):
         check(lib.rf_renderer_bind_accumulation_buffer(self._h, C.c_void_p(device_ptr), nbytes))

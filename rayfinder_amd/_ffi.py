@@ -73,7 +73,8 @@ class Stats(C.Structure):
                 ("ms_accumulate", C.c_double),
                 ("launches_raygen", C.c_uint32), ("launches_closest", C.c_uint32), ("launches_shade", C.c_uint32),
                 ("launches_shadow", C.c_uint32), ("launches_accumulate", C.c_uint32), ("reserved2", C.c_uint32),
-                ("closest_record_fetches", C.c_uint64), ("shadow_record_fetches", C.c_uint64)]
+                ("closest_record_fetches", C.c_uint64), ("shadow_record_fetches", C.c_uint64),
+                ("abandoned_rays", C.c_uint64), ("scalar_redo_rays", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
@@ -118,6 +119,14 @@ SIGNATURES = {
     "rf_renderer_shard_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_renderer_accumulation_device_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "rf_renderer_bind_accumulation_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "rf_comm_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rf_comm_destroy": (None, [C.c_void_p]),
+    "rf_renderer_gather_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "rf_renderer_tonemap_device_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "rf_comm_read_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rf_comm_all_reduce_max": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "rf_gather_layout": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_tiles_for_rank": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rf_renderer_trace_primary_stats": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,24 +1,28 @@
 // rf-render <scene.pt|scene.glb> [--width W] [--height H] [--spp N] [--bounces B] [--vfov deg]
 //           [--zenith deg] [--azimuth deg] [--turbidity t] [--exposure-stops s] [--out image.png]
-//           [--pfm image.pfm]
+//           [--pfm image.pfm] [--gpus N]
 // Offline counterpart of the interactive `pt` app (src/pt/main.cpp): same default camera pose,
 // sky and exposure; renders all samples and writes the tonemapped image (and optionally the
-// mean radiance as PFM).
+// mean radiance as PFM).  --gpus N: one host thread per GPU, the image tile-sharded across them, one RCCL
+// gather to GPU 0 at frame end (rf_renderer_gather_frame).
 #include "cli_common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <thread>
 
 int main(int argc, char** argv)
 {
     if (argc < 2)
     {
         std::printf("Usage: rf-render <scene.pt|scene.glb> [--width W] [--height H] [--spp N] [--bounces B] [--vfov deg]\n"
-                    "                 [--zenith deg] [--azimuth deg] [--turbidity t] [--exposure-stops s] [--out image.png] [--pfm image.pfm]\n");
+                    "                 [--zenith deg] [--azimuth deg] [--turbidity t] [--exposure-stops s] [--out image.png] [--pfm image.pfm] [--gpus N]\n");
         return 0;
     }
     uint32_t    W = 1920, H = 1080, spp = 64, bounces = 2; // UI defaults src/pt/main.cpp:46-60
+    uint32_t    gpus = 1;
     float       vfov = 70.0f, zenith = 30.0f, azimuth = 0.0f, turbidity = 1.0f;
     int         stops = 2;
     std::string out = "render.png", pfm;
@@ -35,6 +39,7 @@ int main(int argc, char** argv)
         else if (k == "--azimuth") azimuth = static_cast<float>(std::atof(val));
         else if (k == "--turbidity") turbidity = static_cast<float>(std::atof(val));
         else if (k == "--exposure-stops") stops = std::atoi(val);
+        else if (k == "--gpus") gpus = static_cast<uint32_t>(std::max(1, std::atoi(val)));
         else if (k == "--out") out = val;
         else if (k == "--pfm") pfm = val;
         else
@@ -59,22 +64,61 @@ int main(int argc, char** argv)
     desc.render_params.num_bounces = bounces;
     desc.render_params.sky = rf_sky{turbidity, {1.0f, 1.0f, 1.0f}, zenith, azimuth};
     desc.render_params.exposure = 1.0f / std::exp2(static_cast<float>(stops));
-    rf_renderer* renderer = nullptr;
-    rfCheck(rf_renderer_create(&desc, &scene, &renderer), "create renderer");
+    // One host thread per GPU (gpus > 1: the image is tile-sharded; one RCCL gather to rank 0 at frame end).
+    uint8_t commId[RF_COMM_ID_BYTES] = {};
+    if (gpus > 1) rfCheck(rf_comm_unique_id(commId), "RCCL unique id");
+    std::atomic<unsigned long long> closestRays{0}, shadowRays{0};
+    std::vector<uint32_t>           bgra(static_cast<size_t>(W) * H);
+    std::vector<float>              acc;
+    if (!pfm.empty()) acc.resize(static_cast<size_t>(W) * H * 4);
+    double       seconds = 0.0;
+    const auto   worker = [&](uint32_t rank) {
+        rf_renderer_descriptor d = desc;
+        d.device_ordinal = static_cast<int32_t>(rank);
+        rf_renderer* renderer = nullptr;
+        rfCheck(rf_renderer_create(&d, &scene, &renderer), "create renderer");
+        rf_comm* comm = nullptr;
+        if (gpus > 1)
+        {
+            rfCheck(rf_renderer_set_tile_shard(renderer, rank, gpus), "tile shard");
+            rfCheck(rf_comm_create(commId, rank, gpus, static_cast<int32_t>(rank), &comm), "RCCL communicator");
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        rfCheck(rf_renderer_render(renderer, spp), "render");
+        void* gathered = nullptr;
+        if (comm) rfCheck(rf_renderer_gather_frame(renderer, comm, 0, 0, &gathered), "gather");
+        rfCheck(rf_renderer_synchronize(renderer), "synchronize");
+        if (rank == 0) seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rf_stats stats;
+        rfCheck(rf_renderer_get_stats(renderer, &stats), "stats");
+        closestRays += stats.closest_rays;
+        shadowRays += stats.shadow_rays;
+        if (rank == 0)
+        {
+            if (comm)
+            {
+                rfCheck(rf_renderer_tonemap_device_image(renderer, gathered, static_cast<uint64_t>(W) * H, spp, bgra.data()), "tonemap");
+                if (!acc.empty()) rfCheck(rf_comm_read_frame(comm, renderer, acc.data()), "read frame");
+            }
+            else
+            {
+                rfCheck(rf_renderer_read_tonemapped(renderer, bgra.data()), "tonemap");
+                uint32_t n = 0;
+                if (!acc.empty()) rfCheck(rf_renderer_read_accumulation(renderer, acc.data(), &n), "read accumulation");
+            }
+        }
+        if (comm) rf_comm_destroy(comm);
+        rf_renderer_destroy(renderer);
+    };
+    std::vector<std::thread> threads;
+    for (uint32_t rank = 1; rank < gpus; ++rank) threads.emplace_back(worker, rank);
+    worker(0);
+    for (std::thread& t : threads) t.join();
 
-    const auto t0 = std::chrono::steady_clock::now();
-    rfCheck(rf_renderer_render(renderer, spp), "render");
-    rfCheck(rf_renderer_synchronize(renderer), "synchronize");
-    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    rf_stats     stats;
-    rfCheck(rf_renderer_get_stats(renderer, &stats), "stats");
-    const double rays = static_cast<double>(stats.closest_rays + stats.shadow_rays);
-    std::printf("%ux%u, %u spp, %u bounces: %.3f s, %.1f Mrays/s (%llu closest + %llu shadow rays), %.1f%% done\n", W, H, spp, bounces, seconds,
-                rays / seconds * 1e-6, (unsigned long long)stats.closest_rays, (unsigned long long)stats.shadow_rays,
-                rf_renderer_render_progress_percentage(renderer));
+    const double rays = static_cast<double>(closestRays.load() + shadowRays.load());
+    std::printf("%ux%u, %u spp, %u bounces on %u GPU(s): %.3f s, %.1f Mrays/s (%llu closest + %llu shadow rays)\n", W, H, spp, bounces, gpus, seconds,
+                rays / seconds * 1e-6, closestRays.load(), shadowRays.load());
 
-    std::vector<uint32_t> bgra(static_cast<size_t>(W) * H);
-    rfCheck(rf_renderer_read_tonemapped(renderer, bgra.data()), "tonemap");
     std::vector<uint8_t> rgba(bgra.size() * 4);
     for (size_t i = 0; i < bgra.size(); ++i)
     {
@@ -84,14 +128,7 @@ int main(int argc, char** argv)
         rgba[4 * i + 3] = 255;
     }
     if (!writePngRgba(out, rgba.data(), W, H)) return 1;
-    if (!pfm.empty())
-    {
-        std::vector<float> acc(static_cast<size_t>(W) * H * 4);
-        uint32_t           n = 0;
-        rfCheck(rf_renderer_read_accumulation(renderer, acc.data(), &n), "read accumulation");
-        writePfm(pfm, acc.data(), W, H, 1.0f / static_cast<float>(std::max(n, 1u)));
-    }
-    rf_renderer_destroy(renderer);
+    if (!pfm.empty()) writePfm(pfm, acc.data(), W, H, 1.0f / static_cast<float>(std::max(spp, 1u)));
     rf_pt_format_destroy(pt);
     return 0;
 }

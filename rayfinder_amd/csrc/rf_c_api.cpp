@@ -5,6 +5,7 @@
 #include "rf_bvh.hpp"
 #include "rf_bvh_gpu.hpp"
 #include "rf_camera.hpp"
+#include "rf_comm.hpp"
 #include "rf_gltf.hpp"
 #include "rf_pt_format.hpp"
 #include "rf_renderer.hpp"
@@ -22,6 +23,11 @@ static_assert(sizeof(rf_camera) == sizeof(rf::Camera));
 struct rf_renderer
 {
     std::unique_ptr<rf::Renderer> impl;
+};
+
+struct rf_comm
+{
+    std::unique_ptr<rf::TileComm> impl;
 };
 
 struct rf_pt_format
@@ -285,6 +291,8 @@ int rf_renderer_get_stats(rf_renderer* r, rf_stats* out)
         out->launches_accumulate = s.launchesAccumulate;
         out->closest_record_fetches = s.closestRecordFetches;
         out->shadow_record_fetches = s.shadowRecordFetches;
+        out->abandoned_rays = s.abandonedRays;
+        out->scalar_redo_rays = s.scalarRedoRays;
         return RF_OK;
     });
 }
@@ -325,6 +333,83 @@ int rf_renderer_bind_accumulation_buffer(rf_renderer* r, void* device_ptr, uint6
     return guarded([&] {
         require(r, "null argument");
         r->impl->bindAccumulationBuffer(device_ptr, bytes);
+        return RF_OK;
+    });
+}
+
+int rf_comm_unique_id(uint8_t id_out[RF_COMM_ID_BYTES])
+{
+    return guarded([&] {
+        require(id_out, "null argument");
+        rf::TileComm::uniqueId(id_out);
+        return RF_OK;
+    });
+}
+
+int rf_comm_create(const uint8_t id[RF_COMM_ID_BYTES], uint32_t rank, uint32_t world_size, int32_t device_ordinal, rf_comm** out)
+{
+    return guarded([&] {
+        require(id && out, "null argument");
+        require(world_size > 0 && rank < world_size, "invalid rank / world size");
+        auto h = std::make_unique<rf_comm>();
+        h->impl = std::make_unique<rf::TileComm>(id, rank, world_size, device_ordinal);
+        *out = h.release();
+        return RF_OK;
+    });
+}
+
+void rf_comm_destroy(rf_comm* c) { delete c; }
+
+int rf_renderer_gather_frame(rf_renderer* r, rf_comm* c, uint32_t root, uint32_t flags, void** image_device_out)
+{
+    return guarded([&] {
+        require(r && c, "null argument");
+        require(root < c->impl->worldSize(), "gather root out of range");
+        require(r->impl->shardRank() == c->impl->rank() && r->impl->shardWorldSize() == c->impl->worldSize(),
+                "the renderer's tile shard differs from the communicator's rank / world size (call rf_renderer_set_tile_shard first)");
+        const void* image = c->impl->gatherFrame(r->impl->accumulationDevicePointer(), r->impl->width(), r->impl->height(), root, r->impl->streamHandle(),
+                                                 (flags & RF_GATHER_LOOPBACK) != 0);
+        if (image_device_out) *image_device_out = const_cast<void*>(image);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_tonemap_device_image(rf_renderer* r, const void* image_device, uint64_t num_pixels, uint32_t samples, uint32_t* dst)
+{
+    return guarded([&] {
+        require(r && image_device && dst, "null argument");
+        require(samples > 0, "samples must be > 0");
+        r->impl->tonemapDeviceImage(image_device, num_pixels, samples, dst);
+        return RF_OK;
+    });
+}
+
+int rf_comm_read_frame(rf_comm* c, rf_renderer* r, float* dst)
+{
+    return guarded([&] {
+        require(c && r && dst, "null argument");
+        c->impl->readFrame(dst, r->impl->streamHandle());
+        return RF_OK;
+    });
+}
+
+int rf_comm_all_reduce_max(rf_comm* c, rf_renderer* r, double* value)
+{
+    return guarded([&] {
+        require(c && value, "null argument");
+        *value = c->impl->allReduceMax(*value, r ? r->impl->streamHandle() : nullptr);
+        return RF_OK;
+    });
+}
+
+int rf_gather_layout(uint32_t width, uint32_t height, uint32_t world_size, uint32_t* rank_first_tile, uint32_t* tile_slot, uint32_t* tile_owner)
+{
+    return guarded([&] {
+        require(width > 0 && height > 0 && world_size > 0, "empty frame or world");
+        const rf::GatherLayout g = rf::gatherLayout(width, height, world_size);
+        if (rank_first_tile) std::memcpy(rank_first_tile, g.rankFirstTile.data(), g.rankFirstTile.size() * sizeof(uint32_t));
+        if (tile_slot) std::memcpy(tile_slot, g.tileSlot.data(), g.tileSlot.size() * sizeof(uint32_t));
+        if (tile_owner) std::memcpy(tile_owner, g.tileOwner.data(), g.tileOwner.size() * sizeof(uint32_t));
         return RF_OK;
     });
 }

@@ -148,6 +148,7 @@ struct TraversalCounters
     uint32_t nodesVisited = 0;
     uint32_t triangleTests = 0;
     uint32_t stackHigh = 0;
+    uint32_t abandoned = 0; // maintained in every build: the ray needed more than kLdsStack + kSpillStack stack entries
 };
 
 // One ray, the reference's visit order.  ANY_HIT: return at the first accepted triangle
@@ -213,7 +214,14 @@ __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, 
                 current = neg ? link : current + 1;
                 if (LDS > 0 && stackSize < LDS) ldsStackLane[stackSize * kBlock] = deferred;
                 else if (stackSize - LDS < kSpill) spill[stackSize - LDS] = deferred;
-                else break; // deeper than kLdsStack + kSpillStack: abandon the ray (reference: undefined past 32)
+                else
+                {
+                    // deeper than kLdsStack + kSpillStack = 96 entries: the ray is abandoned with what it has found so
+                    // far (the reference's 32-entry stack is overrun, i.e. undefined, long before); reported through
+                    // rf_stats.abandoned_rays so that a caller can tell that it happened
+                    counters.abandoned = 1;
+                    break;
+                }
                 ++stackSize;
                 if (COUNT) counters.stackHigh = max(counters.stackHigh, static_cast<uint32_t>(stackSize));
                 advance = true;

@@ -87,6 +87,7 @@ struct DeviceCounters
     // wave-level trip counts of kTraceWide's loops (counting build): lane utilisation = lane work / (64 * trips)
     unsigned long long descendTrips[2], leafTrips[2], leafPhases[2], refillTrips[2], popLaneTrips[2], outerTrips[2];
     unsigned long long scalarRedo[2]; // rays redone by the scalar traversal (irregular or stack overflow), all builds
+    unsigned long long abandonedRays; // rays whose traversal stack outgrew 96 entries (result = what was found until then), all builds
 };
 
 struct FrameParams
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
         const float4   d = ps.rayD[slot];
         ClosestHit     h;
         traverse<false, COUNT>(scene, vec3(o.x, o.y, o.z), vec3(d.x, d.y, d.z), kTMax, &sStack[threadIdx.x], h, tc);
+        if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
         ps.hit[slot] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f);
         if (h.triangle != kMiss) ps.rayO[slot] = make_float4(h.p.x, h.p.y, h.p.z, 0.0f);
     }
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
         const Vec3     l = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
         ClosestHit     h;
         const bool     occluded = traverse<true, COUNT>(scene, vec3(o.x, o.y, o.z), l, kTMax, &sStack[threadIdx.x], h, tc);
+        if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
         const float    visibility = occluded ? 0.0f : 1.0f;
         const float4   pend = ps.pending[slot];
         const float4   rad4 = ps.rad[slot];
@@ -725,6 +728,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                 atomicAdd(&counters->scalarRedo[ANY_HIT ? 1 : 0], 1ull);
                 best.triangle = kMiss;
                 occluded = traverse<ANY_HIT, COUNT, 0>(scene, vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, tMax, nullptr, best, c2);
+                if (c2.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
                 rayTMax = best.triangle != kMiss ? best.t : tMax;
                 rayNodes = c2.nodesVisited;
                 rayTris = c2.triangleTests;
@@ -848,7 +852,7 @@ __global__ void kTonemap(const float4* image, uint32_t n, uint32_t accumulatedSa
 
 // bvh-visualizer pass (src/bvh-visualizer/main.cpp:60-78): pinhole camera.cpp:44-52 rays.
 __global__ __launch_bounds__(kBlock) void kPrimaryStats(DeviceScene scene, Camera cam, uint32_t width, uint32_t height,
-                                                         uint32_t* nodesVisited, uint8_t* hitOut, float* tOut, uint32_t* triTests)
+                                                         uint32_t* nodesVisited, uint8_t* hitOut, float* tOut, uint32_t* triTests, DeviceCounters* counters)
 {
     __shared__ uint32_t sStack[kLdsStack * kBlock];
     // 8x8 pixel blocks per wave for coherence; output is row-major
@@ -864,6 +868,7 @@ __global__ __launch_bounds__(kBlock) void kPrimaryStats(DeviceScene scene, Camer
     ClosestHit        h;
     TraversalCounters tc;
     const bool        found = traverse<false, true>(scene, cam.origin, dir, FLT_MAX, &sStack[threadIdx.x], h, tc);
+    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
     const size_t      k = static_cast<size_t>(i) * width + j;
     nodesVisited[k] = tc.nodesVisited;
     if (hitOut) hitOut[k] = found ? 1 : 0;
@@ -872,7 +877,7 @@ __global__ __launch_bounds__(kBlock) void kPrimaryStats(DeviceScene scene, Camer
 }
 
 __global__ __launch_bounds__(kBlock) void kIntersectRays(DeviceScene scene, const float* rays, uint64_t n, float tMax, uint32_t* triOut,
-                                                          float* tOut, float* uvOut, float* pOut, uint32_t* nvOut, uint32_t* ttOut)
+                                                          float* tOut, float* uvOut, float* pOut, uint32_t* nvOut, uint32_t* ttOut, DeviceCounters* counters)
 {
     __shared__ uint32_t sStack[kLdsStack * kBlock];
     const uint64_t      i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -881,6 +886,7 @@ __global__ __launch_bounds__(kBlock) void kIntersectRays(DeviceScene scene, cons
     ClosestHit        h;
     TraversalCounters tc;
     const bool        found = traverse<false, true>(scene, vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), tMax, &sStack[threadIdx.x], h, tc);
+    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
     triOut[i] = h.triangle;
     if (tOut) tOut[i] = found ? h.t : 0.0f;
     if (uvOut)
@@ -898,7 +904,7 @@ __global__ __launch_bounds__(kBlock) void kIntersectRays(DeviceScene scene, cons
     if (ttOut) ttOut[i] = tc.triangleTests;
 }
 
-__global__ __launch_bounds__(kBlock) void kOccludedRays(DeviceScene scene, const float* rays, uint64_t n, float tMax, float* visOut)
+__global__ __launch_bounds__(kBlock) void kOccludedRays(DeviceScene scene, const float* rays, uint64_t n, float tMax, float* visOut, DeviceCounters* counters)
 {
     __shared__ uint32_t sStack[kLdsStack * kBlock];
     const uint64_t      i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -907,6 +913,7 @@ __global__ __launch_bounds__(kBlock) void kOccludedRays(DeviceScene scene, const
     ClosestHit        h;
     TraversalCounters tc;
     const bool        occluded = traverse<true, false>(scene, vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), tMax, &sStack[threadIdx.x], h, tc);
+    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
     visOut[i] = occluded ? 0.0f : 1.0f;
 }
 
@@ -1170,22 +1177,25 @@ struct Renderer::Impl
             d[i] = make_float4(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], 0.0f);
             ids[i] = static_cast<uint32_t>(i);
         }
-        RF_HIP(hipMemcpy(sRayO.ptr, o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-        RF_HIP(hipMemcpy(sRayD.ptr, d.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-        RF_HIP(hipMemcpy(queueA.ptr, ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        // every copy goes through the handle's stream: ordered behind a batch that may still be in flight there
+        RF_HIP(hipStreamSynchronize(stream));
+        RF_HIP(hipMemcpyAsync(sRayO.ptr, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream));
+        RF_HIP(hipMemcpyAsync(sRayD.ptr, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream));
+        RF_HIP(hipMemcpyAsync(queueA.ptr, ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         const uint32_t words = kLineWords * (1 + kShards);
         if (queueCounts.count < words) queueCounts.alloc(words);
-        RF_HIP(hipMemset(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t)));
+        RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
         const uint32_t count = static_cast<uint32_t>(n);
-        RF_HIP(hipMemcpy(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice));
+        RF_HIP(hipMemcpyAsync(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice, stream));
         PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr};
         const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
         if (shadow)
         {
             // rad = 0, pending = 1: rad.x becomes visibility * SOLAR_INV_PDF
             std::vector<float4> ones(n, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
-            RF_HIP(hipMemcpy(sPending.ptr, ones.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-            RF_HIP(hipMemset(sRad.ptr, 0, n * sizeof(float4)));
+            RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream));
+            RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
+            RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
             if (shadowNearestFirst)
                 hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
@@ -1552,6 +1562,12 @@ float Renderer::renderProgressPercentage() const
 }
 
 uint32_t Renderer::accumulatedSampleCount() const { return mImpl->accumulated; }
+uint32_t Renderer::width() const { return mImpl->params.width; }
+uint32_t Renderer::height() const { return mImpl->params.height; }
+uint32_t Renderer::shardRank() const { return mImpl->rank; }
+uint32_t Renderer::shardWorldSize() const { return mImpl->worldSize; }
+int      Renderer::deviceOrdinal() const { return mImpl->device; }
+void*    Renderer::streamHandle() const { return mImpl->stream; }
 uint32_t Renderer::numBounces() const { return mImpl->params.samplingParams.numBounces; }
 
 void Renderer::synchronize()
@@ -1579,6 +1595,11 @@ void Renderer::bindAccumulationBuffer(void* devicePtr, uint64_t bytes)
 {
     Impl& m = *mImpl;
     synchronize();
+    // The caller's buffer was produced on streams this library does not know (e.g. torch's current stream filling
+    // it with zeros), and the handle's stream is non-blocking: wait for the whole device once, here, so that the
+    // first memset / kAccumulate into the buffer cannot overtake the caller's own writes.  After this call the buffer
+    // belongs to the handle's stream until rf_renderer_synchronize() returns ("Streams").
+    RF_HIP(hipDeviceSynchronize());
     if (devicePtr == nullptr)
     {
         m.image = nullptr;
@@ -1618,6 +1639,21 @@ void Renderer::readTonemapped(uint32_t* dst)
             const uint32_t y = (m.tiles[t] / tilesX) * kTileSize + (block >> 2) * 8u + (lane >> 3);
             if (x < m.params.width && y < m.params.height) dst[static_cast<size_t>(y) * m.params.width + x] = compact[t * 1024 + w];
         }
+}
+
+void Renderer::tonemapDeviceImage(const void* imageDevice, uint64_t numPixels, uint32_t samples, uint32_t* dst)
+{
+    Impl& m = *mImpl;
+    if (numPixels == 0) return;
+    if (numPixels > 0xFFFFFFFFull) throw std::runtime_error("image too large");
+    RF_HIP(hipSetDevice(m.device));
+    const uint32_t         n = static_cast<uint32_t>(numPixels);
+    DeviceBuffer<uint32_t> out;
+    out.alloc(n);
+    hipLaunchKernelGGL(kTonemap, dim3((n + 255) / 256), dim3(256), 0, m.stream, static_cast<const float4*>(imageDevice), n, samples, m.params.exposure, out.ptr);
+    RF_HIP(hipGetLastError());
+    RF_HIP(hipMemcpyAsync(dst, out.ptr, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, m.stream));
+    RF_HIP(hipStreamSynchronize(m.stream));
 }
 
 void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
@@ -1673,6 +1709,8 @@ RenderStats Renderer::stats()
     s.closestRecordFetches = c.closestRecordFetches;
     s.shadowRecordFetches = c.shadowRecordFetches;
     s.paths = c.primaryRays;
+    s.abandonedRays = c.abandonedRays;
+    s.scalarRedoRays = c.scalarRedo[0] + c.scalarRedo[1];
     if (std::getenv("RF_DEBUG_COUNTERS"))
         std::fprintf(stderr, "[rf] rays redone by the scalar traversal: closest %llu of %llu, shadow %llu of %llu\n", c.scalarRedo[0], c.closestRays, c.scalarRedo[1], c.shadowRays);
     if (std::getenv("RF_DEBUG_COUNTERS") && m.counting)
@@ -1714,7 +1752,7 @@ void Renderer::tracePrimaryStats(const Camera& camera, uint32_t width, uint32_t 
     t.alloc(n);
     const uint32_t waves = ((width + 7) / 8) * ((height + 7) / 8);
     hipLaunchKernelGGL(kPrimaryStats, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, m.stream, m.scene, camera, width, height,
-                       nv.ptr, hit.ptr, t.ptr, tt.ptr);
+                       nv.ptr, hit.ptr, t.ptr, tt.ptr, m.counters.ptr);
     RF_HIP(hipGetLastError());
     RF_HIP(hipStreamSynchronize(m.stream));
     RF_HIP(hipMemcpy(nodesVisitedOut, nv.ptr, n * 4, hipMemcpyDeviceToHost));
@@ -1756,7 +1794,7 @@ void Renderer::intersectRays(const float* rays6, uint64_t numRays, float tMax, u
     nv.alloc(numRays);
     tt.alloc(numRays);
     hipLaunchKernelGGL(kIntersectRays, dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
-                       numRays, tMax, tri.ptr, t.ptr, uv.ptr, p.ptr, nv.ptr, tt.ptr);
+                       numRays, tMax, tri.ptr, t.ptr, uv.ptr, p.ptr, nv.ptr, tt.ptr, m.counters.ptr);
     RF_HIP(hipGetLastError());
     RF_HIP(hipStreamSynchronize(m.stream));
     RF_HIP(hipMemcpy(triangleOut, tri.ptr, numRays * 4, hipMemcpyDeviceToHost));
@@ -1783,7 +1821,7 @@ void Renderer::occludedRays(const float* rays6, uint64_t numRays, float tMax, fl
     rays.upload(rays6, 6 * numRays);
     vis.alloc(numRays);
     hipLaunchKernelGGL(kOccludedRays, dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
-                       numRays, tMax, vis.ptr);
+                       numRays, tMax, vis.ptr, m.counters.ptr);
     RF_HIP(hipGetLastError());
     RF_HIP(hipStreamSynchronize(m.stream));
     RF_HIP(hipMemcpy(visibilityOut, vis.ptr, numRays * 4, hipMemcpyDeviceToHost));

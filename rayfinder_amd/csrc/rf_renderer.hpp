@@ -74,6 +74,8 @@ struct RenderStats
     uint64_t paths = 0;
     uint32_t stackHighWater = 0;
     uint64_t closestRecordFetches = 0, shadowRecordFetches = 0; // 64-B BVH records fetched (counting build)
+    uint64_t abandonedRays = 0;  // rays whose traversal stack outgrew 96 entries (reference: undefined past 32); every build
+    uint64_t scalarRedoRays = 0; // rays redone by the reference-ordered scalar traversal (irregular rays, LDS stack overflow); every build
     // hipEvent-timed kernel time (ms) and launch counts, per kernel class, while timing is enabled
     double   msRaygen = 0, msClosest = 0, msShade = 0, msShadow = 0, msAccumulate = 0;
     uint32_t launchesRaygen = 0, launchesClosest = 0, launchesShade = 0, launchesShadow = 0, launchesAccumulate = 0;
@@ -109,6 +111,14 @@ public:
     std::span<const uint32_t> shardTiles() const;
 
     uint32_t accumulatedSampleCount() const;
+    uint32_t width() const;
+    uint32_t height() const;
+    uint32_t shardRank() const;
+    uint32_t shardWorldSize() const;
+    int      deviceOrdinal() const;
+    // The handle's HIP stream (a hipStream_t): work a caller wants ordered behind the frame's kernels (the RCCL
+    // frame exchange, rf_comm.hpp) is enqueued here.
+    void* streamHandle() const;
     // Row-major width*height*4 floats (sum of samples, 16-B stride as the reference's
     // array<vec3f>); pixels outside this rank's tiles are zero.
     void readAccumulation(float* dst);
@@ -119,6 +129,9 @@ public:
     void     bindAccumulationBuffer(void* devicePtr, uint64_t bytes);
     // BGRA8 swap-chain image (wgsl:59-63), row-major.
     void readTonemapped(uint32_t* dstBgra8);
+    // The same display transform for any row-major float4 SUM image in device memory (e.g. the frame a gather
+    // assembled on the root rank): numPixels texels, divided by `samples`, scaled by the handle's exposure.
+    void tonemapDeviceImage(const void* imageDevice, uint64_t numPixels, uint32_t samples, uint32_t* dstBgra8Host);
 
     void        setCounting(bool enabled);
     // Tuning knobs for A/B measurements inside one process ("traversal_variant": 0 = one ray per

@@ -1,13 +1,14 @@
-"""Multi-GPU plumbing: tile shards + one gather at frame end.
+"""Multi-GPU test harness: the tile-shard arithmetic of the frame-end exchange, driven through torch.distributed.
 
-The path shards by image tiles (every pixel's estimate depends only on (x, y, sample index, scene,
-params): reference_path_tracer.wgsl:42-57), the scene is replicated per GPU, and the only exchange
-is a gather of the compact per-rank accumulation buffers to rank 0 -- RCCL over xGMI when the
-process group backend is "nccl", gloo in the CPU tests.  No reduction, no ring.
+The product's exchange is C++ (rf_renderer_gather_frame: RCCL ncclSend/ncclRecv + a device un-tile, rf_comm.hip);
+this module restates its host-visible half -- which tile goes where -- so that the world_size > 1 path can run
+on CPU under gloo (tests/test_distributed_cpu.py).  The path shards by image tiles (every pixel's estimate depends
+only on (x, y, sample index, scene, params): reference_path_tracer.wgsl:42-57), the scene is replicated per GPU,
+and the only exchange is the gather of the compact per-rank accumulation buffers to rank 0.  No reduction, no ring.
 """
 import numpy as np
 
-from . import tiles_for_rank, untile
+from . import gather_layout, tiles_for_rank, untile
 
 
 def shard_layout(width, height, rank, world_size):
@@ -46,3 +47,24 @@ def gather_image(compact, width, height, rank, world_size, group=None):
     """gather_device + assemble.  Returns the image on rank 0, None elsewhere."""
     parts = gather_device(compact, rank, world_size, group)
     return assemble(parts, width, height, world_size) if rank == 0 else None
+
+
+def assemble_with_layout(parts, width, height, world_size):
+    """Rank 0: what rf_comm.hip does on the device -- shards stored rank after rank in a staging area
+    (rf_gather_layout), then one pass per tile of the frame: staging[tile_slot[tile]] -> row-major pixels."""
+    first, slot, owner = gather_layout(width, height, world_size)
+    staging = np.zeros((int(first[-1]) * 1024, 4), np.float32)
+    for r, part in enumerate(parts):
+        n = int(first[r + 1] - first[r])
+        staging[int(first[r]) * 1024:int(first[r + 1]) * 1024] = part.detach().cpu().numpy()[: n * 1024]
+    tiles_x = (width + 31) // 32
+    image = np.zeros((height, width, 4), np.float32)
+    w = np.arange(1024)
+    block, lane = w >> 6, w & 63
+    dx, dy = (block & 3) * 8 + (lane & 7), (block >> 2) * 8 + (lane >> 3)
+    for tile in range(len(slot)):
+        assert first[owner[tile]] <= slot[tile] < first[owner[tile] + 1]
+        x, y = (tile % tiles_x) * 32 + dx, (tile // tiles_x) * 32 + dy
+        ok = (x < width) & (y < height)
+        image[y[ok], x[ok]] = staging[int(slot[tile]) * 1024 + w[ok]]
+    return image

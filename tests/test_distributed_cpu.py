@@ -33,7 +33,7 @@ def _worker(rank, world, port, w, h, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import rayfinder_amd as rf
-    from rayfinder_amd.sharding import gather_image, shard_layout
+    from rayfinder_amd.sharding import assemble, assemble_with_layout, gather_device, shard_layout
     from conftest import DuckOracle
     from oracle import orc
 
@@ -51,9 +51,12 @@ def _worker(rank, world, port, w, h, outdir):
             x = x0 + (block & 3) * 8 + (lane & 7); y = y0 + (block >> 2) * 8 + (lane >> 3)
             if x < w and y < h:
                 compact[t * 1024 + k] = img[y, x]
-    image = gather_image(torch.from_numpy(compact), w, h, rank, world)
+    parts = gather_device(torch.from_numpy(compact), rank, world)
     if rank == 0:
+        image = assemble(parts, w, h, world)
         np.save(os.path.join(outdir, f"gathered_{world}.npy"), image)
+        # the staging layout the C++ RCCL exchange uses (rf_gather_layout / kUntile's mapping)
+        np.save(os.path.join(outdir, f"layout_{world}.npy"), assemble_with_layout(parts, w, h, world))
         if world == 1 or not os.path.exists(os.path.join(outdir, "whole.npy")):
             whole, _ = orc.render(d.scene, rp, 0, spp)
             np.save(os.path.join(outdir, "whole.npy"), whole)
@@ -69,3 +72,18 @@ def test_gloo_tile_gather_reassembles_the_image(world, tmp_path):
     want = np.load(tmp_path / "whole.npy")
     assert got.shape == (h, w, 4)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    via_layout = np.load(tmp_path / f"layout_{world}.npy")
+    assert np.array_equal(via_layout.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,world", [(1920, 1080, 8), (100, 70, 3), (64, 64, 5), (33, 1, 2)])
+def test_gather_layout_is_a_partition_of_the_staging_area(w, h, world):
+    import rayfinder_amd as rf
+    first, slot, owner = rf.gather_layout(w, h, world)
+    n = ((w + 31) // 32) * ((h + 31) // 32)
+    assert first[0] == 0 and first[-1] == n and (np.diff(first.astype(np.int64)) >= 0).all()
+    assert np.array_equal(np.sort(slot), np.arange(n))                     # every staging tile used exactly once
+    for r in range(world):
+        tiles = rf.tiles_for_rank(w, h, r, world)
+        assert (owner[tiles] == r).all()
+        assert np.array_equal(slot[tiles], first[r] + np.arange(len(tiles)))   # a rank's tiles in ascending id = its send order
