@@ -4,27 +4,37 @@
   python bench.py --gpus N --steps K --warmup W            (N = 1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2]/[3]): Sponza stand-in ("synthetic atrium", the real
-assets/Sponza.glb is absent from the reference mount), 1920x1080, 8 bounces, default camera and
-sky.  A STEP is one sample per pixel of the whole frame through the full wavefront pipeline
-(raygen -> [closest-hit traversal -> shade/NEE -> shadow traversal] x 8 -> accumulate); K timed
-steps = K spp.  Inputs (scene, textures, tables) are resident in HBM before the timed region.
-`value` = rays traced (closest-hit + shadow traversals, counted on the device) by all ranks per
-second.  With N > 1 the frame is tile-sharded (strong scaling: total work fixed) and the per-rank
-accumulation buffers are gathered once at frame end with RCCL (inside the timed region).
+Workload (BASELINE.json configs[2]/[3]): Sponza stand-in ("synthetic atrium": the real assets/Sponza.glb is absent
+from the reference mount), 1920x1080, 8 bounces, default camera and sky.
+
+A STEP is SPP_PER_STEP = 16 samples per pixel of the whole frame through the full wavefront pipeline
+(raygen -> [closest-hit traversal -> shade/NEE -> shadow traversal] x 8 -> sky -> accumulate); K timed steps = 16 K spp
+(the default K = 16 is config 3's 256 spp).  Samples are traced in batches of the tuned depth (64 Mi paths = 32 spp
+of a 1080p frame per batch; a rank that owns 1/N of the tiles traces N times as many samples per batch), whatever K
+is.  Inputs (scene, textures, tables) are resident in HBM before the timed region.  `value` = rays traced (closest-hit
++ shadow traversals, counted on the device) by all ranks per second.  With N > 1 the frame is tile-sharded (strong
+scaling: total work fixed) and the per-rank tile buffers are brought to rank 0 once at frame end by the C++ RCCL
+exchange (rf_renderer_gather_frame: grouped ncclSend/ncclRecv + device un-tile), inside the timed region.
 
 The JSON line also carries
-  roofline     traversal-closest kernel: algorithmic bytes per launch (28 B ray in
-               + 16 B hit out + 48 B per node visit + 48 B per triangle test; visits/tests counted
-               by the counting build of the same kernel on the same frames) / its average launch
-               duration, measured with HIP events on the renderer's stream inside the timed region.
-  cpu_baseline the CPU oracle (a port of the reference's algorithm) on a bounded crop of the same
-               frame, on this box's host cores.
+  roofline     the closest-hit traversal kernel against the HBM roofline, in MEASURED bytes: `traffic` = fabric-side
+               bytes per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE (separate --pmc passes of this command,
+               calibrated on known byte counts in the same access pattern: profiles/pmc_per_ray.json, per ray,
+               scaled by the rays one launch traces), `achieved` = traffic / average launch duration (HIP events on
+               the renderer's stream inside the timed region), frac = achieved / 8 TB/s.  SURVEY.md 8(d)'s
+               algorithmic figure (48 B per reference node visit ...) is reported beside it under `algorithmic`
+               and is NOT divided by the HBM peak: the 34 MB of BVH + triangles live in L2 / Infinity Cache, so it is
+               a cache rate.  `l1` is the ceiling that binds: vector-L1 line accesses per second against
+               256 CUs x 1 access/clk x 2.4 GHz.
+  cpu_baseline the CPU oracle (a port of the reference's algorithm) on a bounded crop of the same frame and the
+               reference's bvh-visualizer primary-ray loop, on this box's host cores (1 thread and all of them).
+  parity_crop  the GPU frame of the timed region against the oracle image of that crop.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -32,7 +42,9 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+L1_PEAK_GACC = 256 * 2.4        # 256 CUs x one vector-L1 (TCP) tag access per clock x 2.4 GHz max clock = 614.4 G accesses/s
+SPP_PER_STEP = 16
 
 
 def log(*a):
@@ -49,52 +61,21 @@ def load_scene(path):
     return scenes.atrium()
 
 
-def cpu_baseline(pt, width, height, bounces, seconds_budget=20.0):
-    """Oracle (kind "port") on a centred crop of the same frame; all host cores, row strips."""
-    import threading
-
-    import rayfinder_amd as rf
+def oracle_scene(pt):
     from oracle import orc
     a = pt.arrays()
     descs, off = [], 0
     for (px, w, h) in a["baseColorTextures"]:
         descs.append((w, h, off)); off += px.size
     texels = np.concatenate([px for (px, _, _) in a["baseColorTextures"]])
-    sc = orc.OracleScene(a["bvhNodes"], a["trianglePositionAttributes"], a["triangleVertexAttributes"], np.array(descs, np.uint32), texels)
-    spp = 2
-    rp = orc.make_render_params(width, height, rf.camera_to_array(rf.fly_camera(width, height)), spp, bounces, 0.25,
-                                rf.aligned_sky_state(rf.make_sky()))
-    cores = os.cpu_count() or 1
-    # calibrate on a small crop (1 thread), then size the crop for the budget
-    cw, ch = 64, 36
-    x0, y0 = (width - cw) // 2, (height - ch) // 2
-    t0 = time.time()
-    _, st = orc.render(sc, rp, 0, spp, x0, y0, x0 + cw, y0 + ch)       # warm-up / calibration
-    dt1 = time.time() - t0
-    rays1 = st.closestRays + st.shadowRays
-    # single-thread figure (what the reference's bvh-visualizer / CPU code does): ~3 s sample
-    reps = int(min(max(1, 3.0 / max(dt1, 1e-3)), 64))
-    rp1 = orc.make_render_params(width, height, rf.camera_to_array(rf.fly_camera(width, height)), spp * reps, bounces, 0.25,
-                                 rf.aligned_sky_state(rf.make_sky()))
-    t0 = time.time()
-    _, st = orc.render(sc, rp1, 0, spp * reps, x0, y0, x0 + cw, y0 + ch)
-    single = (st.closestRays + st.shadowRays) / (time.time() - t0)
-    # rays wanted for the budget (parallel efficiency on this many-core host measured at ~10-15 % of
-    # linear: the traversal is memory-latency bound on the CPU too), as crop area first, then spp
-    want = seconds_budget * min(cores, 24) * 0.5 * single
-    f = min(max(1.0, want / max(rays1, 1)) ** 0.5, min(width / cw, height / ch))
-    cw2, ch2 = int(cw * f) // 8 * 8, max(int(ch * f) // 4 * 4, 4)
-    per_spp = rays1 / spp * (cw2 * ch2) / (cw * ch)
-    spp = int(min(max(2, want / max(per_spp, 1)), 64))
-    rp = orc.make_render_params(width, height, rf.camera_to_array(rf.fly_camera(width, height)), spp, bounces, 0.25,
-                                rf.aligned_sky_state(rf.make_sky()))
-    x0, y0 = (width - cw2) // 2, (height - ch2) // 2
-    image = np.zeros((height, width, 4), np.float32)
-    # dynamic scheduling: 4-row strips pulled from a shared counter (rows differ a lot in cost)
-    strips = list(range(y0, y0 + ch2, 4))
+    return orc.OracleScene(a["bvhNodes"], a["trianglePositionAttributes"], a["triangleVertexAttributes"], np.array(descs, np.uint32), texels), a
+
+
+def run_strips(cores, strips, fn):
+    """dynamic scheduling over the host cores: strips pulled from a shared counter (they differ a lot in cost)"""
     lock = threading.Lock()
     nxt = [0]
-    stats = []
+    out = []
 
     def work():
         while True:
@@ -103,39 +84,87 @@ def cpu_baseline(pt, width, height, bounces, seconds_budget=20.0):
                 nxt[0] += 1
             if i >= len(strips):
                 return
-            _, st = orc.render(sc, rp, 0, spp, x0, strips[i], x0 + cw2, min(strips[i] + 4, y0 + ch2), image=image)
+            r = fn(strips[i])
             with lock:
-                stats.append(st)
+                out.append(r)
 
     threads = [threading.Thread(target=work) for _ in range(cores)]
     t0 = time.time()
     [t.start() for t in threads]
     [t.join() for t in threads]
-    dt = time.time() - t0
+    return out, time.time() - t0
+
+
+def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, gpu_image):
+    """Oracle (kind "port") on a centred crop of EXACTLY the frames the timed region traced (same sample indices, same
+    order), all host cores; the crop is also the parity check of the timed frame.  Plus the reference's own CPU
+    loop, bvh-visualizer's primary rays (src/bvh-visualizer/main.cpp:60-78), at 1 thread and at all cores."""
+    import rayfinder_amd as rf
+    from oracle import orc
+    sc, a = oracle_scene(pt)
+    cores = os.cpu_count() or 1
+    cam = rf.camera_to_array(rf.fly_camera(width, height))
+    sky = rf.aligned_sky_state(rf.make_sky())
+    rp = orc.make_render_params(width, height, cam, spp, bounces, 0.25, sky)
+    # calibration: 1 thread, a 32x8 patch in the middle, 2 of the frames
+    cw, ch = 32, 8
+    x0, y0 = (width - cw) // 2, (height - ch) // 2
+    t0 = time.time()
+    _, st = orc.render(sc, rp, first_frame, 2, x0, y0, x0 + cw, y0 + ch)
+    dt1 = max(time.time() - t0, 1e-4)
+    single = (st.closestRays + st.shadowRays) / dt1
+    rays_per_pixel = (st.closestRays + st.shadowRays) / (cw * ch * 2) * spp        # at the full sample count
+    # crop sized for the budget (parallel efficiency of this memory-latency-bound loop on a many-core host: ~50 % of
+    # linear up to 24 threads, little beyond), at least 64x64 (the parity crop), at most the frame
+    want = seconds_budget * min(cores, 24) * 0.5 * single
+    side = int(min(max(64.0, (want / max(rays_per_pixel, 1.0)) ** 0.5), min(width, height)))
+    cw2, ch2 = min(side // 8 * 8, width), min(side // 4 * 4, height)
+    x0, y0 = (width - cw2) // 2, (height - ch2) // 2
+    image = np.zeros((height, width, 4), np.float32)
+    strips = list(range(y0, y0 + ch2, 4))
+    stats, dt = run_strips(cores, strips, lambda y: orc.render(sc, rp, first_frame, spp, x0, y, x0 + cw2, min(y + 4, y0 + ch2), image=image)[1])
     rays = sum(s.closestRays + s.shadowRays for s in stats)
-    return dict(value=round(rays / dt * 1e-6, 3), unit="Mrays/s", cores=cores, kind="port",
-                sample=f"oracle/rf_oracle.c full path tracer, centred {cw2}x{ch2} crop of the {width}x{height} frame, {spp} spp, {bounces} bounces, "
+    # parity of the timed GPU frame on that crop
+    g, c = gpu_image[y0:y0 + ch2, x0:x0 + cw2, :3], image[y0:y0 + ch2, x0:x0 + cw2, :3]
+    same_nan = bool(np.array_equal(np.isnan(g), np.isnan(c)))
+    identical = int(((g.view(np.uint32) == c.view(np.uint32)).all(axis=-1) | np.isnan(c).any(axis=-1)).sum())
+    parity = dict(crop=[x0, y0, cw2, ch2], spp=spp, pixels=cw2 * ch2, bit_identical_pixels=identical, nan_pixels_match=same_nan,
+                  verdict="bit-identical" if identical == cw2 * ch2 and same_nan else "DIFFERENT")
+    # the reference's CPU path: buildBvh is timed in `bvh_build`; here its primary-ray loop at bvh-visualizer's own size
+    vw, vh = 1280, 720
+    vcam = rf.camera_to_array(rf.bvh_visualizer_camera(a["bvhNodes"], np.float32(np.float32(vw) / np.float32(vh))))
+    tris36 = a["bvhPositionAttributes"]
+    t0 = time.time()
+    one = orc.bvh_visualize(a["bvhNodes"], tris36, vcam, vw, vh, vh * 3 // 8, vh * 5 // 8)   # the middle quarter of the rows on one thread
+    viz_single = vw * (vh * 5 // 8 - vh * 3 // 8) / max(time.time() - t0, 1e-6)
+    _, vdt = run_strips(cores, list(range(0, vh, 8)), lambda r0: orc.bvh_visualize(a["bvhNodes"], tris36, vcam, vw, vh, r0, min(r0 + 8, vh)))
+    del one
+    base = dict(value=round(rays / dt * 1e-6, 3), unit="Mrays/s", cores=cores, kind="port",
+                sample=f"oracle/rf_oracle.c full path tracer, centred {cw2}x{ch2} crop of the {width}x{height} frame, {spp} spp (the timed frames), {bounces} bounces, "
                        f"{rays} rays in {dt:.1f} s on {cores} threads (4-row strips, dynamic); 1 thread: {single * 1e-6:.3f} Mrays/s",
-                single_thread_value=round(single * 1e-6, 3))
+                single_thread_value=round(single * 1e-6, 3),
+                bvh_visualizer_primary_rays=dict(unit="Mrays/s", image=f"{vw}x{vh}", one_thread=round(viz_single * 1e-6, 3),
+                                                 all_cores=round(vw * vh / vdt * 1e-6, 3), cores=cores,
+                                                 note="the reference's only CPU traversal loop (src/bvh-visualizer/main.cpp:60-78, single-threaded there), restated in oracle/rf_oracle.c"))
+    return base, parity
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=32)   # one full batch (32 samples of 1080p = 64 Mi paths)
+    ap.add_argument("--steps", type=int, default=16, help="timed steps of 16 spp each (16 = the 256 spp of BASELINE.json config 3)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed steps of 16 spp each (2 = one full batch of 32 spp)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--scene", default=os.environ.get("RF_SCENE", ""), help="Sponza.pt / Sponza.glb; default: synthetic atrium")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--no-counting", action="store_true", help="skip the untimed counting pass (profiling runs): roofline.achieved is null then")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (and with them the parity crop)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-counting", action="store_true", help="skip the untimed counting pass (profiling runs): the algorithmic figures are null then")
     args = ap.parse_args()
 
     import torch
     import rayfinder_amd as rf
-    from rayfinder_amd.sharding import assemble, gather_device, shard_layout
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -146,25 +175,27 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
+    comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # torch.distributed is the launcher's plumbing (rendezvous, barrier, max over ranks); the data path's one
+        # exchange goes through the product's own RCCL communicator, whose id travels over the rendezvous store
+        ids = [rf.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = rf.TileComm(ids[0], rank, world, local_rank)
 
-    W, H, K, WU, B = args.width, args.height, args.steps, args.warmup, args.bounces
+    W, H, K, WU, B = args.width, args.height, max(args.steps, 1), max(args.warmup, 0), args.bounces
+    spp, warm_spp = SPP_PER_STEP * K, SPP_PER_STEP * WU
     t0 = time.time()
     pt, info = load_scene(args.scene)
     log(f"[bench] rank {rank}: scene {info} ready in {time.time() - t0:.1f} s")
 
     cam = rf.fly_camera(W, H)
     sky = rf.make_sky()
-    spp = max(K, 1)
-    params = rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25)
-    r = rf.ReferencePathTracer(params, pt.scene(), device_ordinal=local_rank)
+    r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25), pt.scene(), device_ordinal=local_rank)
     r.set_tile_shard(rank, world)
-    tiles, max_tiles = shard_layout(W, H, rank, world)
-    accum = torch.zeros((max_tiles * 1024, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-    r.bind_accumulation_buffer(accum.data_ptr(), accum.numel() * 4)
 
     def barrier():
         r.synchronize()
@@ -172,25 +203,34 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warm-up: W untimed steps (+ one gather so RCCL is connected); path state for the timed batches is
+    # warm-up: W untimed steps (+ one exchange so that RCCL's connections exist); path state for the timed batches is
     # allocated here, whatever W is, so that the timed region never calls hipMalloc
-    r.set_option("reserve_samples", K)
-    r.render(WU)
+    r.set_option("reserve_samples", spp)
+    if warm_spp:
+        r.render(warm_spp)
+    if comm is not None:
+        r.gather_frame(comm, 0)
     r.synchronize()
-    if dist is not None:
-        gather_device(accum, rank, world)
-    # restart the accumulation (frameCount keeps counting: sample indices are a rotation of 0..K-1)
+    # restart the accumulation (frameCount keeps counting: the timed frames are warm_spp .. warm_spp + spp - 1, i.e. the
+    # sample indices 0..spp-1 rotated by warm_spp)
     r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.5))
     r.set_timing(True)
     r.reset_stats()
 
+    # Timed region: EXACTLY K steps, barrier + device synchronize on both sides.  The clock stops when THIS rank's
+    # stream is idle (after the exchange, which on rank 0 ends with the un-tile of every rank's shard); the barrier
+    # that follows only lines the ranks up again and would add its own latency to every rank's figure, so it sits
+    # after the clock.  The reported time is the max over ranks.
     barrier()
     t0 = time.perf_counter()
-    r.render(K)                       # EXACTLY K steps
+    r.render(spp)
+    if comm is not None:
+        r.gather_frame(comm, 0)
     r.synchronize()
-    parts = gather_device(accum, rank, world)   # frame-end RCCL gather (device to device; no-op at N=1)
-    barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
+
     s = r.stats()
     bs = r.bounce_stats()   # queue occupancy and traversal time per bounce of the timed region (this rank)
     per_bounce = [dict(bounce=i + 1, closest_rays=int(bs["closest_rays"][i]), ms_closest=round(float(bs["ms_closest"][i]), 3),
@@ -202,66 +242,79 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([rays_local, s["closest_rays"], s["shadow_rays"], s["primary_rays"]], dtype=torch.float64, device=f"cuda:{local_rank}")
+        c = torch.tensor([rays_local, s["closest_rays"], s["shadow_rays"], s["primary_rays"], s["abandoned_rays"]], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        rays_total, closest_total, shadow_total, paths_total = (float(x) for x in c.tolist())
+        rays_total, closest_total, shadow_total, paths_total, abandoned_total = (float(x) for x in c.tolist())
     else:
-        rays_total, closest_total, shadow_total, paths_total = float(rays_local), float(s["closest_rays"]), float(s["shadow_rays"]), float(s["primary_rays"])
+        rays_total, closest_total, shadow_total, paths_total, abandoned_total = (float(rays_local), float(s["closest_rays"]), float(s["shadow_rays"]),
+                                                                                 float(s["primary_rays"]), float(s["abandoned_rays"]))
+
+    # the frame of the timed region (read-back outside the timed region for every N)
+    image = None
+    if rank == 0:
+        image = comm.read_frame(r, W, H) if comm is not None else r.read_accumulation()[0]
 
     # counting pass (untimed): node visits / triangle tests of exactly the timed frames on this rank
     cs = None
     if not args.no_counting:
         r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25))
-        # frameCount is now WU + K; the counting pass must see the same sample indices as the timed one
-        # (n = frameCount % spp): the timed pass used frames WU..WU+K-1, this one WU+K..WU+2K-1 == same set mod K
+        # frameCount is now warm_spp + spp: this pass traces frames warm_spp + spp .. warm_spp + 2 spp - 1, the same
+        # sample indices (n = frameCount % spp) as the timed one
         r.set_counting(True)
         r.reset_stats()
-        r.render(K)
+        r.render(spp)
         r.synchronize()
         cs = r.stats()
         r.set_counting(False)
         assert cs["closest_rays"] == s["closest_rays"] and cs["shadow_rays"] == s["shadow_rays"], "counting pass traced different rays"
 
-    # roofline of the dominant kernel (closest-hit traversal), SURVEY.md 8(d) bytes
+    # ---- roofline of the dominant kernel (closest-hit traversal)
     launches = max(s["launches_closest"], 1)
     avg_ms = s["ms_closest"] / launches
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    rays_per_launch = s["closest_rays"] / launches
+    roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=None, kernel="kTraceWide<closest>",
+                    avg_launch_ms=round(avg_ms, 4), launches=launches, rays_per_launch=int(rays_per_launch), compulsory_hbm_bytes_per_ray=44)
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_per_ray.json")
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
-            # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes of the SAME command
-            # (same frame, bounces, steps per launch); launches differ in size, the figure is their average
-            if pmc.get("kernel") == "kTraceWide<closest>" and pmc.get("workload") == f"{W}x{H}x{B}" and pmc.get("launches_per_128_steps") == round(launches * 128 / K):
-                traffic = pmc.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+            # fabric-side bytes per ray of this kernel from the committed rocprofv3 PMC passes of this command on this
+            # workload (same scene, frame, bounces; the figure is per ray, so it does not depend on --steps or on N)
+            if pmc.get("workload") == f"{info['name']} {W}x{H}x{B}":
+                per_ray = float(pmc["hbm_side_bytes_per_ray"])
+                traffic = per_ray * rays_per_launch
+                achieved = traffic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                roofline.update(traffic=int(traffic), achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBPS, 4),
+                                traffic_source=dict(file="profiles/pmc_per_ray.json", profile=pmc.get("profile"), hbm_side_bytes_per_ray=per_ray,
+                                                    fetch_size_bytes_per_ray=pmc.get("fetch_size_bytes_per_ray"), fetch_calibration=pmc.get("fetch_calibration"),
+                                                    write_size_bytes_per_ray=pmc.get("write_size_bytes_per_ray"), write_calibration=pmc.get("write_calibration"),
+                                                    l2_hit_rate=pmc.get("l2_hit_rate")))
+                if pmc.get("l1_accesses_per_ray"):
+                    gacc = float(pmc["l1_accesses_per_ray"]) * rays_per_launch / (avg_ms * 1e-3) / 1e9
+                    roofline["l1"] = dict(accesses_per_ray=pmc["l1_accesses_per_ray"], G_accesses_per_s=round(gacc, 1), peak_G_accesses_per_s=L1_PEAK_GACC,
+                                          frac=round(gacc / L1_PEAK_GACC, 4), counter="TCP_TOTAL_CACHE_ACCESSES_sum")
+        except Exception as e:  # a malformed file must not take the bench line down
+            log(f"[bench] profiles/pmc_per_ray.json ignored: {e}")
     if cs is not None:
         bytes_closest = 28 * cs["closest_rays"] + 16 * cs["closest_rays"] + 48 * (cs["closest_node_visits"] + cs["closest_triangle_tests"])
         bytes_shadow = 28 * cs["shadow_rays"] + 4 * cs["shadow_rays"] + 48 * (cs["shadow_node_visits"] + cs["shadow_triangle_tests"])
-        achieved = bytes_closest / launches / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBPS, 4),
-                        traffic=traffic, kernel="kTraceWide<closest>", avg_launch_ms=round(avg_ms, 4), launches=launches,
-                        algorithmic_bytes_per_launch=int(bytes_closest / launches),
-                        rays_per_launch=int(cs["closest_rays"] / launches),
-                        node_visits_per_ray=round(cs["closest_node_visits"] / max(cs["closest_rays"], 1), 2),
-                        triangle_tests_per_ray=round(cs["closest_triangle_tests"] / max(cs["closest_rays"], 1), 2),
-                        shadow_kernel_GBps=round(bytes_shadow / max(s["ms_shadow"], 1e-9) / 1e6, 1),
-                        # what the kernel itself requests: 64 B per wide record + 48 B per triangle + ray I/O (the wide layout
-                        # needs one record per two reference node visits, so this is below the algorithmic figure)
-                        requested_GBps=round((44 * cs["closest_rays"] + 64 * cs["closest_record_fetches"] + 48 * cs["closest_triangle_tests"])
-                                             / max(s["ms_closest"], 1e-9) / 1e6, 1),
-                        record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2),
-                        # the schema's "bound" is hbm|mfma; what actually limits this kernel (profiles/r01_final):
-                        limiter="L1->VGPR return path (TD busy 86-97 %) and VALU issue (62 %); the BVH is resident in L2 / Infinity Cache, "
-                                "so HBM-side traffic is ~1/8 of the algorithmic bytes and frac > 1")
-    else:
-        roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=traffic, kernel="kTraceWide<closest>",
-                        avg_launch_ms=round(avg_ms, 4), launches=launches)
+        roofline["algorithmic"] = dict(
+            bytes_per_launch=int(bytes_closest / launches), bytes_per_ray=round(bytes_closest / max(cs["closest_rays"], 1), 1),
+            GBps=round(bytes_closest / launches / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+            node_visits_per_ray=round(cs["closest_node_visits"] / max(cs["closest_rays"], 1), 2),
+            triangle_tests_per_ray=round(cs["closest_triangle_tests"] / max(cs["closest_rays"], 1), 2),
+            shadow_kernel_GBps=round(bytes_shadow / max(s["ms_shadow"], 1e-9) / 1e6, 1),
+            # what the kernel itself requests: 56 of the 64 B of a wide record (one record = both children of a reference node,
+            # leaves are never fetched) + 36 B per triangle + ray I/O
+            requested_GBps=round((44 * cs["closest_rays"] + 56 * cs["closest_record_fetches"] + 36 * cs["closest_triangle_tests"]) / max(s["ms_closest"], 1e-9) / 1e6, 1),
+            record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2),
+            note="SURVEY.md 8(d): 28 B ray in + 16 B hit out + 48 B per reference node visit + 48 B per triangle test; a cache rate (the BVH is "
+                 "resident in L2 / Infinity Cache), reported for reference and not divided by the HBM peak")
+    roofline["limiter"] = "vector-L1 (TCP) tag-access rate and VALU issue; HBM-side traffic is a small fraction of the peak because the scene is cache resident"
+
     cfg_label = {(1920, 1080, 8): "BASELINE.json config 3" if world == 1 else "BASELINE.json config 4", (3840, 2160, 16): "BASELINE.json config 5",
                  (800, 600, 4): "BASELINE.json config 2"}.get((W, H, B), "custom configuration")
     if rank == 0:
-        image = assemble(parts, W, H, world)      # read-back + un-tile, outside the timed region for every N
         nan_pixels = int(np.isnan(image[..., :3]).any(axis=-1).sum())
         out = {
             "metric": "Mrays/sec at 1920x1080 Sponza, 8 bounces; achieved HBM GB/s on traversal",
@@ -276,27 +329,33 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{info['name']}, {W}x{H}, {K} spp, {B} bounces, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
+            "config": {"workload": f"{info['name']}{'' if args.scene else ' -- the real Sponza.glb is not in the reference mount'}, {W}x{H}, {B} bounces, "
+                                   f"{SPP_PER_STEP} spp per step x {K} steps = {spp} spp, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
+                       "spp_per_step": SPP_PER_STEP, "spp": spp,
                        "scene_triangles": info.get("triangles"), "scene_textures": info.get("textures"), "scene_digest": info.get("digest"),
-                       "sharding": f"32x32 tiles, scrambled round-robin over {world} rank(s), one RCCL gather at frame end" if world > 1 else "none"},
+                       "sharding": f"32x32 tiles, scrambled round-robin over {world} rank(s), one RCCL gather (grouped ncclSend/ncclRecv + device un-tile) at frame end" if world > 1 else "none"},
+            "timed_region_s": round(elapsed, 4),
             "paths_per_s": round(paths_total / elapsed, 1),
-            "rays": {"closest": int(closest_total), "shadow": int(shadow_total)},
+            "rays": {"closest": int(closest_total), "shadow": int(shadow_total), "abandoned": int(abandoned_total)},
             "kernel_ms_rank0": {k: round(s[k], 3) for k in ("ms_raygen", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")},
             "nan_pixels": nan_pixels,
             "per_bounce_rank0": per_bounce,
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pt, W, H, B, args.cpu_seconds)
+            out["cpu_baseline"], out["parity_crop"] = cpu_baseline(pt, W, H, B, warm_spp, spp, args.cpu_seconds, image)
             # scene bake beside it: the reference's recursive builder as restated on the host (one
-            # thread, what pt-format-tool does) and the GPU builder that emits the same node bytes
+            # thread, what pt-format-tool does) and the GPU builder that emits the same bytes
             tris = pt.arrays()["bvhPositionAttributes"]
-            t0 = time.perf_counter(); host_nodes, _, _ = rf.build_bvh(tris); host_ms = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter(); host_nodes, host_idx, _ = rf.build_bvh(tris); host_ms = (time.perf_counter() - t0) * 1e3
             rf.build_bvh_gpu(tris[:4096])                                       # module load / first-launch cost outside the figure
-            gpu_nodes, _, _, gpu_ms = rf.build_bvh_gpu(tris)
+            gpu_nodes, gpu_idx, _, gpu_ms = rf.build_bvh_gpu(tris)
             out["bvh_build"] = {"triangles": int(len(tris)), "nodes": int(len(host_nodes)), "host_ms_1_thread": round(host_ms, 2),
-                                "gpu_ms": round(float(gpu_ms), 3), "node_bytes_identical": bool(host_nodes.tobytes() == gpu_nodes.tobytes())}
+                                "gpu_ms": round(float(gpu_ms), 3), "node_bytes_identical": bool(host_nodes.tobytes() == gpu_nodes.tobytes()),
+                                "triangle_order_identical": bool(np.array_equal(host_idx, gpu_idx))}
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     r.close()
     if dist is not None:
         dist.barrier()

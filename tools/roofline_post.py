@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""tools/roofline_post.py <dir>  -- turns the summaries tools/roofline_pmc.sh wrote into
+     <dir>/calibration.json   counter / known-bytes ratios of the microbenchmark, per access pattern
+     <dir>/pmc_per_ray.json   fabric-side bytes and vector-L1 accesses per ray of the closest-hit traversal kernel
+(the latter is what bench.py reads from profiles/pmc_per_ray.json).  Pure text processing; runs anywhere."""
+import json
+import os
+import re
+import sys
+
+out = sys.argv[1]
+
+
+def summary(path):
+    """-> {kernel: {counter: per-dispatch average, "_dispatches": n}}"""
+    res = {}
+    if not os.path.exists(path):
+        return res
+    for line in open(path):
+        m = re.match(r"(\S.*?)\s+dispatches=\s*(\d+)\s+(.*)", line)
+        if not m:
+            continue
+        k = m.group(1).strip()
+        d = {"_dispatches": int(m.group(2))}
+        for c, tot, per in re.findall(r"(\w+)=(\S+) \(per dispatch ([0-9.eE+-]+)\)", m.group(3)):
+            d[c] = float(per)
+        res[k] = d
+    return res
+
+
+def merged(prefix, count):
+    res = {}
+    for i in range(1, count + 1):
+        for k, d in summary(os.path.join(out, f"{prefix}{i}_summary.txt")).items():
+            res.setdefault(k, {}).update(d)
+    return res
+
+
+# ---------------------------------------------------------------- calibration
+plain = {}
+for line in open(os.path.join(out, "calib_plain.jsonl")):
+    line = line.strip()
+    if not line.startswith("{"):
+        continue
+    j = json.loads(line)
+    key = j["kernel"]
+    if j.get("rep", 1) == 0:
+        continue          # first pass of the read kernels = cold; the counters below average both, so keep rep 1 as the time
+    plain[key] = j
+cal = merged("calib_pmc", 6)
+calibration = {}
+for k, j in plain.items():
+    c = cal.get(k, {})
+    known = j.get("bytes", j.get("bytes_lines", j.get("bytes_requested")))
+    row = dict(known_bytes=known, ms=j["ms"], rate=j.get("GBps", j.get("Grecords_per_s")))
+    if "FETCH_SIZE" in c:
+        row["FETCH_SIZE_bytes"] = c["FETCH_SIZE"] * 1024.0
+        row["fetch_ratio"] = row["FETCH_SIZE_bytes"] / known
+    if "WRITE_SIZE" in c:
+        row["WRITE_SIZE_bytes"] = c["WRITE_SIZE"] * 1024.0
+        row["write_ratio"] = row["WRITE_SIZE_bytes"] / known
+    if "records" in j and "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+        row["l1_accesses_per_record"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / j["records"]
+        row["l1_to_l2_read_requests_per_record"] = c.get("TCP_TCC_READ_REQ_sum", 0.0) / j["records"]
+    if "TCC_HIT_sum" in c:
+        row["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
+    for name in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"):
+        if name in c:
+            row[name] = c[name]
+    calibration[k] = row
+
+
+def ratio(kernel, field):
+    return calibration.get(kernel, {}).get(field)
+
+
+# The factors applied to the traversal kernel's counters:
+#   reads : the record gather over a table far larger than L2 + Infinity Cache -- every record is one distinct 64-B line
+#           that must come through the fabric, so known bytes = records x 64 and factor = known / FETCH_SIZE
+#   writes: coalesced full-line stores of a table far larger than the caches: factor = bytes / WRITE_SIZE
+fr = ratio("gather56<33>", "fetch_ratio")
+wr = ratio("fill16<33>", "write_ratio")
+factors = dict(fetch_calibration=(1.0 / fr) if fr else None, write_calibration=(1.0 / wr) if wr else None,
+               fetch_pattern="gather56<33>: 56 of 64 B of a random 64-B record per lane, 8 GiB table (all from HBM): known = records x 64 B",
+               write_pattern="fill16<33>: coalesced 16 B/lane stores of 8 GiB: known = bytes written",
+               streaming_read_ratio=ratio("stream16<33>", "fetch_ratio"),
+               note="ratio = counter bytes / known bytes; MI355X_MICROARCH.md predicts 0.5 for wide coalesced streaming reads on gfx950")
+json.dump(dict(factors=factors, kernels=calibration), open(os.path.join(out, "calibration.json"), "w"), indent=1)
+print(json.dumps(factors, indent=1))
+
+# ---------------------------------------------------------------- the bench command
+bench = json.loads(open(os.path.join(out, "bench_under_trace.json")).read().strip().splitlines()[-1])
+pm = merged("pmc", 7)
+K = "kTraceWide<false, false, false>"
+k = pm.get(K)
+if not k:
+    raise SystemExit(f"{K} not found in the PMC summaries: {list(pm)}")
+rays = bench["roofline"]["rays_per_launch"]
+W, H = re.search(r"(\d+)x(\d+)", bench["config"]["workload"]).groups()
+B = re.search(r"(\d+) bounces", bench["config"]["workload"]).group(1)
+name = bench["config"]["workload"].split(" -- ")[0].split(", ")[0]
+fetch = k["FETCH_SIZE"] * 1024.0 / rays
+write = k["WRITE_SIZE"] * 1024.0 / rays
+fc = factors["fetch_calibration"] or 1.0
+wc = factors["write_calibration"] or 1.0
+per_ray = dict(
+    profile=os.path.basename(os.path.abspath(out)), kernel="kTraceWide<closest>", workload=f"{name} {W}x{H}x{B}",
+    rays_per_launch=rays, dispatches_averaged=k["_dispatches"],
+    fetch_size_bytes_per_ray=round(fetch, 2), write_size_bytes_per_ray=round(write, 2),
+    fetch_calibration=round(fc, 4), write_calibration=round(wc, 4),
+    hbm_side_bytes_per_ray=round(fc * fetch + wc * write, 2),
+    l1_accesses_per_ray=round(k.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / rays, 2),
+    l1_to_l2_read_requests_per_ray=round(k.get("TCP_TCC_READ_REQ_sum", 0.0) / rays, 2),
+    l2_hit_rate=round(k["TCC_HIT_sum"] / max(k["TCC_HIT_sum"] + k["TCC_MISS_sum"], 1.0), 4) if "TCC_HIT_sum" in k else None,
+    valu_lane_utilisation=round(k["SQ_THREAD_CYCLES_VALU"] / max(k.get("SQ_ACTIVE_INST_VALU", 0.0) * 64, 1.0), 4) if "SQ_THREAD_CYCLES_VALU" in k and "SQ_ACTIVE_INST_VALU" in k else None,
+    gpu_cycles_per_launch=k.get("GRBM_GUI_ACTIVE"),
+    avg_launch_ms_under_trace=bench["roofline"]["avg_launch_ms"],
+    source="rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-counting` (tools/roofline_pmc.sh), one counter group per run, averaged over every launch of "
+           "the kernel and divided by the rays one launch traces; FETCH_SIZE / WRITE_SIZE (KB) x 1024 x the calibration factors of calibration.json; fabric-side "
+           "requests of the 8 L2s (Infinity-Cache hits included)")
+json.dump(per_ray, open(os.path.join(out, "pmc_per_ray.json"), "w"), indent=1)
+print(json.dumps(per_ray, indent=1))
