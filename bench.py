@@ -110,7 +110,7 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     cw, ch = 32, 8
     x0, y0 = (width - cw) // 2, (height - ch) // 2
     t0 = time.time()
-    _, st = orc.render(sc, rp, first_frame, 2, x0, y0, x0 + cw, y0 + ch)
+    _, st = orc.render(sc, rp, first_frame, 2, x0, y0, x0 + cw, y0 + ch, accumulated_start=0)
     dt1 = max(time.time() - t0, 1e-4)
     single = (st.closestRays + st.shadowRays) / dt1
     rays_per_pixel = (st.closestRays + st.shadowRays) / (cw * ch * 2) * spp        # at the full sample count
@@ -122,7 +122,7 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     x0, y0 = (width - cw2) // 2, (height - ch2) // 2
     image = np.zeros((height, width, 4), np.float32)
     strips = list(range(y0, y0 + ch2, 4))
-    stats, dt = run_strips(cores, strips, lambda y: orc.render(sc, rp, first_frame, spp, x0, y, x0 + cw2, min(y + 4, y0 + ch2), image=image)[1])
+    stats, dt = run_strips(cores, strips, lambda y: orc.render(sc, rp, first_frame, spp, x0, y, x0 + cw2, min(y + 4, y0 + ch2), image=image, accumulated_start=0)[1])
     rays = sum(s.closestRays + s.shadowRays for s in stats)
     # parity of the timed GPU frame on that crop
     g, c = gpu_image[y0:y0 + ch2, x0:x0 + cw2, :3], image[y0:y0 + ch2, x0:x0 + cw2, :3]

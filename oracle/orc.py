@@ -83,6 +83,7 @@ def lib():
         _lib.orc_wgsl_camera_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _lib.orc_pixel_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.orc_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
+        _lib.orc_render_from.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p]
         _lib.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
         _lib.orc_pixar_onb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_direction_in_cone.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
@@ -298,14 +299,17 @@ def make_render_params(width, height, cam19, spp, bounces, exposure, sky40):
     return rp
 
 
-def render(scene, rp, first_frame, num_frames, x0=0, y0=0, x1=None, y1=None, image=None):
+def render(scene, rp, first_frame, num_frames, x0=0, y0=0, x1=None, y1=None, image=None, accumulated_start=None):
+    """num_frames render() calls from frameCount = first_frame.  accumulated_start: the accumulated sample count at that
+    point (None: a fresh renderer, == first_frame); 0 after a setRenderParameters() change (reference_path_tracer.cpp:556-563)."""
     lib()
     x1 = rp.width if x1 is None else x1
     y1 = rp.height if y1 is None else y1
     if image is None:
         image = np.zeros((rp.height, rp.width, 4), np.float32)
     st = Stats()
-    lib().orc_render(C.byref(scene.c), C.byref(rp), first_frame, num_frames, x0, y0, x1, y1, _p(image), C.byref(st))
+    lib().orc_render_from(C.byref(scene.c), C.byref(rp), first_frame, first_frame if accumulated_start is None else accumulated_start, num_frames,
+                          x0, y0, x1, y1, _p(image), C.byref(st))
     return image, st
 
 

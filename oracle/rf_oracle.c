@@ -996,14 +996,18 @@ ORC_API void orc_pixel_sample(const OrcScene* sc, const OrcRenderParams* rp, uin
  * renderer: `numFrames` calls of render(); frame f uses frameCount = firstFrame + f and
  * accumulatedSampleCount = min(firstFrame + f, spp).  image = W*H*4 floats (array<vec3f>, 16-B
  * stride, wgsl:32); only pixels in [x0,x1) x [y0,y1) are touched. */
-ORC_API void orc_render(const OrcScene* sc, const OrcRenderParams* rp, uint32_t firstFrame, uint32_t numFrames,
-                        uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float* image, OrcStats* st)
+/* Host-side state stepping of reference_path_tracer.cpp:556-595: frameCount only ever grows, the accumulated sample
+ * count restarts at 0 whenever setRenderParameters() sees a change.  orc_render_from() steps numFrames render() calls
+ * from (frameCount = firstFrame, accumulatedSampleCount = accumulatedStart); a fresh renderer has both equal. */
+ORC_API void orc_render_from(const OrcScene* sc, const OrcRenderParams* rp, uint32_t firstFrame, uint32_t accumulatedStart, uint32_t numFrames,
+                             uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float* image, OrcStats* st)
 {
     OrcStats local; memset(&local, 0, sizeof local);
     if (!st) st = &local;
     for (uint32_t f = 0; f < numFrames; ++f) {
         const uint32_t frameCount = firstFrame + f;
-        const uint32_t acc = frameCount < rp->numSamplesPerPixel ? frameCount : rp->numSamplesPerPixel;
+        const uint32_t accNow = accumulatedStart + f;
+        const uint32_t acc = accNow < rp->numSamplesPerPixel ? accNow : rp->numSamplesPerPixel;
         for (uint32_t y = y0; y < y1; ++y) {
             for (uint32_t x = x0; x < x1; ++x) {
                 float* px = image + 4 * ((size_t)y * rp->width + x);
@@ -1021,6 +1025,12 @@ ORC_API void orc_render(const OrcScene* sc, const OrcRenderParams* rp, uint32_t 
             const float* px = image + 4 * ((size_t)y * rp->width + x);
             if (px[0] != px[0] || px[1] != px[1] || px[2] != px[2]) st->nanPixels++;
         }
+}
+
+ORC_API void orc_render(const OrcScene* sc, const OrcRenderParams* rp, uint32_t firstFrame, uint32_t numFrames,
+                        uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float* image, OrcStats* st)
+{
+    orc_render_from(sc, rp, firstFrame, firstFrame, numFrames, x0, y0, x1, y1, image, st);
 }
 
 /* fsMain tonemap tail, wgsl:59-63 + acesFilmic :277-285.  Returns BGRA8 packed like the swap

@@ -711,3 +711,75 @@ def test_rccl_frame_exchange_world_size_one(duck_pt):
     assert np.array_equal(bgra, r.read_tonemapped())
     comm.close()
     r.close()
+
+
+# ------------------------------------------------------------------ round 2: the analytic scenes on the GPU
+def _pt_from_rects(rects):
+    import analytic_scene as an
+    P, N, T, I, tex = an.scene_arrays(rects)
+    return rf.PtFormat.from_triangles(P, N, T, I, tex)
+
+
+def test_analytic_corner_scene_gpu_vs_independent_integrator_and_oracle():
+    """The two-walls-and-a-floor scene of tests/test_oracle_pins.py: the GPU's f32 sum image equals the oracle's bit for
+    bit, and single samples agree with the independent float64 integrator (tests/analytic_scene.py) where its
+    decisions are robust -- multi-bounce throughput order, NEE before the last-bounce break, unclamped cosine."""
+    import analytic_scene as an
+    from test_oracle_pins import corner_rects
+    rects = corner_rects()
+    pt = _pt_from_rects(rects)
+    sc, _ = oracle_scene_from_pt(pt)
+    W = H = 24
+    cam = rf.create_camera((-1.5, 2.0, 2.0), (0.3, 0.0, -0.3), 0.0, 1.0, float(orc.degrees_to_radians(50.0)), 1.0)
+    sky = rf.make_sky(1.0, (1.0, 1.0, 1.0), 30.0, 35.0)
+    sky40 = rf.aligned_sky_state(sky)
+    for bounces in (1, 2, 3):
+        # one sample per pixel and spp = 1: the accumulation image IS the sample (n = frame % 1 = 0)
+        r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, 1, bounces, sky, 1.0), pt.scene())
+        r.render(1)
+        img, _ = r.read_accumulation()
+        r.close()
+        ref, _ = orc.render(sc, orc.make_render_params(W, H, rf.camera_to_array(cam), 1, bounces, 1.0, sky40), 0, 1)
+        assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
+        checked = 0
+        for y in range(H):
+            for x in range(W):
+                u = orc.animated_blue_noise(x, y, 0, 1).astype(np.float64)
+                want, robust, _ = an.path_sample(rects, rf.camera_to_array(cam), sky40, W, H, x, y, u, bounces)
+                if robust:
+                    checked += 1
+                    assert np.allclose(img[y, x, :3].astype(np.float64), want, rtol=3e-4, atol=2e-5 * max(1.0, float(np.abs(want).max()))), (x, y, bounces)
+        assert checked > 0.8 * W * H
+
+
+def test_sealed_room_is_exactly_black_on_the_gpu():
+    """Closed white room, camera inside: every sun sample occluded, no path reaches the sky -> every pixel exactly 0
+    after 6 bounces x 8 spp; any traversal leak (missed far child, wrong offset side, dropped stack entry) would light one."""
+    from test_oracle_pins import box_rects
+    pt = _pt_from_rects(box_rects(True))
+    W, H, spp, bounces = 96, 64, 8, 6
+    cam = rf.create_camera((0.2, -0.3, 0.4), (0.9, 0.2, -0.8), 0.0, 1.0, float(orc.degrees_to_radians(80.0)), W / H)
+    r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, bounces, rf.make_sky(), 1.0), pt.scene())
+    r.render(spp)
+    img, _ = r.read_accumulation()
+    s = r.stats()
+    r.close()
+    assert not img[..., :3].any()
+    assert s["closest_rays"] == W * H * spp * bounces == s["shadow_rays"]
+
+
+def test_accumulation_restart_keeps_frame_count(duck_pt, duck_oracle):
+    """setRenderParameters() with a change restarts the accumulation but frameCount keeps counting
+    (reference_path_tracer.cpp:556-563,577-591): the restarted image holds samples n = frameCount % spp in a rotated
+    order -- what bench.py's timed region is, and what its parity crop compares with."""
+    W, H, spp, bounces = 96, 64, 6, 3
+    r, params = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(4)                                                   # frames 0..3
+    r.set_render_parameters(rf.make_render_parameters(W, H, params.camera, spp, bounces, params.sky, 0.5))
+    r.render(spp + 2)                                             # frames 4..9 accumulate, 10..11 only advance frameCount
+    img, acc = r.read_accumulation()
+    assert acc == spp
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.5, rf.aligned_sky_state(params.sky))
+    ref, _ = orc.render(duck_oracle.scene, rp, 4, spp + 2, accumulated_start=0)
+    assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
+    r.close()

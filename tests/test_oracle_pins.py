@@ -352,3 +352,107 @@ def test_aces_tonemap_known_answers():
     assert out[2][2] == 1.0                                   # saturates
     # exposure and sample count enter as exposure * sum / n
     assert np.array_equal(orc.tonemap(img * 8, 4, 0.5), orc.tonemap(img, 1, 1.0))
+
+
+# ---------------------------------------------------------------- multi-bounce known answers (round 2)
+# Nothing in the reference tests rayColor (wgsl:180-234).  tests/analytic_scene.py is a second, independent
+# restatement (float64, analytic rectangles, no BVH / Moller-Trumbore, no code shared with the oracle); the two
+# must agree wherever the analytic one's decisions are robust.
+def _oracle_scene_from_rects(rects):
+    import analytic_scene as an
+    P, N, T, I, tex = an.scene_arrays(rects)
+    nodes, idx, _ = orc.build_bvh(P)
+    Pr, Nr, Tr, Ir = orc.reorder(P, idx), orc.reorder(N, idx), orc.reorder(T, idx), orc.reorder(I, idx)
+    n = len(Pr)
+    pos48 = np.zeros((n, 12), np.float32); pos48[:, 0:3] = Pr[:, 0:3]; pos48[:, 4:7] = Pr[:, 3:6]; pos48[:, 8:11] = Pr[:, 6:9]
+    att = np.zeros((n, 20), np.float32)
+    att[:, 0:3] = Nr[:, 0:3]; att[:, 4:7] = Nr[:, 3:6]; att[:, 8:11] = Nr[:, 6:9]; att[:, 12:18] = Tr
+    att.view(np.uint32)[:, 18] = Ir
+    descs = np.array([[1, 1, k] for k in range(len(tex))], np.uint32)
+    texels = np.concatenate([px for px, _, _ in tex])
+    return orc.OracleScene(nodes, pos48, att, descs, texels)
+
+
+def corner_rects():
+    """Floor + two walls.  The x = 1 wall is wound AWAY from the scene (geometric normal +x) while its shading normal
+    faces the scene (-x): hit points on it are pushed behind it (wgsl:514-516), so its sun sample is unoccluded with a
+    NEGATIVE cosine -- the unclamped NEE term of wgsl:201."""
+    import analytic_scene as an
+    return [an.Rect(1, 0.0, (-3, -3), (3, 3), (0, 1, 0), +1, (200, 120, 60)),
+            an.Rect(0, 1.0, (0, -3), (1.5, 3), (-1, 0, 0), +1, (90, 200, 160)),
+            an.Rect(2, -1.2, (-3, 0), (1, 2.0), (0, 0, 1), +1, (230, 230, 230))]
+
+
+@pytest.mark.parametrize("bounces", [1, 2, 3])
+def test_multi_bounce_paths_match_an_independent_analytic_integrator(bounces):
+    import analytic_scene as an
+    rects = corner_rects()
+    sc = _oracle_scene_from_rects(rects)
+    W = H = 24
+    cam = orc.create_camera([-1.5, 2.0, 2.0], [0.3, 0.0, -0.3], 0.0, 1.0, orc.degrees_to_radians(50.0), 1.0)
+    sky = orc.aligned_sky_state(azimuth_deg=35.0)      # sun (0.41, 0.87, -0.29): grazes none of the three planes
+    spp = 4
+    rp = orc.make_render_params(W, H, cam, spp, bounces, 1.0, sky)
+    kinds, checked = set(), 0
+    for frame in range(spp):
+        for y in range(H):
+            for x in range(W):
+                u = orc.animated_blue_noise(x, y, frame, spp).astype(np.float64)
+                want, robust, trace = an.path_sample(rects, cam, sky, W, H, x, y, u, bounces)
+                if not robust:
+                    continue
+                got, st = orc.pixel_sample(sc, rp, x, y, frame)
+                scale = max(1.0, float(np.abs(want).max()))
+                assert np.allclose(got.astype(np.float64), want, rtol=3e-4, atol=2e-5 * scale), (x, y, frame, got, want, trace)
+                checked += 1
+                assert st.closestRays == len(trace) and st.shadowRays == sum(1 for t in trace if t[0] == "hit")
+                for t in trace:
+                    kinds.add(("sky", t[1]) if t[0] == "sky" else ("hit", t[1], t[3] > 0, t[4] < 0))
+    assert checked > 0.8 * W * H * spp
+    assert ("hit", 1, True, False) in kinds                     # lit first vertex
+    if bounces >= 2:
+        assert ("sky", 2) in kinds                              # escaped after one bounce: throughput = albedo of vertex 1
+        assert any(k[0] == "hit" and k[1] == 2 for k in kinds)  # NEE at the second vertex, added before the `bounce == numBounces` break
+        assert any(k[0] == "hit" and k[2] and k[3] for k in kinds)      # unoccluded sun sample with a negative cosine (no clamp)
+        assert any(k[0] == "hit" and not k[2] for k in kinds)   # a shadowed vertex
+    if bounces >= 3:
+        assert ("sky", 3) in kinds and any(k[0] == "hit" and k[1] == 3 for k in kinds)
+
+
+def box_rects(sealed, srgb=(255, 255, 255)):
+    """A room [-1, 1]^3 seen from inside; faces overlap at the edges (each spans [-1.5, 1.5]) so that no ray can slip
+    between two faces; normals (geometric and shading) point inwards."""
+    import analytic_scene as an
+    faces = []
+    for axis in range(3):
+        for side in (-1, 1):
+            if axis == 1 and side == 1 and not sealed:
+                continue                                        # open to the sky
+            n = [0, 0, 0]; n[axis] = -side
+            faces.append(an.Rect(axis, float(side), (-1.5, -1.5), (1.5, 1.5), n, -side, srgb))
+    return faces
+
+
+def test_sealed_white_room_is_black_and_open_room_respects_the_energy_bound():
+    """Closed scene: every sun sample is occluded and no path reaches the sky, so the estimate is EXACTLY zero
+    whatever the albedo and bounce count -- any leak (self-intersection, a missed far child, a wrong offset side)
+    shows up as a non-zero pixel.  Open top, albedo rho: every sample lies within
+    +- sum_b rho^b * solar * invPdf / pi  +  rho^k * max sky radiance (wgsl:203,228 with |n.l| <= 1)."""
+    W = H = 32
+    cam = orc.create_camera([0.2, -0.3, 0.4], [0.9, 0.2, -0.8], 0.0, 1.0, orc.degrees_to_radians(80.0), 1.0)
+    sky = orc.aligned_sky_state()
+    sc = _oracle_scene_from_rects(box_rects(True))
+    img, st = orc.render(sc, orc.make_render_params(W, H, cam, 4, 6, 1.0, sky), 0, 4)
+    assert st.closestRays == W * H * 4 * 6 and st.shadowRays == st.closestRays     # every ray hit a wall, every bounce
+    assert not img[..., :3].any()
+    srgb = (186, 186, 186)
+    rho = (186 / 255.0) ** 2.2
+    sc = _oracle_scene_from_rects(box_rects(False, srgb))
+    bounces, spp = 5, 8
+    img, st = orc.render(sc, orc.make_render_params(W, H, cam, spp, bounces, 1.0, sky), 0, spp)
+    solar, inv_pdf = sky[30:33].astype(np.float64), 6.216817e-05
+    import analytic_scene as an
+    max_sky = max(an.sky_radiance(sky, t, g).max() for t in np.linspace(0, np.pi / 2, 40) for g in np.linspace(0, np.pi, 40))
+    bound = spp * (sum(rho ** b for b in range(1, bounces + 1)) * solar.max() * inv_pdf / np.pi + max_sky)
+    assert np.isfinite(img).all() and np.abs(img[..., :3]).max() <= bound
+    assert img[..., :3].max() > 0 and st.shadowRays < st.closestRays              # light does get in, some paths leave

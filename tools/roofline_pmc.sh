@@ -8,6 +8,7 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$REPO/gpurun_out/roofline}
+case $OUT in /*) ;; *) OUT=$PWD/$OUT ;; esac     # the passes run from /tmp
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-4}; WARMUP=${WARMUP:-2}
