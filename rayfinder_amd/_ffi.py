@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librayfinder_amd.so")
+# RAYFINDER_AMD_LIB: an experiment build of the same library (make EXP=... LIBNAME=...), for A/B measurements
+LIB_PATH = os.environ.get("RAYFINDER_AMD_LIB") or os.path.join(_HERE, "librayfinder_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -283,14 +283,13 @@ __device__ __forceinline__ Vec3 basisTimes(Vec3 c0, Vec3 c1, Vec3 c2, Vec3 v)
     return (v.x * c0 + v.y * c1) + v.z * c2;
 }
 
-// wgsl:247-275 (sky dome only; the solar disk is reached through next-event estimation)
-__device__ __forceinline__ float skyRadiance(const SkyStateGpu& sky, float theta, float gamma, int channel)
+// wgsl:247-275 (sky dome only; the solar disk is reached through next-event estimation).  cosTheta = |cos(theta)| and
+// cosGamma = cos(gamma) are the same for the three channels: the caller evaluates them once (identical values).
+__device__ __forceinline__ float skyRadiance(const SkyStateGpu& sky, float cosTheta, float gamma, float cosGamma, int channel)
 {
     const float  r = sky.skyRadiances[channel];
     const float* p = sky.params + 9 * channel;
-    const float  cosGamma = wCos(gamma);
     const float  cosGamma2 = cosGamma * cosGamma;
-    const float  cosTheta = fabsf(wCos(theta));
     const float  expM = wExp(p[4] * gamma);
     const float  mieLhs = 1.0f + cosGamma2;
     const float  mieRhs = wPow(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma, 1.5f);

@@ -77,6 +77,24 @@ __device__ __forceinline__ Vec3 load3(const float4* p)
     return vec3(v.x, v.y, v.z);
 }
 
+// Path state touched once per ray by the traversal kernels (queue entry, origin, direction, result): with
+// RF_EXP_NT these accesses carry the non-temporal hint so that they do not displace BVH lines from L1 / L2
+// (A/B experiment).
+typedef float v4f __attribute__((ext_vector_type(4)));
+#if defined(RF_EXP_NT)
+__device__ __forceinline__ Vec3 load3s(const float4* p)
+{
+    const v3f v = __builtin_nontemporal_load(reinterpret_cast<const v3f*>(p));
+    return vec3(v.x, v.y, v.z);
+}
+__device__ __forceinline__ uint32_t loadQ(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void     store4s(float4* p, float x, float y, float z, float w) { __builtin_nontemporal_store(v4f{x, y, z, w}, reinterpret_cast<v4f*>(p)); }
+#else
+__device__ __forceinline__ Vec3     load3s(const float4* p) { return load3(p); }
+__device__ __forceinline__ uint32_t loadQ(const uint32_t* p) { return *p; }
+__device__ __forceinline__ void     store4s(float4* p, float x, float y, float z, float w) { *p = make_float4(x, y, z, w); }
+#endif
+
 struct DeviceCounters
 {
     unsigned long long primaryRays, closestRays, shadowRays;
@@ -169,7 +187,11 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
     bool                keep[kItems];
     uint32_t            slots[kItems];
     uint32_t            numValid = 0;
+#if defined(RF_EXP_RAYGEN_UNROLL)
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int k = 0; k < kItems; ++k)
     {
         const uint32_t slot = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
@@ -196,10 +218,10 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
             const Vec3  origin = fp.camera.origin + (lensX * fp.camera.right + lensY * fp.camera.up);
             const Vec3  dir = normalize(fp.camera.lowerLeftCorner + s * fp.camera.horizontal + t * fp.camera.vertical - origin);
 
+            // throughput = 1 and radiance = 0 (wgsl:183-184) are not stored: bounce 1 knows them (kFlagFirstBounce, the
+            // first-bounce bit of a miss-list entry), which saves 32 of the 80 bytes a path costs here and the reads back
             ps.rayO[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
             ps.rayD[slot] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-            ps.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            ps.rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             ps.noise[slot] = make_float4(nx, cosPhi, sinPhi, 0.0f);
             ++numValid;
         }
@@ -274,9 +296,11 @@ __device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, const SunBasis
     return basisTimes(basis.u, basis.v, sun, local);
 }
 
+constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
+
 __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                   const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
-                                                  uint32_t* missCount, uint32_t isLastBounce)
+                                                  uint32_t* missCount, uint32_t bounceFlags)
 {
     __shared__ uint32_t sScratch[8];
     __shared__ float    sLut[256];
@@ -285,17 +309,19 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
     static_assert(kBlock == 256, "one table entry per thread");
     sLut[threadIdx.x] = scene.albedoLut[threadIdx.x];
     __syncthreads();
-    bool     isHit[kItems], isMiss[kItems];
-    uint32_t slots[kItems];
+    const bool isLastBounce = (bounceFlags & kShadeLastBounce) != 0u, isFirstBounce = (bounceFlags & kShadeFirstBounce) != 0u;
+    bool       isHit[kItems], isMiss[kItems];
+    uint32_t   slots[kItems], missEntries[kItems];
 #pragma unroll 1
     for (int k = 0; k < kItems; ++k)
     {
         const uint32_t i = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
         isHit[k] = isMiss[k] = false;
-        slots[k] = 0;
+        slots[k] = missEntries[k] = 0;
         if (i >= count) continue;
         const uint32_t slot = queue[i];
         slots[k] = slot;
+        missEntries[k] = isFirstBounce ? (slot | 0x80000000u) : slot;
         const float4   h = ps.hit[slot];
         const uint32_t tri = __float_as_uint(h.x);
         if (tri == kMiss)
@@ -310,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             const Vec3 hp = hitPoint(scene, tri, h.y, h.z);
             ps.rayO[slot] = make_float4(hp.x, hp.y, hp.z, 0.0f);
         }
-        const Vec3  throughput = load3(ps.thr + slot);
+        const Vec3  throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + slot); // wgsl:184
         const Vec3  nz = load3(ps.noise + slot);
         const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
         // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
@@ -345,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         }
     }
     blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch);
-    blockAppend<kItems>(isMiss, slots, missQueue, missCount, sScratch);
+    blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
 }
 
 // Paths that left the scene (at any bounce of this batch): radiance += throughput * sky
@@ -356,22 +382,25 @@ __global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, 
 {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= *missCount) return;
-    const uint32_t slot = missQueue[i];
-    const float4   d4 = ps.rayD[slot];
-    const float4   thr4 = ps.thr[slot];
-    const Vec3     v = vec3(d4.x, d4.y, d4.z);
+    const uint32_t entry = missQueue[i];
+    const uint32_t slot = entry & 0x7FFFFFFFu;
+    const bool     first = (entry >> 31) != 0u; // left the scene at bounce 1: throughput 1, radiance 0, neither in memory
+    const Vec3     v = load3(ps.rayD + slot);
+    const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + slot);
+    const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot);
     const Vec3     s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
     const float    theta = wAcos(v.y);
     const float    gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
-    const Vec3     dome = vec3(skyRadiance(sky, theta, gamma, 0), skyRadiance(sky, theta, gamma, 1), skyRadiance(sky, theta, gamma, 2));
-    const float4   rad4 = ps.rad[slot];
-    const Vec3     radiance = vec3(rad4.x, rad4.y, rad4.z) + vec3(thr4.x, thr4.y, thr4.z) * dome;
+    // cos(gamma) and |cos(theta)| do not depend on the channel: evaluated once instead of three times (same values)
+    const float cosGamma = wCos(gamma), cosTheta = fabsf(wCos(theta));
+    const Vec3  dome = vec3(skyRadiance(sky, cosTheta, gamma, cosGamma, 0), skyRadiance(sky, cosTheta, gamma, cosGamma, 1), skyRadiance(sky, cosTheta, gamma, cosGamma, 2));
+    const Vec3  radiance = rad + thr * dome;
     ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
 }
 
 template<bool COUNT>
 __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
-                                                        const uint32_t* queueCount, DeviceCounters* counters)
+                                                        const uint32_t* queueCount, DeviceCounters* counters, uint32_t firstBounce)
 {
     __shared__ uint32_t sStack[kLdsStack * kBlock];
     const uint32_t      i = blockIdx.x * kBlock + threadIdx.x;
@@ -389,10 +418,10 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
         if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
         const float    visibility = occluded ? 0.0f : 1.0f;
         const float4   pend = ps.pending[slot];
-        const float4   rad4 = ps.rad[slot];
+        const Vec3     rad0 = firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot); // bounce 1: radiance is still 0 (wgsl:183)
         // wgsl:203  radiance += ((throughput*L)*reflectance) * visibility * SOLAR_INV_PDF
         const Vec3 add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
-        const Vec3 radiance = vec3(rad4.x, rad4.y, rad4.z) + add;
+        const Vec3 radiance = rad0 + add;
         ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     }
     if (COUNT)
@@ -418,6 +447,8 @@ constexpr uint32_t kRefillMin = 32; // refill once this many lanes are idle
 constexpr uint32_t kLeafVote = 24; // leave the descent loop when fewer lanes than this are descending
 
 constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
+constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
+
 // Lane state of kTraceWide lives in ONE register, the next thing to visit: a child word of
 // rf_wide.hpp (bit 31 clear: interior record index; set: leaf descriptor) or one of two sentinels
 // (no leaf word reaches them: that would take count field 7 with big-leaf index 0x0FFFFFFE).
@@ -473,6 +504,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
     const bool       shadowDirFromStream = flags & kFlagShadowDirFromStream;
+    const bool       firstBounce = flags & kFlagFirstBounce;
 
     // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
     // shard of its block and moves on round-robin when a shard is dry.
@@ -550,15 +582,15 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
             if (node == kNodeIdle && rankInIdle < take)
             {
-                slot = queue[chunkPos + rankInIdle];
-                const Vec3 o = load3(ps.rayO + slot);
+                slot = loadQ(queue + chunkPos + rankInIdle);
+                const Vec3 o = load3s(ps.rayO + slot);
                 Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
                 {
-                    const Vec3 nz = load3(ps.noise + slot);
+                    const Vec3 nz = load3s(ps.noise + slot);
                     dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
-                else dir = load3(ps.rayD + slot);
+                else dir = load3s(ps.rayD + slot);
                 const RayPrep ray = prepareRay(o, dir);
                 pr = packRay(ray);
                 rayDir = dir;
@@ -743,14 +775,14 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             if (ANY_HIT)
             {
                 const float  visibility = occluded ? 0.0f : 1.0f;
-                const Vec3   add = (load3(ps.pending + slot) * visibility) * __uint_as_float(kSolarInvPdfBits);
-                const Vec3   radiance = load3(ps.rad + slot) + add;
-                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+                const Vec3   add = (load3s(ps.pending + slot) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3   radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add; // bounce 1: still 0 (wgsl:183)
+                store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
             }
             else
             {
                 // .w = t of the hit (rayTMax == best.t then); read by the query path only
-                ps.hit[slot] = make_float4(__uint_as_float(best.triangle), best.u, best.v, rayTMax);
+                store4s(ps.hit + slot, __uint_as_float(best.triangle), best.u, best.v, rayTMax);
             }
             node = kNodeIdle;
         }
@@ -1283,31 +1315,32 @@ struct Renderer::Impl
             }, bounce - 1);
             launchTimed(2, [&] {
                 hipLaunchKernelGGL(kShade, dim3(itemBlocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
-                                   bounce == numBounces ? 1u : 0u);
+                                   (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u));
             });
+            const uint32_t shadowFlags = bounce == 1 ? kFlagFirstBounce : 0u;
             launchTimed(3, [&] {
                 if (traversalVariant == 0)
                 {
                     if (counting)
-                        hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr);
+                        hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
                     else
-                        hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr);
+                        hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
                 }
                 else if (shadowNearestFirst)
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                     else
                         hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                 else
                     hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
             }, bounce - 1);
             std::swap(qIn, qOut);
         }
