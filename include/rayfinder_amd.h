@@ -152,6 +152,18 @@ RF_API int rf_renderer_read_accumulation(rf_renderer* r, float* dst, uint32_t* a
 /* fsMain's return value (wgsl:59-63) as the BGRA8Unorm swap-chain texel, row-major. */
 RF_API int rf_renderer_read_tonemapped(rf_renderer* r, uint32_t* dst_bgra8);
 
+/* Deferred-lighting variant (replaces nlrs::DeferredRenderer's lighting + resolve passes, src/pt/deferred_renderer.hpp,
+ * deferred_renderer_lighting_pass.wgsl:96-186 -- fixed 2-bounce surfaceColor, solar disk in the sky term, the
+ * 1/16384 + 1024 offset constants :498-500 -- and deferred_renderer_resolve_pass.wgsl:33-54 -- 0.1 / 0.9 exponential
+ * average).  The G-buffer comes from one primary ray per pixel through the jittered pixel centre
+ * (deferred_renderer.cpp:309-315) instead of the reference's raster pass.  Camera, sky and exposure are the handle's
+ * render parameters; the deferred frame counter starts at 0 and is separate from rf_renderer_render's. */
+RF_API int rf_renderer_render_deferred(rf_renderer* r, uint32_t num_frames);
+RF_API int rf_renderer_reset_deferred(rf_renderer* r);
+/* sampleBuffer and accumulationBuffer (width*height*3 f32, row-major: array<array<f32, 3>>) and the resolve pass's
+ * return value as BGRA8; any pointer may be NULL. */
+RF_API int rf_renderer_read_deferred(rf_renderer* r, float* sample_rgb, float* accumulation_rgb, uint32_t* bgra8, uint32_t* frame_count);
+
 /* Statistics (replaces the ImGui perf read-out, src/pt/main.cpp:251-257). */
 RF_API int rf_renderer_set_counting(rf_renderer* r, int enabled);
 RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);

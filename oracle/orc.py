@@ -84,6 +84,7 @@ def lib():
         _lib.orc_pixel_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.orc_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
         _lib.orc_render_from.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p]
+        _lib.orc_deferred_frame.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 5 + [C.c_void_p] * 4
         _lib.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
         _lib.orc_pixar_onb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_direction_in_cone.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
@@ -311,6 +312,18 @@ def render(scene, rp, first_frame, num_frames, x0=0, y0=0, x1=None, y1=None, ima
     lib().orc_render_from(C.byref(scene.c), C.byref(rp), first_frame, first_frame if accumulated_start is None else accumulated_start, num_frames,
                           x0, y0, x1, y1, _p(image), C.byref(st))
     return image, st
+
+
+def deferred_frames(scene, rp, num_frames, x0=0, y0=0, x1=None, y1=None):
+    """The deferred-lighting variant (lighting + resolve pass over a primary-ray G-buffer), frames 0..num_frames-1 of a fresh
+    renderer -> (last sample buffer (H,W,3), accumulation buffer (H,W,3), resolve output srgb (H,W,3), stats)."""
+    x1 = rp.width if x1 is None else x1
+    y1 = rp.height if y1 is None else y1
+    sample = np.zeros((rp.height, rp.width, 3), np.float32); accum = np.zeros_like(sample); srgb = np.zeros_like(sample)
+    st = Stats()
+    for f in range(num_frames):
+        lib().orc_deferred_frame(C.byref(scene.c), C.byref(rp), f, x0, y0, x1, y1, _p(sample), _p(accum), _p(srgb), C.byref(st))
+    return sample, accum, srgb, st
 
 
 def pixel_sample(scene, rp, x, y, frame):

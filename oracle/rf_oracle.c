@@ -1033,6 +1033,162 @@ ORC_API void orc_render(const OrcScene* sc, const OrcRenderParams* rp, uint32_t 
     orc_render_from(sc, rp, firstFrame, firstFrame, numFrames, x0, y0, x1, y1, image, st);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Deferred-lighting variant  (pt/deferred_renderer_lighting_pass.wgsl + _resolve_pass.wgsl)    */
+/* SURVEY.md 8(f) row 4.  The reference fills its G-buffer with a hardware rasteriser            */
+/* (deferred_renderer_gbuffer_pass.wgsl); here the G-buffer comes from one primary ray per pixel  */
+/* through the jittered pixel centre -- everything downstream restates the WGSL line by line.    */
+/* ------------------------------------------------------------------------------------------ */
+static v3 offset_position_deferred(v3 p, v3 n)
+{ /* lighting_pass.wgsl:498-518: the same construction as offset_ray with FLOAT_SCALE 1/16384 and INT_SCALE 1024 */
+    const float ORIGIN = 1.0f / 32.0f, FLOAT_SCALE = 1.0f / 16384.0f, INT_SCALE = 1024.0f;
+    const int32_t ox = (int32_t)(INT_SCALE * n.x), oy = (int32_t)(INT_SCALE * n.y), oz = (int32_t)(INT_SCALE * n.z);
+    int32_t ix, iy, iz;
+    memcpy(&ix, &p.x, 4); memcpy(&iy, &p.y, 4); memcpy(&iz, &p.z, 4);
+    ix = (int32_t)((uint32_t)ix + (uint32_t)(p.x < 0 ? -ox : ox));
+    iy = (int32_t)((uint32_t)iy + (uint32_t)(p.y < 0 ? -oy : oy));
+    iz = (int32_t)((uint32_t)iz + (uint32_t)(p.z < 0 ? -oz : oz));
+    v3 po; memcpy(&po.x, &ix, 4); memcpy(&po.y, &iy, 4); memcpy(&po.z, &iz, 4);
+    return V3(fabsf(p.x) < ORIGIN ? p.x + FLOAT_SCALE * n.x : po.x,
+              fabsf(p.y) < ORIGIN ? p.y + FLOAT_SCALE * n.y : po.y,
+              fabsf(p.z) < ORIGIN ? p.z + FLOAT_SCALE * n.z : po.z);
+}
+
+static float sky_radiance_with_sun(const float* sky, float theta, float gamma, uint32_t channel)
+{ /* lighting_pass.wgsl:200-238: the dome of wgsl:247-275 plus the solar disk (:231-235); TERRESTRIAL_SOLAR_RADIUS
+   * = 0.255f * (PI / 180f) const-evaluated in f32 = 0x3B91D640 */
+    const float radius = gamma / f32_from_bits(0x3B91D640u);
+    const float solar = radius <= 1.0f ? sky[30 + channel] : 0.0f;
+    return sky_radiance(sky, theta, gamma, channel) + solar;
+}
+
+static void r2_sequence_host(uint32_t n, uint32_t sequenceLength, float* x, float* y)
+{ /* common/r_sequence.hpp:9-21 with common/math.hpp:7-17's sign-preserving fract (arguments are >= 0 here) */
+    const float G = 1.32471795f;
+    const float A1 = 1.0f / G, A2 = 1.0f / (G * G);
+    const float i = (float)(n % sequenceLength);
+    const float a = 0.5f + A1 * i, b = 0.5f + A2 * i;
+    *x = a - floorf(a); *y = b - floorf(b);
+}
+
+typedef struct { int hit; v3 position, normal, albedo, direction; } GTexel;
+
+/* Interpolated attributes of a hit (lighting_pass.wgsl:312-321) + the hit point pushed off the surface along the
+ * geometric normal with the deferred constants (:447-450). */
+static void deferred_hit_attributes(const OrcScene* sc, const BvhHit* h, v3* pOffset, v3* pPlain, v3* n, v3* albedo, OrcStats* st)
+{
+    const OrcPositionAttribute* t = &sc->positions[h->triIdx];
+    const v3 p0 = V3(t->p0[0], t->p0[1], t->p0[2]), p1 = V3(t->p1[0], t->p1[1], t->p1[2]), p2 = V3(t->p2[0], t->p2[1], t->p2[2]);
+    const v3 e1 = v3_sub(p1, p0), e2 = v3_sub(p2, p0);
+    const v3 p = v3_add(v3_add(p0, v3_scale(h->u, e1)), v3_scale(h->v, e2));
+    *pPlain = p;
+    *pOffset = offset_position_deferred(p, v3_normalize(v3_cross(e1, e2)));
+    const OrcVertexAttributes* va = &sc->attrs[h->triIdx];
+    const float b0 = 1.0f - h->u - h->v, b1 = h->u, b2 = h->v;
+    *n = v3_add(v3_add(v3_scale(b0, V3(va->n0[0], va->n0[1], va->n0[2])), v3_scale(b1, V3(va->n1[0], va->n1[1], va->n1[2]))),
+                v3_scale(b2, V3(va->n2[0], va->n2[1], va->n2[2])));
+    const float uvx = (b0 * va->uv0[0] + b1 * va->uv1[0]) + b2 * va->uv2[0];
+    const float uvy = (b0 * va->uv0[1] + b1 * va->uv1[1]) + b2 * va->uv2[1];
+    *albedo = texture_lookup(sc, va->textureIdx, uvx, uvy, st);
+}
+
+static v3 deferred_light_sample(const OrcScene* sc, const float* sky, float ux, float uy, v3 position, v3 normal, v3 albedo, OrcStats* st)
+{ /* lighting_pass.wgsl:188-198 */
+    const v3 sunDirection = V3(sky[36], sky[37], sky[38]);
+    v3 ou, ov; pixar_onb(sunDirection, &ou, &ov);
+    const v3 lightDirection = mat3_mul(ou, ov, sunDirection, direction_in_cone(ux, uy, SOLAR_COS_THETA_MAX));
+    const v3 lightIntensity = V3(sky[30], sky[31], sky[32]);
+    const v3 brdf = v3_scale(W_FRAC_1_PI, albedo);
+    const v3 reflectance = v3_scale(v3_dot(normal, lightDirection), brdf);
+    st->shadowRays++;
+    uint32_t snv = 0, stt = 0;
+    const float vis = shadow_ray(position, lightDirection, sc->nodes, (const float*)sc->positions, 12, W_T_MAX, &snv, &stt);
+    st->shadowNodeVisits += snv; st->shadowTriTests += stt;
+    return v3_scale(SOLAR_INV_PDF, v3_scale(vis, v3_mul(lightIntensity, reflectance)));
+}
+
+/* One frame of the deferred renderer for the pixels [x0,x1) x [y0,y1): G-buffer from a primary ray through the pixel
+ * centre displaced by the frame's projection jitter (deferred_renderer.cpp:309-315: NDC offset (r2 - 0.5) / size =
+ * (r2 - 0.5) / 2 pixels), lighting pass (lighting_pass.wgsl:96-186), resolve (resolve_pass.wgsl:33-54).
+ * sampleBuffer / accumulationBuffer: W*H*3 floats (array<array<f32, 3>>).  srgb_out3 (NULL ok): the resolve pass's
+ * return value, acesFilmic(exposure * colour) ^ (1/2.2). */
+ORC_API void orc_deferred_frame(const OrcScene* sc, const OrcRenderParams* rp, uint32_t frameCount, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                                float* sampleBuffer, float* accumulationBuffer, float* srgb_out3, OrcStats* st)
+{
+    OrcStats local; memset(&local, 0, sizeof local);
+    if (!st) st = &local;
+    OrcCamera c; memcpy(&c, rp->camera, sizeof c);
+    const float* sky = rp->sky;
+    const v3 sunDirection = V3(sky[36], sky[37], sky[38]);
+    const float W = (float)rp->width, H = (float)rp->height;
+    float jx, jy; r2_sequence_host(frameCount, 1u << 20, &jx, &jy);
+    for (uint32_t y = y0; y < y1; ++y) {
+        for (uint32_t x = x0; x < x1; ++x) {
+            const float su = ((float)x + 0.5f) / W - (jx - 0.5f) / (2.0f * W);
+            const float tv = (1.0f - ((float)y + 0.5f) / H) - (jy - 0.5f) / (2.0f * H);
+            v3 ro, rd; generate_camera_ray_pinhole(&c, su, tv, &ro, &rd);
+            BvhHit h; memset(&h, 0, sizeof h);
+            st->closestRays++;
+            v3 color;
+            if (!ray_intersect_bvh(ro, rd, sc->nodes, (const float*)sc->positions, 12, W_T_MAX, &h)) {
+                /* :106-117 (depth == 0: nothing rasterised) */
+                float dvs = v3_dot(rd, sunDirection);
+                dvs = fmin_glm(fmax_glm(dvs, -1.0f), 1.0f);
+                const float theta = W_ACOS(rd.y), gamma = W_ACOS(dvs);
+                color = V3(sky_radiance_with_sun(sky, theta, gamma, 0), sky_radiance_with_sun(sky, theta, gamma, 1), sky_radiance_with_sun(sky, theta, gamma, 2));
+            } else {
+                v3 pOff, pPlain, normal, albedo;
+                deferred_hit_attributes(sc, &h, &pOff, &pPlain, &normal, &albedo, st);
+                /* :118-125: the G-buffer position is the surface point; it is offset along the SHADING normal */
+                v3 position = offset_position_deferred(pPlain, normal);
+                /* surfaceColor :142-186, NUM_BOUNCES = 2 */
+                v3 radiance = v3s(0.0f), throughput = v3s(1.0f);
+                float ux, uy; animated_blue_noise(sc, x, y, frameCount, 1u << 20, &ux, &uy);
+                radiance = v3_add(radiance, v3_mul(throughput, deferred_light_sample(sc, sky, ux, uy, position, normal, albedo, st)));
+                for (int bounce = 1; bounce < 2; ++bounce) {
+                    v3 nu, nv; pixar_onb(normal, &nu, &nv);
+                    const v3 wi = mat3_mul(nu, nv, normal, direction_in_cosine_weighted_hemisphere(ux, uy));
+                    throughput = v3_mul(throughput, albedo);
+                    BvhHit h2; memset(&h2, 0, sizeof h2);
+                    st->closestRays++;
+                    if (ray_intersect_bvh(position, wi, sc->nodes, (const float*)sc->positions, 12, W_T_MAX, &h2)) {
+                        v3 unused;
+                        deferred_hit_attributes(sc, &h2, &position, &unused, &normal, &albedo, st);
+                    } else {
+                        float dvs = v3_dot(wi, sunDirection);
+                        dvs = fmin_glm(fmax_glm(dvs, -1.0f), 1.0f);
+                        const float theta = W_ACOS(wi.y), gamma = W_ACOS(dvs);
+                        const v3 skyRad = V3(sky_radiance_with_sun(sky, theta, gamma, 0), sky_radiance_with_sun(sky, theta, gamma, 1), sky_radiance_with_sun(sky, theta, gamma, 2));
+                        radiance = v3_add(radiance, v3_mul(throughput, skyRad));
+                        break;
+                    }
+                    radiance = v3_add(radiance, v3_mul(throughput, deferred_light_sample(sc, sky, ux, uy, position, normal, albedo, st)));
+                }
+                color = radiance;
+            }
+            const size_t idx = (size_t)y * rp->width + x;
+            sampleBuffer[3 * idx] = color.x; sampleBuffer[3 * idx + 1] = color.y; sampleBuffer[3 * idx + 2] = color.z;
+            /* resolve_pass.wgsl:38-52 */
+            v3 outc = color;
+            if (frameCount != 0) {
+                const v3 prev = V3(accumulationBuffer[3 * idx], accumulationBuffer[3 * idx + 1], accumulationBuffer[3 * idx + 2]);
+                outc = v3_add(v3_scale(0.1f, color), v3_scale(0.9f, prev));
+            }
+            accumulationBuffer[3 * idx] = outc.x; accumulationBuffer[3 * idx + 1] = outc.y; accumulationBuffer[3 * idx + 2] = outc.z;
+            if (srgb_out3) {
+                const float in[3] = {outc.x, outc.y, outc.z};
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float xx = rp->exposure * in[ch];
+                    const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
+                    float yy = (xx * (a * xx + b)) / (xx * (cc * xx + d) + e);
+                    yy = fmin_glm(fmax_glm(yy, 0.0f), 1.0f);
+                    srgb_out3[3 * idx + ch] = W_POW(yy, 1.0f / 2.2f);
+                }
+            }
+        }
+    }
+}
+
 /* fsMain tonemap tail, wgsl:59-63 + acesFilmic :277-285.  Returns BGRA8 packed like the swap
  * chain (BGRA8Unorm): round-to-nearest of srgb*255. */
 ORC_API void orc_tonemap(const float* image, uint32_t numPixels, uint32_t accumulatedSampleCount, float exposure, float* srgb_out3)

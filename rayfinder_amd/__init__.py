@@ -366,6 +366,21 @@ class ReferencePathTracer:
         check(lib.rf_renderer_read_tonemapped(self._h, _ptr(img)))
         return img
 
+    # deferred-lighting variant (nlrs::DeferredRenderer's lighting + resolve passes over a primary-ray G-buffer)
+    def render_deferred(self, num_frames=1):
+        check(lib.rf_renderer_render_deferred(self._h, num_frames))
+
+    def reset_deferred(self):
+        check(lib.rf_renderer_reset_deferred(self._h))
+
+    def read_deferred(self):
+        """-> (sample buffer (H,W,3), accumulation buffer (H,W,3), BGRA8 (H,W), frames rendered)"""
+        w, h = self._params.width, self._params.height
+        sample = np.zeros((h, w, 3), np.float32); accum = np.zeros((h, w, 3), np.float32); bgra = np.zeros((h, w), np.uint32)
+        n = C.c_uint32(0)
+        check(lib.rf_renderer_read_deferred(self._h, _ptr(sample), _ptr(accum), _ptr(bgra), C.byref(n)))
+        return sample, accum, bgra, n.value
+
     def set_counting(self, enabled):
         check(lib.rf_renderer_set_counting(self._h, int(enabled)))
 

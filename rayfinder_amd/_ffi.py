@@ -111,6 +111,9 @@ SIGNATURES = {
     "rf_renderer_render_progress_percentage": (C.c_float, [C.c_void_p]),
     "rf_renderer_read_accumulation": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_renderer_read_tonemapped": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rf_renderer_render_deferred": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rf_renderer_reset_deferred": (C.c_int, [C.c_void_p]),
+    "rf_renderer_read_deferred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_renderer_set_counting": (C.c_int, [C.c_void_p, C.c_int]),
     "rf_renderer_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "rf_renderer_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),

@@ -208,6 +208,34 @@ int rf_renderer_read_tonemapped(rf_renderer* r, uint32_t* dst)
     });
 }
 
+int rf_renderer_render_deferred(rf_renderer* r, uint32_t num_frames)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->renderDeferred(num_frames);
+        return RF_OK;
+    });
+}
+
+int rf_renderer_reset_deferred(rf_renderer* r)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->resetDeferred();
+        return RF_OK;
+    });
+}
+
+int rf_renderer_read_deferred(rf_renderer* r, float* sample_rgb, float* accumulation_rgb, uint32_t* bgra8, uint32_t* frame_count)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        r->impl->readDeferred(sample_rgb, accumulation_rgb, bgra8);
+        if (frame_count) *frame_count = r->impl->deferredFrameCount();
+        return RF_OK;
+    });
+}
+
 int rf_renderer_set_counting(rf_renderer* r, int enabled)
 {
     return guarded([&] {

@@ -229,8 +229,10 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
         slots[k] = slot;
     }
     blockAppend<kItems>(keep, slots, queue, queueCount, sScratch);
-    const unsigned long long n = waveSum(numValid);
-    if (__lane_id() == 0 && n) atomicAdd(&counters->primaryRays, n);
+    // primary rays are counted on the host (samples x valid pixels of the shard): one atomic per wave on a single counter
+    // was what bound this kernel -- 261 k waves at ~90 same-address atomics/us = 2.9 of its 3.2 ms (MI355X_MICROARCH.md "dequeue")
+    (void)numValid;
+    (void)counters;
 }
 
 template<bool COUNT>
@@ -949,6 +951,165 @@ __global__ __launch_bounds__(kBlock) void kOccludedRays(DeviceScene scene, const
     visOut[i] = occluded ? 0.0f : 1.0f;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Deferred-lighting variant: src/pt/deferred_renderer_lighting_pass.wgsl:96-186 and
+// deferred_renderer_resolve_pass.wgsl:33-54 over a G-buffer that comes from ONE PRIMARY RAY per pixel instead of
+// the reference's raster pass (deferred_renderer_gbuffer_pass.wgsl: needs a hardware rasteriser).  What differs from
+// the reference by construction, and only there: the albedo is the nearest texel (the path tracer's textureLookup,
+// the raster pass samples through a sampler), the shading normal and position are not quantised by a texture format,
+// and visibility comes from the primary ray rather than the depth buffer.  Everything downstream is the WGSL's: the
+// fixed 2-bounce surfaceColor with the solar disk in the sky term (:231-235), the OTHER self-intersection constants
+// (1/16384 and 1024, :498-500), one blue-noise pair per pixel with a 2^20-frame cycle, the 0.1 / 0.9 exponential
+// resolve.  An interactive-preview path: one thread per pixel, the scalar reference-ordered traversal.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Vec3 offsetPositionDeferred(Vec3 p, Vec3 n)
+{
+    constexpr float kOrigin = 1.0f / 32.0f, kFloatScale = 1.0f / 16384.0f, kIntScale = 1024.0f; // lighting_pass.wgsl:498-500
+    const int       ox = static_cast<int>(kIntScale * n.x), oy = static_cast<int>(kIntScale * n.y), oz = static_cast<int>(kIntScale * n.z);
+    const Vec3      shifted = vec3(__int_as_float(__float_as_int(p.x) + (p.x < 0 ? -ox : ox)), __int_as_float(__float_as_int(p.y) + (p.y < 0 ? -oy : oy)),
+                                   __int_as_float(__float_as_int(p.z) + (p.z < 0 ? -oz : oz)));
+    return vec3(fabsf(p.x) < kOrigin ? p.x + kFloatScale * n.x : shifted.x, fabsf(p.y) < kOrigin ? p.y + kFloatScale * n.y : shifted.y,
+                fabsf(p.z) < kOrigin ? p.z + kFloatScale * n.z : shifted.z);
+}
+
+struct DeferredSurface
+{
+    Vec3 plain, offset, normal, albedo;
+};
+
+// interpolated attributes of a hit (lighting_pass.wgsl:312-321) + hit point pushed along the geometric normal (:447-450)
+__device__ __forceinline__ DeferredSurface deferredSurface(const DeviceScene& scene, const float* lut, const ClosestHit& h)
+{
+    DeferredSurface out;
+    const Vec3 p0 = load3(scene.triangles + kTriStride * h.triangle), p1 = load3(scene.triangles + kTriStride * h.triangle + 1),
+               p2 = load3(scene.triangles + kTriStride * h.triangle + 2);
+    const Vec3 e1 = p1 - p0, e2 = p2 - p0;
+    out.plain = p0 + h.u * e1 + h.v * e2;
+    out.offset = offsetPositionDeferred(out.plain, normalize(cross(e1, e2)));
+    const float4* va = scene.attributes + 4 * static_cast<size_t>(h.triangle);
+    const float4  a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
+    const Vec3    n0 = vec3(a0.x, a0.y, a0.z), n1 = vec3(a0.w, a1.x, a1.y), n2 = vec3(a1.z, a1.w, a2.x);
+    const float   b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+    out.normal = (b0 * n0 + b1 * n1) + b2 * n2;
+    const float uvx = (b0 * a2.y + b1 * a2.w) + b2 * a3.y, uvy = (b0 * a2.z + b1 * a3.x) + b2 * a3.z;
+    out.albedo = evalTexture(scene, lut, __float_as_uint(a3.w), uvx, uvy);
+    return out;
+}
+
+// lighting_pass.wgsl:200-238: the dome plus the solar disk; TERRESTRIAL_SOLAR_RADIUS = 0.255f * (PI / 180f) in f32
+__device__ __forceinline__ Vec3 skyWithSun(const SkyStateGpu& sky, Vec3 v)
+{
+    const Vec3  s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
+    const float theta = wAcos(v.y), gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
+    const float cosGamma = wCos(gamma), cosTheta = fabsf(wCos(theta));
+    const bool  inDisk = gamma / __uint_as_float(0x3B91D640u) <= 1.0f;
+    return vec3(skyRadiance(sky, cosTheta, gamma, cosGamma, 0) + (inDisk ? sky.solarRadiances[0] : 0.0f),
+                skyRadiance(sky, cosTheta, gamma, cosGamma, 1) + (inDisk ? sky.solarRadiances[1] : 0.0f),
+                skyRadiance(sky, cosTheta, gamma, cosGamma, 2) + (inDisk ? sky.solarRadiances[2] : 0.0f));
+}
+
+__global__ __launch_bounds__(kBlock) void kDeferredLighting(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, Camera cam, uint32_t width, uint32_t height,
+                                                             uint32_t frameCount, float jitterX, float jitterY, float exposure, float* sampleBuffer,
+                                                             float* accumulationBuffer, uint32_t* bgraOut, DeviceCounters* counters)
+{
+    __shared__ uint32_t sStack[kLdsStack * kBlock];
+    __shared__ float    sLut[256];
+    sLut[threadIdx.x] = scene.albedoLut[threadIdx.x];
+    __syncthreads();
+    // 8x8-pixel blocks per wave
+    const uint32_t blocksX = (width + 7u) / 8u;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = (wave % blocksX) * 8u + (lane & 7u), y = (wave / blocksX) * 8u + (lane >> 3);
+    if (x >= width || y >= height) return;
+    const float W = static_cast<float>(width), H = static_cast<float>(height);
+    // pixel centre displaced by the frame's projection jitter (deferred_renderer.cpp:309-315: (r2 - 0.5) / size in NDC)
+    const float su = (static_cast<float>(x) + 0.5f) / W - (jitterX - 0.5f) / (2.0f * W);
+    const float tv = (1.0f - (static_cast<float>(y) + 0.5f) / H) - (jitterY - 0.5f) / (2.0f * H);
+    const Vec3  rd = normalize(cam.lowerLeftCorner + cam.horizontal * su + cam.vertical * tv - cam.origin);
+    TraversalCounters  tc;
+    ClosestHit         h;
+    unsigned long long closest = 1, shadow = 0;
+    Vec3               color;
+    const Vec3         lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
+    if (!traverse<false, false>(scene, cam.origin, rd, kTMax, &sStack[threadIdx.x], h, tc)) color = skyWithSun(sky, rd); // :106-117
+    else
+    {
+        DeferredSurface sf = deferredSurface(scene, sLut, h);
+        Vec3            normal = sf.normal, albedo = sf.albedo;
+        Vec3            position = offsetPositionDeferred(sf.plain, normal); // :118-125: along the SHADING normal
+        float           ux, uy;
+        animatedBlueNoise(scene.blueNoise, x, y, frameCount, 1u << 20, ux, uy);
+        const float phi = 2.0f * kPi * uy;
+        const float cosPhi = wCos(phi), sinPhi = wSin(phi);
+        const Vec3  light = sunSample(sky, sunBasis, ux, cosPhi, sinPhi);
+        const auto  lightSample = [&](Vec3 pos, Vec3 n, Vec3 alb) { // :188-198
+            const Vec3 reflectance = (alb * kFrac1Pi) * dot(n, light);
+            ClosestHit unused;
+            ++shadow;
+            const float vis = traverse<true, false>(scene, pos, light, kTMax, &sStack[threadIdx.x], unused, tc) ? 0.0f : 1.0f;
+            return ((lightIntensity * reflectance) * vis) * __uint_as_float(kSolarInvPdfBits);
+        };
+        Vec3 radiance = vec3(0.0f, 0.0f, 0.0f), throughput = vec3(1.0f, 1.0f, 1.0f);
+        radiance = radiance + throughput * lightSample(position, normal, albedo);
+        for (int bounce = 1; bounce < 2; ++bounce) // NUM_BOUNCES = 2 (:140)
+        {
+            const float sinTheta = rf_sqrt(1.0f - ux);
+            Vec3        bu, bv;
+            pixarOnb(normal, bu, bv);
+            const Vec3 wi = basisTimes(bu, bv, normal, vec3(cosPhi * sinTheta, sinPhi * sinTheta, rf_sqrt(ux)));
+            throughput = throughput * albedo;
+            ++closest;
+            if (traverse<false, false>(scene, position, wi, kTMax, &sStack[threadIdx.x], h, tc))
+            {
+                sf = deferredSurface(scene, sLut, h);
+                position = sf.offset;
+                normal = sf.normal;
+                albedo = sf.albedo;
+            }
+            else
+            {
+                radiance = radiance + throughput * skyWithSun(sky, wi);
+                break;
+            }
+            radiance = radiance + throughput * lightSample(position, normal, albedo);
+        }
+        color = radiance;
+    }
+    const size_t idx = static_cast<size_t>(y) * width + x;
+    sampleBuffer[3 * idx] = color.x;
+    sampleBuffer[3 * idx + 1] = color.y;
+    sampleBuffer[3 * idx + 2] = color.z;
+    // resolve_pass.wgsl:38-52
+    Vec3 outc = color;
+    if (frameCount != 0u)
+    {
+        const Vec3 prev = vec3(accumulationBuffer[3 * idx], accumulationBuffer[3 * idx + 1], accumulationBuffer[3 * idx + 2]);
+        outc = 0.1f * color + 0.9f * prev;
+    }
+    accumulationBuffer[3 * idx] = outc.x;
+    accumulationBuffer[3 * idx + 1] = outc.y;
+    accumulationBuffer[3 * idx + 2] = outc.z;
+    const float in[3] = {outc.x, outc.y, outc.z};
+    uint32_t    q[3];
+    for (int c = 0; c < 3; ++c)
+    {
+        const float xx = exposure * in[c];
+        const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
+        float       yy = (xx * (a * xx + b)) / (xx * (cc * xx + d) + e);
+        yy = minf(maxf(yy, 0.0f), 1.0f);
+        q[c] = static_cast<uint32_t>(floorf(wPow(yy, 1.0f / 2.2f) * 255.0f + 0.5f));
+    }
+    bgraOut[idx] = q[2] | (q[1] << 8) | (q[0] << 16) | (255u << 24);
+    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
+    const unsigned long long cr = waveSum(closest), sr = waveSum(shadow);
+    if (__lane_id() == 0)
+    {
+        atomicAdd(&counters->closestRays, cr);
+        atomicAdd(&counters->shadowRays, sr);
+    }
+}
+
 template<typename T>
 struct DeviceBuffer
 {
@@ -1052,11 +1213,18 @@ struct Renderer::Impl
     uint64_t                imageBytes = 0;
     bool                    imageDirty = true; // needs zeroing before the next sample
 
+    uint64_t                validPixels = 0;     // pixels of this rank's tiles that lie inside the frame
+    unsigned long long      primaryRaysHost = 0; // samples traced x validPixels since the last resetStats()
     uint64_t                maxPaths = 0;
     DeviceBuffer<float4>    sRayO, sRayD, sThr, sRad, sHit, sPending, sNoise;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
     DeviceBuffer<unsigned long long> bounceTotals; // 2 x kMaxBounceStats
+
+    // deferred-lighting variant: its own frame counter and buffers (array<array<f32, 3>>)
+    uint32_t               deferredFrameCount = 0;
+    DeviceBuffer<float>    deferredSample, deferredAccum;
+    DeviceBuffer<uint32_t> deferredBgra;
 
     bool counting = false, timing = false;
     int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
@@ -1123,6 +1291,15 @@ struct Renderer::Impl
         tiles = tilesForRank(params.width, params.height, rank, worldSize);
         tileIds.upload(tiles.data(), tiles.size());
         const uint64_t pixelsPadded = static_cast<uint64_t>(tiles.size()) * 1024;
+        {
+            const uint32_t tilesX = (params.width + kTileSize - 1) / kTileSize;
+            validPixels = 0;
+            for (const uint32_t t : tiles)
+            {
+                const uint32_t x0 = (t % tilesX) * kTileSize, y0 = (t / tilesX) * kTileSize;
+                validPixels += static_cast<uint64_t>(std::min(kTileSize, params.width - x0)) * std::min(kTileSize, params.height - y0);
+            }
+        }
         if (image == nullptr || image == ownedImage.ptr)
         {
             ownedImage.alloc(std::max<uint64_t>(pixelsPadded, 1));
@@ -1270,6 +1447,7 @@ struct Renderer::Impl
 
         const uint64_t paths = static_cast<uint64_t>(numSamples) * fp.pixelsPadded;
         const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
+        primaryRaysHost += static_cast<unsigned long long>(numSamples) * validPixels;
         PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr};
         const uint32_t numBounces = fp.numBounces;
 
@@ -1689,6 +1867,50 @@ void Renderer::tonemapDeviceImage(const void* imageDevice, uint64_t numPixels, u
     RF_HIP(hipStreamSynchronize(m.stream));
 }
 
+void Renderer::renderDeferred(uint32_t numFrames)
+{
+    Impl& m = *mImpl;
+    RF_HIP(hipSetDevice(m.device));
+    const uint32_t W = m.params.width, H = m.params.height;
+    const size_t   n = static_cast<size_t>(W) * H;
+    if (m.deferredSample.count != 3 * n)
+    {
+        RF_HIP(hipStreamSynchronize(m.stream));
+        m.deferredSample.alloc(3 * n);
+        m.deferredAccum.alloc(3 * n);
+        m.deferredBgra.alloc(n);
+        m.deferredFrameCount = 0;
+    }
+    const uint32_t waves = ((W + 7) / 8) * ((H + 7) / 8);
+    for (uint32_t f = 0; f < numFrames; ++f)
+    {
+        // r2Sequence(frameCount, 1 << 20), src/common/r_sequence.hpp:9-21 (the host-side variant: + 0.5, 1/G constants)
+        constexpr float G = 1.32471795f;
+        constexpr float A1 = 1.0f / G, A2 = 1.0f / (G * G);
+        const float     i = static_cast<float>(m.deferredFrameCount % (1u << 20));
+        const float     a = 0.5f + A1 * i, b = 0.5f + A2 * i;
+        const float     jx = a - std::floor(a), jy = b - std::floor(b);
+        hipLaunchKernelGGL(kDeferredLighting, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, m.stream, m.scene, m.sky, m.sunBasis, m.params.camera, W, H,
+                           m.deferredFrameCount, jx, jy, m.params.exposure, m.deferredSample.ptr, m.deferredAccum.ptr, m.deferredBgra.ptr, m.counters.ptr);
+        ++m.deferredFrameCount;
+    }
+    RF_HIP(hipGetLastError());
+}
+
+void Renderer::resetDeferred() { mImpl->deferredFrameCount = 0; }
+uint32_t Renderer::deferredFrameCount() const { return mImpl->deferredFrameCount; }
+
+void Renderer::readDeferred(float* sampleRgb, float* accumulationRgb, uint32_t* bgra8)
+{
+    Impl& m = *mImpl;
+    synchronize();
+    const size_t n = static_cast<size_t>(m.params.width) * m.params.height;
+    if (m.deferredSample.count != 3 * n) throw std::runtime_error("no deferred frame has been rendered at this framebuffer size");
+    if (sampleRgb) RF_HIP(hipMemcpy(sampleRgb, m.deferredSample.ptr, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (accumulationRgb) RF_HIP(hipMemcpy(accumulationRgb, m.deferredAccum.ptr, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (bgra8) RF_HIP(hipMemcpy(bgra8, m.deferredBgra.ptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+}
+
 void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
 
 void Renderer::setOption(const std::string& name, int64_t value)
@@ -1721,6 +1943,7 @@ void Renderer::resetStats()
     RF_HIP(hipMemcpy(m.counters.ptr, &zero, sizeof zero, hipMemcpyHostToDevice));
     RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 2 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
     m.hostStats = RenderStats{};
+    m.primaryRaysHost = 0;
 }
 
 RenderStats Renderer::stats()
@@ -1731,7 +1954,7 @@ RenderStats Renderer::stats()
     DeviceCounters c{};
     RF_HIP(hipMemcpy(&c, m.counters.ptr, sizeof c, hipMemcpyDeviceToHost));
     RenderStats s = m.hostStats;
-    s.primaryRays = c.primaryRays;
+    s.primaryRays = m.primaryRaysHost;
     s.closestRays = c.closestRays;
     s.shadowRays = c.shadowRays;
     s.closestNodeVisits = c.closestNodeVisits;
@@ -1741,7 +1964,7 @@ RenderStats Renderer::stats()
     s.stackHighWater = c.stackHigh;
     s.closestRecordFetches = c.closestRecordFetches;
     s.shadowRecordFetches = c.shadowRecordFetches;
-    s.paths = c.primaryRays;
+    s.paths = m.primaryRaysHost;
     s.abandonedRays = c.abandonedRays;
     s.scalarRedoRays = c.scalarRedo[0] + c.scalarRedo[1];
     if (std::getenv("RF_DEBUG_COUNTERS"))

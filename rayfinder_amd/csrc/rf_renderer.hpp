@@ -133,6 +133,16 @@ public:
     // assembled on the root rank): numPixels texels, divided by `samples`, scaled by the handle's exposure.
     void tonemapDeviceImage(const void* imageDevice, uint64_t numPixels, uint32_t samples, uint32_t* dstBgra8Host);
 
+    // Deferred-lighting variant: numFrames frames of lighting pass + exponential resolve
+    // (src/pt/deferred_renderer_lighting_pass.wgsl:96-186, deferred_renderer_resolve_pass.wgsl:33-54) over a
+    // primary-ray G-buffer; uses the handle's camera, sky and exposure.  Its frame counter starts at 0 (frame 0
+    // initialises the accumulation, resolve_pass.wgsl:41-44) and is independent of render()'s.
+    void     renderDeferred(uint32_t numFrames);
+    void     resetDeferred();
+    uint32_t deferredFrameCount() const;
+    // sampleBuffer / accumulationBuffer (width*height*3 floats, row-major) and the resolve pass's BGRA8 output; NULL = skip
+    void readDeferred(float* sampleRgb, float* accumulationRgb, uint32_t* bgra8);
+
     void        setCounting(bool enabled);
     // Tuning knobs for A/B measurements inside one process ("traversal_variant": 0 = one ray per
     // thread kernels, 1 = persistent waves with lane refill).  Results never depend on them.

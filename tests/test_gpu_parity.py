@@ -783,3 +783,30 @@ def test_accumulation_restart_keeps_frame_count(duck_pt, duck_oracle):
     ref, _ = orc.render(duck_oracle.scene, rp, 4, spp + 2, accumulated_start=0)
     assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
     r.close()
+
+
+# ------------------------------------------------------------------ deferred-lighting variant
+def test_deferred_lighting_variant_vs_oracle(duck_pt, duck_oracle):
+    """Lighting pass (deferred_renderer_lighting_pass.wgsl:96-186: fixed 2 bounces, solar disk in the sky term, the
+    1/16384 + 1024 offsets) + exponential resolve (deferred_renderer_resolve_pass.wgsl:33-54) over a primary-ray
+    G-buffer: sample buffer, accumulation buffer and BGRA output == the oracle's restatement, frame after frame."""
+    W, H = 136, 96
+    r, params = _renderer(duck_pt, W, H, 1, 2, exposure=0.25)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), 1, 2, 0.25, rf.aligned_sky_state(params.sky))
+    for frames in (1, 4):
+        r.reset_deferred()
+        r.render_deferred(frames)
+        sample, accum, bgra, n = r.read_deferred()
+        assert n == frames
+        ws, wa, wsrgb, st = orc.deferred_frames(duck_oracle.scene, rp, frames)
+        assert np.array_equal(bits(sample), bits(ws))
+        assert np.array_equal(bits(accum), bits(wa))
+        want = np.floor(wsrgb * np.float32(255.0) + np.float32(0.5)).astype(np.int64)
+        got = np.stack([(bgra >> 16) & 255, (bgra >> 8) & 255, bgra & 255], axis=-1).astype(np.int64)
+        assert np.array_equal(got, want)
+    # frame 0 initialises the accumulation; later frames move it by a tenth of the difference
+    assert np.isfinite(accum).all() and (sample[..., 2] > 0).any()
+    # sky pixels that look at the sun carry the solar disk term
+    s = r.stats()
+    assert s["shadow_rays"] > 0
+    r.close()

@@ -456,3 +456,32 @@ def test_sealed_white_room_is_black_and_open_room_respects_the_energy_bound():
     bound = spp * (sum(rho ** b for b in range(1, bounces + 1)) * solar.max() * inv_pdf / np.pi + max_sky)
     assert np.isfinite(img).all() and np.abs(img[..., :3]).max() <= bound
     assert img[..., :3].max() > 0 and st.shadowRays < st.closestRays              # light does get in, some paths leave
+
+
+def test_deferred_variant_analytic_properties():
+    """The deferred-lighting restatement (oracle side): frame 0 initialises the accumulation, later frames are the 0.1 / 0.9
+    blend (resolve_pass.wgsl:41-49); a pixel that sees only sky carries skyRadiance (+ the solar disk inside 0.255 deg);
+    a floor pixel's first light sample equals the path tracer's single-bounce NEE term up to the different offset."""
+    import analytic_scene as an
+    rects = [an.Rect(1, 0.0, (-2, -2), (2, 2), (0, 1, 0), +1, (255, 255, 255))]
+    sc = _oracle_scene_from_rects(rects)
+    W = H = 16
+    cam = orc.create_camera([0, 3, 0.001], [0, 0, 0], 0.0, 1.0, orc.degrees_to_radians(40.0), 1.0)
+    sky = orc.aligned_sky_state()
+    rp = orc.make_render_params(W, H, cam, 1, 2, 1.0, sky)
+    s1, a1, _, _ = orc.deferred_frames(sc, rp, 1)
+    assert np.array_equal(bits(s1), bits(a1))
+    s2, a2, _, _ = orc.deferred_frames(sc, rp, 2)
+    # frame 1's blend: replay frame 0 for the previous value
+    assert np.array_equal(bits(a2), bits(np.float32(0.1) * s2 + np.float32(0.9) * a1))
+    # an isolated floor: the bounce ray always escapes, so colour = NEE(floor) + albedo * sky(wi) (+ sun if wi looks at it)
+    solar, inv_pdf = sky[30:33].astype(np.float64), 6.216817e-05
+    nee = solar / np.pi * np.cos(np.radians(30.0)) * inv_pdf
+    px = s1[8, 8].astype(np.float64)
+    assert (px > nee * 0.99).all() and (px < nee * 1.01 + 60.0).all()
+    # looking up: sky only, and the pixel that looks into the sun includes the solar radiance
+    up = orc.create_camera([0, 1, 0], [0.5, 1 + 0.8660254, 0.0], 0.0, 1.0, orc.degrees_to_radians(2.0), 1.0)   # towards the sun (zenith 30 deg, azimuth 0)
+    rp2 = orc.make_render_params(W, H, up, 1, 2, 1.0, sky)
+    s, _, _, st = orc.deferred_frames(sc, rp2, 1)
+    assert st.shadowRays == 0
+    assert s[..., 0].max() > 0.5 * sky[30] and s[..., 0].min() < 0.01 * sky[30]     # inside / outside the 0.255-degree disk
