@@ -445,8 +445,8 @@ constexpr uint32_t kChunk = 128;   // queue entries claimed per atomic (small en
 constexpr uint32_t kShards = 16;   // work cursors per launch, one 64-byte line each: a single cursor
                                    // saturates near 90 claims/us (8 M rays / 64 per 1.2 ms = 100/us)
 constexpr uint32_t kLineWords = 16;
-constexpr uint32_t kRefillMin = 32; // refill once this many lanes are idle
-constexpr uint32_t kLeafVote = 24; // leave the descent loop when fewer lanes than this are descending
+constexpr uint32_t kRefillMin = 40; // refill once this many lanes are idle (r02 sweep: 32 -> 40 = +1 %)
+constexpr uint32_t kLeafVote = 20; // leave the descent loop when fewer lanes than this are descending (16..24 measure the same)
 
 constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
 constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)

@@ -810,3 +810,40 @@ def test_deferred_lighting_variant_vs_oracle(duck_pt, duck_oracle):
     s = r.stats()
     assert s["shadow_rays"] > 0
     r.close()
+
+
+# ------------------------------------------------------------------ round 2: a Sponza-shaped asset end to end
+def test_courtyard_asset_bake_render_and_bench(tmp_path):
+    """tools/make_test_asset.py (multi-mesh, multi-material .gltf with external PNG / progressive-JPEG URIs, node TRS):
+    rf-pt-format-tool with the host builder and with --gpu-bvh write the same .pt; the render of it equals the oracle's
+    bit for bit; bench.py --scene runs on it."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_test_asset
+    path = make_test_asset.write_courtyard(str(tmp_path / "courtyard"))
+    tool = os.path.join(ROOT, "rayfinder_amd", "bin", "rf-pt-format-tool")
+    subprocess.check_call([tool, path], stdout=subprocess.DEVNULL)
+    host = open(path.replace(".gltf", ".pt"), "rb").read()
+    subprocess.check_call([tool, "--gpu-bvh", path], stdout=subprocess.DEVNULL)
+    gpu = open(path.replace(".gltf", ".pt"), "rb").read()
+    assert host == gpu
+    pt = rf.PtFormat.load(path.replace(".gltf", ".pt"))
+    sc, _ = oracle_scene_from_pt(pt)
+    W, H, spp, bounces = 160, 96, 4, 4
+    cam = rf.create_camera((4.0, 2.5, 4.5), (1.0, 0.8, -1.0), 0.0, 1.0, float(orc.degrees_to_radians(55.0)), W / H)
+    r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, bounces, rf.make_sky(), 0.25), pt.scene())
+    r.render(spp)
+    img, _ = r.read_accumulation()
+    s = r.stats()
+    r.close()
+    ref, st = orc.render(sc, orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.25, rf.aligned_sky_state(rf.make_sky())), 0, spp)
+    assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
+    assert s["closest_rays"] == st.closestRays and s["shadow_rays"] == st.shadowRays > 0
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", path.replace(".gltf", ".pt"), "--width", "320", "--height", "192",
+                                   "--steps", "1", "--warmup", "1", "--bounces", "4", "--cpu-seconds", "1"], stderr=subprocess.DEVNULL)
+    line = json.loads(out.decode().strip().splitlines()[-1])
+    assert line["value"] > 0 and line["nan_pixels"] == 0 and line["parity_crop"]["verdict"] == "bit-identical"
+    assert "courtyard.pt" in line["config"]["workload"]

@@ -9,6 +9,7 @@ import os
 import re
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -467,3 +468,49 @@ def test_png_header_checks():
     for depth, ctype, n in [(3, 0, 13), (32, 0, 13), (200, 2, 13), (4, 2, 13), (16, 3, 13), (8, 6, 9), (8, 5, 13)]:
         with pytest.raises(rf.RayfinderError):
             rf.texture_from_memory(png(depth, ctype, n))
+
+
+# ---------------------------------------------------------------- a Sponza-shaped asset (round 2)
+def _courtyard(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_test_asset
+    return make_test_asset.write_courtyard(str(tmp_path / "courtyard"))
+
+
+def test_multi_material_gltf_with_external_uris_and_jpegs_bakes_like_the_independent_ingest(tmp_path):
+    """tools/make_test_asset.py: .gltf + external .bin, external PNG (RGB / RGBA / palette) and JPEG (baseline 4:2:0,
+    progressive 4:4:4, grey) images -- one URI percent-encoded --, a three-level node hierarchy with T/R/S and a raw
+    matrix, six meshes, ten materials (image-backed with shared images, factor-only with a repeated factor), u8 / u16 /
+    u32 indices (gltf_model.cpp:74-121,266-465).  Product C++ ingest == oracle/gltf_ref.py (numpy + PIL) bit for bit on
+    every geometry array and PNG texel; JPEG texels within 2 levels of libjpeg-turbo (stb's IDCT differs)."""
+    path = _courtyard(tmp_path)
+    pt = rf.PtFormat.from_gltf(path)
+    a = pt.arrays()
+    m = gltf_ref.load_model(path)
+    P, N, T, I = gltf_ref.flatten(m)
+    assert len(P) == len(a["bvhPositionAttributes"]) > 2500 and len(m["textures"]) == len(a["baseColorTextures"]) == 8
+    nodes, idx, _ = orc.build_bvh(P)
+    assert nodes.tobytes() == a["bvhNodes"].tobytes()
+    tris = orc.reorder(P, idx)
+    assert np.array_equal(bits(tris), bits(a["bvhPositionAttributes"]))
+    pos48, attr80 = gltf_ref.gpu_layout(tris, orc.reorder(N, idx), orc.reorder(T, idx), orc.reorder(I, idx))
+    assert np.array_equal(bits(pos48), bits(a["trianglePositionAttributes"]))
+    assert np.array_equal(np.ascontiguousarray(attr80).view(np.uint32).reshape(-1, 20), a["triangleVertexAttributes"].view(np.uint32))
+    tex_idx = a["triangleVertexAttributes"].view(np.uint32)[:, 18]
+    assert set(tex_idx) == set(range(8))                       # every texture is used by some triangle
+    exact = 0
+    for (px, w, h), (opx, ow, oh) in zip(a["baseColorTextures"], m["textures"]):
+        assert (w, h) == (ow, oh)
+        ch = lambda p: ((np.asarray(p)[:, None] >> np.array([0, 8, 16, 24])) & 255).astype(int)
+        d = np.abs(ch(px) - ch(opx)).max()
+        assert d <= 2
+        exact += d == 0
+    assert exact >= 5                                          # three PNGs + two factor textures
+    # the raster-mesh arrays of pt_format.cpp:85-148: one slice per primitive, sorted by texture index
+    assert len(a["modelBaseColorTextureIndices"]) == 10 and (np.diff(a["modelBaseColorTextureIndices"].astype(int)) >= 0).all()
+    # CLI bake (host builder) == library bake, and a .pt round trip
+    tool = os.path.join(ROOT, "rayfinder_amd", "bin", "rf-pt-format-tool")
+    out = subprocess.check_output([tool, path]).decode()
+    assert f"{len(nodes)} nodes" in out and "8 textures" in out
+    data = open(path.replace(".gltf", ".pt"), "rb").read()
+    assert data == pt.serialize() and rf.PtFormat.deserialize(data).serialize() == data
