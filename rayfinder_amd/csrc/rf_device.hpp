@@ -37,6 +37,7 @@ struct DeviceScene
     const float4*            nodes;      // 2 per node
     const float4*            triangles;  // kTriStride per triangle (p0, p1, p2, pad)
     const float4*            attributes; // 4 per triangle: the 80-B VertexAttributes packed to 64 B (rf_renderer.hip)
+    const float4*            shadeRecords; // 8 per triangle (128 B, 128-B aligned): p0 p1 p2 + the 4 attribute float4 -- everything kShade needs of a triangle in one L2 line
     const TextureDescriptor* textureDescriptors;
     const uint32_t*          texels;
     uint64_t                 numTexels;

@@ -299,6 +299,7 @@ __device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, const SunBasis
 }
 
 constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
+constexpr uint32_t kShadeMaxBlocks = 256u * 8u * 4u; // four rounds of the 8 resident workgroups per CU
 
 __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                   const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
@@ -307,17 +308,22 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
     __shared__ uint32_t sScratch[8];
     __shared__ float    sLut[256];
     const uint32_t      count = *queueCount;
-    if (blockIdx.x * kItems * kBlock >= count) return; // whole block out of range (uniform)
+    // grid-stride over tiles of kItems * kBlock queue entries: the grid is capped (kShadeMaxBlocks), so late bounces, whose
+    // queues hold a sixth of the paths, do not pay for hundreds of thousands of empty workgroups
+    const uint32_t tiles = (count + kItems * kBlock - 1) / (kItems * kBlock);
+    if (blockIdx.x >= tiles) return; // whole block out of range (uniform)
     static_assert(kBlock == 256, "one table entry per thread");
     sLut[threadIdx.x] = scene.albedoLut[threadIdx.x];
     __syncthreads();
     const bool isLastBounce = (bounceFlags & kShadeLastBounce) != 0u, isFirstBounce = (bounceFlags & kShadeFirstBounce) != 0u;
+  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
+  {
     bool       isHit[kItems], isMiss[kItems];
     uint32_t   slots[kItems], missEntries[kItems];
 #pragma unroll 1
     for (int k = 0; k < kItems; ++k)
     {
-        const uint32_t i = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
+        const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
         isHit[k] = isMiss[k] = false;
         slots[k] = missEntries[k] = 0;
         if (i >= count) continue;
@@ -332,17 +338,22 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             continue;
         }
         isHit[k] = true;
+        // everything this stage needs of the triangle sits in ONE 128-byte record (positions + packed attributes): one L2 line
+        // per shaded hit instead of a triangle line and an attribute line (kShade 56.1 -> 53.0 ms per 128 spp)
+        const float4* rec = scene.shadeRecords + 8 * static_cast<size_t>(tri);
         {
             // hit point pushed off the surface along the geometric normal (wgsl:511-519,523-544): origin of
             // the shadow ray and of the next bounce; same arithmetic as the scalar traversal (rf_device.hpp)
-            const Vec3 hp = hitPoint(scene, tri, h.y, h.z);
+            const Vec3 p0 = load3(rec), p1 = load3(rec + 1), p2 = load3(rec + 2);
+            const Vec3 e1 = p1 - p0, e2 = p2 - p0;
+            const Vec3 hp = offsetRay(p0 + h.y * e1 + h.z * e2, normalize(cross(e1, e2)));
             ps.rayO[slot] = make_float4(hp.x, hp.y, hp.z, 0.0f);
         }
         const Vec3  throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + slot); // wgsl:184
         const Vec3  nz = load3(ps.noise + slot);
         const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
         // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
-        const float4* va = scene.attributes + 4 * static_cast<size_t>(tri);
+        const float4* va = rec + 3;
         const float4  a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
         const Vec3    n0 = vec3(a0.x, a0.y, a0.z), n1 = vec3(a0.w, a1.x, a1.y), n2 = vec3(a1.z, a1.w, a2.x);
         const float   b0 = 1.0f - h.y - h.z, b1 = h.y, b2 = h.z; // wgsl:515
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
     }
     blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch);
     blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
+  }
 }
 
 // Paths that left the scene (at any bounce of this batch): radiance += throughput * sky
@@ -1191,6 +1203,7 @@ struct Renderer::Impl
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
     DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
+    DeviceBuffer<float4>            shadeRecords; // 8 per triangle: kShade's 128-byte record
     DeviceBuffer<TextureDescriptor> textureDescriptors;
     DeviceBuffer<uint32_t>          texels;
     DeviceBuffer<uint8_t>           blueNoise;
@@ -1492,7 +1505,7 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
             }, bounce - 1);
             launchTimed(2, [&] {
-                hipLaunchKernelGGL(kShade, dim3(itemBlocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
+                hipLaunchKernelGGL(kShade, dim3(std::min(itemBlocks, kShadeMaxBlocks)), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
                                    (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u));
             });
             const uint32_t shadowFlags = bounce == 1 ? kFlagFirstBounce : 0u;
@@ -1603,6 +1616,17 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             packed[4 * i + 3] = make_float4(v.uv1.y, v.uv2.x, v.uv2.y, bitsFloat(v.textureIdx));
         }
         m.attributes.upload(packed.data(), packed.size());
+        // kShade's record: positions + these four float4, 128 B per triangle
+        std::vector<float4> rec(8 * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        for (size_t i = 0; i < n; ++i)
+        {
+            const PositionAttribute& t = sceneView.positionAttributes[i];
+            rec[8 * i] = make_float4(t.p0.x, t.p0.y, t.p0.z, 0.0f);
+            rec[8 * i + 1] = make_float4(t.p1.x, t.p1.y, t.p1.z, 0.0f);
+            rec[8 * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
+            for (int k = 0; k < 4; ++k) rec[8 * i + 3 + k] = packed[4 * i + k];
+        }
+        m.shadeRecords.upload(rec.data(), rec.size());
     }
 
     // texture blob + descriptors in the order of the model's textures (reference_path_tracer.cpp:210-270)
@@ -1634,6 +1658,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.scene.nodes = m.nodes.ptr;
     m.scene.triangles = m.triangles.ptr;
     m.scene.attributes = m.attributes.ptr;
+    m.scene.shadeRecords = m.shadeRecords.ptr;
     m.scene.textureDescriptors = m.textureDescriptors.ptr;
     m.scene.texels = m.texels.ptr;
     m.scene.numTexels = m.texels.count;
@@ -1659,10 +1684,11 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.maxWidth = desc.maxWidth ? desc.maxWidth : desc.renderParams.width;
     m.maxHeight = desc.maxHeight ? desc.maxHeight : desc.renderParams.height;
     const uint64_t maxTiles = static_cast<uint64_t>((m.maxWidth + kTileSize - 1) / kTileSize) * ((m.maxHeight + kTileSize - 1) / kTileSize);
-    // 64 Mi paths per batch by default (7.5 GB of path state): later bounces of a batch keep ~15 % of
-    // the paths, and a traversal launch needs millions of rays to fill 6144 persistent waves
-    // (measured on the atrium: 8 Mi paths 3234, 32 Mi 3690, 64 Mi 3752 Mrays/s).
-    const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (64ull << 20);
+    // 256 Mi paths per batch by default (33 GB of path state + queues out of 288 GB): later bounces of a batch keep
+    // ~15 % of the paths, and a traversal launch needs millions of rays to fill 6144 persistent waves and to amortise
+    // its tail (measured on the atrium, 1080p: 8 Mi paths 3234, 32 Mi 3690, 64 Mi 5125, 128 Mi 5171, 256 Mi 5224 Mrays/s
+    // -- the last three with the round-2 kernels).  Allocated on demand for the largest batch actually traced.
+    const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (256ull << 20);
     // path slots and queue indices are 32-bit: at most 2^31 paths per batch, and one sample of the whole
     // (padded) frame must fit in a batch
     constexpr uint64_t kMaxPathsPerBatch = 1ull << 31;
