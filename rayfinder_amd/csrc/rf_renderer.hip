@@ -117,8 +117,43 @@ struct FrameParams
     uint32_t numSamples; // samples traced in this batch
     uint32_t numTiles;
     uint32_t pixelsPadded; // numTiles * 1024
+    // Path slot <-> (sample k of the batch, local pixel lp).  Groups of 2^g consecutive local pixels (g = 0: one pixel,
+    // 6: one 8x8 block, 10: one tile) keep all their samples together:
+    //     slot = (((lp >> g) * numSamples + k) << g) + (lp & (2^g - 1)),
+    // so that neighbours in the ray queues (= in a wave, on a CU) are the same few pixels' other samples rather than the
+    // same sample's other pixels.  kSlotSampleMajor: the round-1 order, slot = k * pixelsPadded + lp.
+    uint32_t slotGroupShift;
+    // Order of a pixel group's samples inside its run of slots: position p holds sample samplePerm[p] (inverse:
+    // sampleInvPerm).  nullptr = identity.  kSamplePermutation sorts the batch's samples along a Z-order curve through their
+    // R2 points, so that a wave's rays (a few neighbouring pixels x consecutive positions) leave the same surface in similar
+    // directions (u = fract(blueNoise(pixel) + r2(sample)): the same pair drives every bounce, wgsl:52-55,194,209).
+    const uint32_t* samplePerm;
+    const uint32_t* sampleInvPerm;
     uint32_t tilesX;
 };
+
+constexpr uint32_t kSlotSampleMajor = 31u;
+
+__device__ __forceinline__ void slotToSamplePixel(const FrameParams& fp, uint32_t slot, uint32_t& k, uint32_t& lp)
+{
+    if (fp.slotGroupShift == kSlotSampleMajor)
+    {
+        k = slot / fp.pixelsPadded;
+        lp = slot % fp.pixelsPadded;
+    }
+    else
+    {
+        const uint32_t g = fp.slotGroupShift, chunk = slot >> g;
+        k = chunk % fp.numSamples;
+        lp = ((chunk / fp.numSamples) << g) + (slot & ((1u << g) - 1u));
+    }
+}
+__device__ __forceinline__ size_t samplePixelToSlot(const FrameParams& fp, uint32_t k, uint32_t lp)
+{
+    if (fp.slotGroupShift == kSlotSampleMajor) return static_cast<size_t>(k) * fp.pixelsPadded + lp;
+    const uint32_t g = fp.slotGroupShift;
+    return ((static_cast<size_t>(lp >> g) * fp.numSamples + k) << g) + (lp & ((1u << g) - 1u));
+}
 
 // local pixel index (tile-major, 8x8 pixel blocks = one wave) -> image coordinates
 __device__ __forceinline__ bool localPixelToXY(const FrameParams& fp, const uint32_t* tileIds, uint32_t lp, uint32_t& x, uint32_t& y)
@@ -178,6 +213,38 @@ __device__ __forceinline__ uint32_t waveMax(uint32_t v)
     return v;
 }
 
+// Z-order key of sample k's R2 point (the temporal part of animatedBlueNoise, wgsl:606-615; only the ORDER matters)
+__device__ __forceinline__ uint32_t sampleKey(uint32_t firstFrame, uint32_t spp, uint32_t k)
+{
+    const uint32_t n = (firstFrame + k) % spp;
+    const float    rx = wFract(0.7548776662466927f * static_cast<float>(n)), ry = wFract(0.5698402909980532f * static_cast<float>(n));
+    uint32_t       x = static_cast<uint32_t>(rx * 65536.0f) & 0xFFFFu, y = static_cast<uint32_t>(ry * 65536.0f) & 0xFFFFu;
+    const auto     spread = [](uint32_t v) {
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+
+// perm / inverse of the batch's samples by (key, k): S is at most a few thousand, one thread per sample counts its rank
+__global__ void kSamplePermutation(uint32_t firstFrame, uint32_t spp, uint32_t numSamples, uint32_t* perm, uint32_t* inv)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= numSamples) return;
+    const uint32_t mine = sampleKey(firstFrame, spp, k);
+    uint32_t       rank = 0;
+    for (uint32_t j = 0; j < numSamples; ++j)
+    {
+        const uint32_t other = sampleKey(firstFrame, spp, j);
+        rank += (other < mine || (other == mine && j < k)) ? 1u : 0u;
+    }
+    perm[rank] = k;
+    inv[k] = rank;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene scene, const uint32_t* tileIds, PathStreams ps,
                                                    uint32_t* queue, uint32_t* queueCount, DeviceCounters* counters)
@@ -196,11 +263,12 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
     {
         const uint32_t slot = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
         bool           valid = slot < total;
-        uint32_t       x = 0, y = 0;
-        if (valid) valid = localPixelToXY(fp, tileIds, slot % fp.pixelsPadded, x, y);
+        uint32_t       x = 0, y = 0, sampleIdx = 0, lp = 0;
+        if (valid) slotToSamplePixel(fp, slot, sampleIdx, lp);
+        if (valid) valid = localPixelToXY(fp, tileIds, lp, x, y);
         if (valid)
         {
-            const uint32_t frame = fp.firstFrame + slot / fp.pixelsPadded;
+            const uint32_t frame = fp.firstFrame + (fp.samplePerm ? fp.samplePerm[sampleIdx] : sampleIdx);
             float          nx, ny;
             animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
 
@@ -299,7 +367,7 @@ __device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, const SunBasis
 }
 
 constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
-constexpr uint32_t kShadeMaxBlocks = 256u * 8u * 4u; // four rounds of the 8 resident workgroups per CU
+
 
 __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                   const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
@@ -867,7 +935,7 @@ __global__ __launch_bounds__(kBlock) void kAccumulate(FrameParams fp, const uint
     float4 acc = image[lp];
     for (uint32_t k = 0; k < fp.numSamples; ++k)
     {
-        const float4 r = ps.rad[static_cast<size_t>(k) * fp.pixelsPadded + lp];
+        const float4 r = ps.rad[samplePixelToSlot(fp, fp.sampleInvPerm ? fp.sampleInvPerm[k] : k, lp)];
         acc.x += r.x;
         acc.y += r.y;
         acc.z += r.z;
@@ -1246,6 +1314,13 @@ struct Renderer::Impl
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
+    // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
+    // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
+    // workgroups but cost the traversal kernels 2-5 %)
+    uint32_t optShadeBlocks = 0;
+    bool                   optSampleSort = true;
+    DeviceBuffer<uint32_t> samplePerm;
+    uint32_t optSlotGroupShift = 0; // see FrameParams::slotGroupShift (r02 A/B on the atrium, Mrays/s: sample-major 5282; unsorted g = 6: 5416, 2: 5507, 0: 5450; with sorted samples g = 2: 5519, 1: 5589, 0: 5650)
     RenderStats hostStats;
 
     struct TimedLaunch
@@ -1455,6 +1530,14 @@ struct Renderer::Impl
         fp.numSamples = numSamples;
         fp.numTiles = static_cast<uint32_t>(tiles.size());
         fp.pixelsPadded = fp.numTiles * 1024u;
+        fp.slotGroupShift = optSlotGroupShift;
+        fp.samplePerm = fp.sampleInvPerm = nullptr;
+        if (optSampleSort && numSamples > 1 && optSlotGroupShift != kSlotSampleMajor)
+        {
+            if (samplePerm.count < 2ull * numSamples) samplePerm.alloc(2ull * numSamples); // (the stream is idle the first time; later batches are no larger)
+            fp.samplePerm = samplePerm.ptr;
+            fp.sampleInvPerm = samplePerm.ptr + numSamples;
+        }
         fp.tilesX = (params.width + kTileSize - 1) / kTileSize;
         if (fp.numTiles == 0) return;
 
@@ -1479,6 +1562,9 @@ struct Renderer::Impl
 
         uint32_t* qIn = queueA.ptr;
         uint32_t* qOut = queueB.ptr;
+        if (fp.samplePerm)
+            hipLaunchKernelGGL(kSamplePermutation, dim3((numSamples + 255) / 256), dim3(256), 0, stream, firstFrame, fp.samplesPerPixel, numSamples,
+                               const_cast<uint32_t*>(fp.samplePerm), const_cast<uint32_t*>(fp.sampleInvPerm));
         launchTimed(0, [&] {
             hipLaunchKernelGGL(kRaygen, dim3(itemBlocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
         });
@@ -1505,7 +1591,7 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
             }, bounce - 1);
             launchTimed(2, [&] {
-                hipLaunchKernelGGL(kShade, dim3(std::min(itemBlocks, kShadeMaxBlocks)), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
+                hipLaunchKernelGGL(kShade, dim3(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
                                    (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u));
             });
             const uint32_t shadowFlags = bounce == 1 ? kFlagFirstBounce : 0u;
@@ -1684,11 +1770,12 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.maxWidth = desc.maxWidth ? desc.maxWidth : desc.renderParams.width;
     m.maxHeight = desc.maxHeight ? desc.maxHeight : desc.renderParams.height;
     const uint64_t maxTiles = static_cast<uint64_t>((m.maxWidth + kTileSize - 1) / kTileSize) * ((m.maxHeight + kTileSize - 1) / kTileSize);
-    // 256 Mi paths per batch by default (33 GB of path state + queues out of 288 GB): later bounces of a batch keep
-    // ~15 % of the paths, and a traversal launch needs millions of rays to fill 6144 persistent waves and to amortise
-    // its tail (measured on the atrium, 1080p: 8 Mi paths 3234, 32 Mi 3690, 64 Mi 5125, 128 Mi 5171, 256 Mi 5224 Mrays/s
-    // -- the last three with the round-2 kernels).  Allocated on demand for the largest batch actually traced.
-    const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (256ull << 20);
+    // 512 Mi paths per batch by default (66 GB of path state + queues out of 288 GB): later bounces of a batch keep ~15 % of
+    // the paths, a traversal launch needs millions of rays to fill 6144 persistent waves and to amortise its tail, and the
+    // more samples of a pixel a batch holds, the closer the directions of the 64 direction-sorted samples that share a
+    // wave (FrameParams::samplePerm).  Measured on the atrium, 1080p, Mrays/s: 64 Mi 5125, 128 Mi 5171, 256 Mi 5224 (before
+    // the sample sort); 256 Mi 5692, 512 Mi 5826 (with it).  Allocated on demand for the largest batch actually traced.
+    const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (512ull << 20);
     // path slots and queue indices are 32-bit: at most 2^31 paths per batch, and one sample of the whole
     // (padded) frame must fit in a batch
     constexpr uint64_t kMaxPathsPerBatch = 1ull << 31;
@@ -1773,7 +1860,11 @@ void Renderer::render(uint32_t numFrames)
             m.imageDirty = false;
         }
         const uint32_t perBatch = static_cast<uint32_t>(std::max<uint64_t>(1, m.maxPaths / pixelsPadded));
-        const uint32_t n = std::min({remaining, spp - m.accumulated, perBatch});
+        // equal batches (320 samples with room for 256 per batch -> 160 + 160, not 256 + 64): a small trailing batch has
+        // short launches and, with few samples per pixel, less coherent waves
+        const uint32_t todo = std::min(remaining, spp - m.accumulated);
+        const uint32_t numBatches = (todo + perBatch - 1) / perBatch;
+        const uint32_t n = (todo + numBatches - 1) / numBatches;
         m.ensurePathState(static_cast<uint64_t>(n) * pixelsPadded);
         m.traceBatch(m.frameCount, n);
         m.frameCount += n;
@@ -1945,6 +2036,9 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "refill_min") mImpl->optRefillMin = static_cast<uint32_t>(value);
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);
+    else if (name == "sample_sort") mImpl->optSampleSort = value != 0;
+    else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
+    else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "reserve_samples")
     {

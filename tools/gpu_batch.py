@@ -6,9 +6,9 @@ sys.path.insert(0, ROOT)
 import rayfinder_amd as rf
 from rayfinder_amd import scenes
 pt, info = scenes.atrium()
-W, H, b, spp = 1920, 1080, 8, 512
+W, H, b, spp = 1920, 1080, 8, 1024
 cam = rf.fly_camera(W, H)
-for mpaths in [256, 512, 256, 512]:
+for mpaths in [512, 1024, 512]:
     r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, b, rf.make_sky(), 0.25), pt.scene(), max_paths_in_flight=mpaths << 20)
     r.render(spp); r.synchronize()
     best = 0
