@@ -9,7 +9,7 @@ from the reference mount), 1920x1080, 8 bounces, default camera and sky.
 
 A STEP is SPP_PER_STEP = 16 samples per pixel of the whole frame through the full wavefront pipeline
 (raygen -> [closest-hit traversal -> shade/NEE -> shadow traversal] x 8 -> sky -> accumulate); K timed steps = 16 K spp
-(the default K = 16 is config 3's 256 spp).  Samples are traced in equal batches of up to the tuned depth (512 Mi paths = 256 spp
+(the default K = 16 is config 3's 256 spp).  Samples are traced in equal batches of up to the tuned depth (1 Gi paths = 514 spp
 of a 1080p frame per batch; a rank that owns 1/N of the tiles traces N times as many samples per batch), whatever K
 is.  Inputs (scene, textures, tables) are resident in HBM before the timed region.  `value` = rays traced (closest-hit
 + shadow traversals, counted on the device) by all ranks per second.  With N > 1 the frame is tile-sharded (strong

@@ -100,7 +100,7 @@ typedef struct rf_renderer_descriptor
     rf_render_parameters render_params;
     uint32_t             max_width, max_height; /* maxFramebufferSize; 0 = render_params size */
     int32_t              device_ordinal;
-    uint64_t             max_paths_in_flight;   /* 0 = default (512 Mi paths per batch, 66 GB of path state) */
+    uint64_t             max_paths_in_flight;   /* 0 = default (1 Gi paths per batch; path state is allocated on demand: samples x pixels x 124 B) */
 } rf_renderer_descriptor;
 
 typedef struct rf_stats

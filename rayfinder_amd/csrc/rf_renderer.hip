@@ -1770,12 +1770,13 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.maxWidth = desc.maxWidth ? desc.maxWidth : desc.renderParams.width;
     m.maxHeight = desc.maxHeight ? desc.maxHeight : desc.renderParams.height;
     const uint64_t maxTiles = static_cast<uint64_t>((m.maxWidth + kTileSize - 1) / kTileSize) * ((m.maxHeight + kTileSize - 1) / kTileSize);
-    // 512 Mi paths per batch by default (66 GB of path state + queues out of 288 GB): later bounces of a batch keep ~15 % of
+    // 1 Gi paths per batch by default (133 GB of path state + queues out of 288 GB; allocated on demand, so a render only ever
+    // takes samples x pixels x 124 B): later bounces of a batch keep ~15 % of
     // the paths, a traversal launch needs millions of rays to fill 6144 persistent waves and to amortise its tail, and the
     // more samples of a pixel a batch holds, the closer the directions of the 64 direction-sorted samples that share a
     // wave (FrameParams::samplePerm).  Measured on the atrium, 1080p, Mrays/s: 64 Mi 5125, 128 Mi 5171, 256 Mi 5224 (before
-    // the sample sort); 256 Mi 5692, 512 Mi 5826 (with it).  Allocated on demand for the largest batch actually traced.
-    const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (512ull << 20);
+    // the sample sort); 256 Mi 5692, 512 Mi 5826 / 5796, 1 Gi 5983 (with it).
+    const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (1024ull << 20);
     // path slots and queue indices are 32-bit: at most 2^31 paths per batch, and one sample of the whole
     // (padded) frame must fit in a batch
     constexpr uint64_t kMaxPathsPerBatch = 1ull << 31;
