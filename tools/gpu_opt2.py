@@ -26,11 +26,11 @@ for rd in range(rounds):
         r.set_timing(True); r.reset_stats()
         t0 = time.perf_counter(); r.render(spp); r.synchronize(); dt = time.perf_counter() - t0
         s = r.stats()
-        res[v].append(((s["closest_rays"] + s["shadow_rays"]) / dt * 1e-6, s["ms_closest"], s["ms_shadow"], s["ms_shade"], s["ms_raygen"]))
+        res[v].append(((s["closest_rays"] + s["shadow_rays"]) / dt * 1e-6, s["ms_closest"], s["ms_shadow"], s["ms_shade"], s["ms_raygen"], s["ms_accumulate"]))
         img, _ = r.read_accumulation()
         if ref is None: ref = img
         elif not np.array_equal(img.view(np.uint32), ref.view(np.uint32)): print("IMAGE MISMATCH", v)
 for v in variants:
     a = np.array(res[v])
-    print(f"{v:40s} Mrays/s median {np.median(a[:,0]):8.1f} best {a[:,0].max():8.1f} | ms closest/shadow/shade/raygen (min) {a[:,1].min():7.2f} {a[:,2].min():7.2f} {a[:,3].min():7.2f} {a[:,4].min():6.2f}")
+    print(f"{v:40s} Mrays/s median {np.median(a[:,0]):8.1f} best {a[:,0].max():8.1f} | ms closest/shadow/shade/raygen/accumulate (min) {a[:,1].min():7.2f} {a[:,2].min():7.2f} {a[:,3].min():7.2f} {a[:,4].min():6.2f} {a[:,5].min():6.2f}")
 r.close()

@@ -95,7 +95,11 @@ K = "kTraceWide<false, false, false>"
 k = pm.get(K)
 if not k:
     raise SystemExit(f"{K} not found in the PMC summaries: {list(pm)}")
-rays = bench["roofline"]["rays_per_launch"]
+# rays behind the counters: every dispatch of the kernel in the profiled process = warm-up + timed steps (the counting pass
+# is off); the same frame is traced throughout, so rays scale with the samples.  `rays` = rays per AVERAGE dispatch.
+timed_rays = bench["roofline"]["rays_per_launch"] * bench["roofline"]["launches"]
+all_rays = timed_rays * (bench["steps"] + bench["warmup"]) / bench["steps"]
+rays = all_rays / k["_dispatches"]
 W, H = re.search(r"(\d+)x(\d+)", bench["config"]["workload"]).groups()
 B = re.search(r"(\d+) bounces", bench["config"]["workload"]).group(1)
 name = bench["config"]["workload"].split(" -- ")[0].split(", ")[0]
@@ -105,7 +109,7 @@ fc = factors["fetch_calibration"] or 1.0
 wc = factors["write_calibration"] or 1.0
 per_ray = dict(
     profile=os.path.basename(os.path.abspath(out)), kernel="kTraceWide<closest>", workload=f"{name} {W}x{H}x{B}",
-    rays_per_launch=rays, dispatches_averaged=k["_dispatches"],
+    rays_per_average_dispatch=round(rays), dispatches_averaged=k["_dispatches"], steps=bench["steps"], warmup=bench["warmup"],
     fetch_size_bytes_per_ray=round(fetch, 2), write_size_bytes_per_ray=round(write, 2),
     fetch_calibration=round(fc, 4), write_calibration=round(wc, 4),
     hbm_side_bytes_per_ray=round(fc * fetch + wc * write, 2),
