@@ -847,3 +847,58 @@ def test_courtyard_asset_bake_render_and_bench(tmp_path):
     line = json.loads(out.decode().strip().splitlines()[-1])
     assert line["value"] > 0 and line["nan_pixels"] == 0 and line["parity_crop"]["verdict"] == "bit-identical"
     assert "courtyard.pt" in line["config"]["workload"]
+
+
+# ------------------------------------------------------------------ round 2: scheduling choices never change a pixel
+def test_slot_order_batching_and_accumulation_variants_give_identical_images(duck_pt, duck_oracle):
+    """Path-slot order (sample-major / pixel groups of 1, 4, 64 pixels), direction-sorted samples, the LDS accumulation
+    kernel, kShade's grid cap and the batch size are scheduling decisions: the f32 sum image is the oracle's, bit for
+    bit, under every combination (odd frame size, spp that is not a multiple of anything, several batches)."""
+    W, H, spp, bounces = 150, 90, 23, 4
+    cam = rf.fly_camera(W, H)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.25, rf.aligned_sky_state(rf.make_sky()))
+    ref, _ = orc.render(duck_oracle.scene, rp, 0, spp)
+    variants = [dict(), dict(slot_group_shift=-1), dict(slot_group_shift=2), dict(slot_group_shift=6, sample_sort=0), dict(sample_sort=0),
+                dict(accumulate_runs=0), dict(shade_blocks=7), dict(slot_group_shift=10, accumulate_runs=0)]
+    for opts in variants:
+        for max_paths in (0, 5 * 15 * 1024):                  # default batch (all 23 samples at once) / 5 samples per batch -> 5, 5, 5, 4, 4
+            r, _ = _renderer(duck_pt, W, H, spp, bounces, cam=cam, max_paths_in_flight=max_paths)
+            for k, v in opts.items():
+                r.set_option(k, v)
+            r.render(spp)
+            img, acc = r.read_accumulation()
+            r.close()
+            assert acc == spp
+            assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3])), (opts, max_paths)
+
+
+def test_rf_render_cli_writes_the_tonemapped_image(duck_pt, tmp_path):
+    """rf-render (the offline twin of the `pt` app, --gpus 1 path): its PNG holds exactly rf_renderer_read_tonemapped's texels."""
+    import subprocess
+    import zlib
+    from conftest import ROOT
+    scene = tmp_path / "Duck.pt"
+    duck_pt.save(scene)
+    out = tmp_path / "duck.png"
+    W, H, spp, bounces = 96, 64, 4, 3
+    txt = subprocess.check_output([os.path.join(ROOT, "rayfinder_amd", "bin", "rf-render"), str(scene), "--width", str(W), "--height", str(H), "--spp", str(spp),
+                                   "--bounces", str(bounces), "--out", str(out), "--gpus", "1"]).decode()
+    assert f"{W}x{H}, {spp} spp, {bounces} bounces on 1 GPU(s)" in txt
+    data = open(out, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    idat = b""
+    off = 8
+    while off < len(data):
+        n = int.from_bytes(data[off:off + 4], "big"); typ = data[off + 4:off + 8]
+        if typ == b"IDAT":
+            idat += data[off + 8:off + 8 + n]
+        off += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 4 * W)
+    assert (raw[:, 0] == 0).all()
+    rgba = raw[:, 1:].reshape(H, W, 4)
+    r, _ = _renderer(duck_pt, W, H, spp, bounces)       # rf-render's defaults: fly camera, default sky, exposure 2 stops = 0.25
+    r.render(spp)
+    bgra = r.read_tonemapped()
+    r.close()
+    want = np.stack([(bgra >> 16) & 255, (bgra >> 8) & 255, bgra & 255, bgra >> 24], -1).astype(np.uint8)
+    assert np.array_equal(rgba, want)
