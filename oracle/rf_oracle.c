@@ -18,7 +18,14 @@
  *     mount, so it is unbuildable here and cannot be linked as oracle/_ref.            -> PINNED by
  *     the reference's test scenarios + the glm operation orders stated in SURVEY.md 8(a).
  *   - shading (WGSL rayColor): no reference test exists and WGSL cannot run here       -> PARITY
- *     UNPINNED for the shading stage; pinned only by analytic known answers in tests/.
+ *     UNPINNED for the shading stage (no reference-produced vector can exist); what stands in: analytic
+ *     known answers and an independent second restatement (tests/analytic_scene.py, float64, no BVH,
+ *     no shared code) that this file matches on multi-bounce paths (tests/test_oracle_pins.py).
+ *   - deferred-lighting variant (orc_deferred_frame): same status -- PARITY UNPINNED; its G-buffer comes
+ *     from primary rays where the reference rasterises, so it is not the reference's pixels by construction.
+ *   - where the reference leaves behaviour to its standard library or asserts (triangle order inside
+ *     multi-triangle leaves = std::partition; a node without a finite SAH cost), the documented choice is
+ *     libstdc++'s partition / "becomes a leaf", identical in the product's host and GPU builders.
  *
  * Floating point policy (the same policy is implemented independently by the HIP product):
  *   - all arithmetic IEEE f32, no FMA contraction (build with -ffp-contract=off), glm 0.9.9.8

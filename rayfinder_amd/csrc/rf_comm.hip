@@ -181,16 +181,24 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
 
     // one group: the root posts every receive at once, so all of its xGMI links carry data concurrently
     RF_NCCL(ncclGroupStart());
-    if (isRoot)
+    try
     {
-        for (uint32_t p = 0; p < m.world; ++p)
+        if (isRoot)
         {
-            if (tilesOf(p) == 0 || (p == root && !loopback)) continue;
-            RF_NCCL(ncclRecv(m.staging.p + static_cast<size_t>(g.rankFirstTile[p]) * kTilePixels, tilesOf(p) * floatsPerTile, ncclFloat, static_cast<int>(p), m.comm, stream));
+            for (uint32_t p = 0; p < m.world; ++p)
+            {
+                if (tilesOf(p) == 0 || (p == root && !loopback)) continue;
+                RF_NCCL(ncclRecv(m.staging.p + static_cast<size_t>(g.rankFirstTile[p]) * kTilePixels, tilesOf(p) * floatsPerTile, ncclFloat, static_cast<int>(p), m.comm, stream));
+            }
         }
+        if (tilesOf(m.rank) > 0 && (!isRoot || loopback))
+            RF_NCCL(ncclSend(compactDevice, tilesOf(m.rank) * floatsPerTile, ncclFloat, static_cast<int>(root), m.comm, stream));
     }
-    if (tilesOf(m.rank) > 0 && (!isRoot || loopback))
-        RF_NCCL(ncclSend(compactDevice, tilesOf(m.rank) * floatsPerTile, ncclFloat, static_cast<int>(root), m.comm, stream));
+    catch (...)
+    {
+        (void)ncclGroupEnd(); // never leave the thread inside an open group
+        throw;
+    }
     RF_NCCL(ncclGroupEnd());
     if (!isRoot) return nullptr;
 

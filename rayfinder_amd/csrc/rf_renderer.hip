@@ -1572,7 +1572,9 @@ struct Renderer::Impl
         fp.pixelsPadded = fp.numTiles * 1024u;
         fp.slotGroupShift = optSlotGroupShift;
         fp.samplePerm = fp.sampleInvPerm = nullptr;
-        if (optSampleSort && numSamples > 1 && optSlotGroupShift != kSlotSampleMajor)
+        // (kSamplePermutation ranks by counting, O(S^2): fine for the few hundred samples a batch of a real frame holds,
+        // skipped for the huge sample counts a tiny frame can put into one batch)
+        if (optSampleSort && numSamples > 1 && numSamples <= 8192 && optSlotGroupShift != kSlotSampleMajor)
         {
             if (samplePerm.count < 2ull * numSamples) samplePerm.alloc(2ull * numSamples); // (the stream is idle the first time; later batches are no larger)
             fp.samplePerm = samplePerm.ptr;
