@@ -529,6 +529,7 @@ constexpr uint32_t kRefillMin = 40; // refill once this many lanes are idle (r02
 constexpr uint32_t kLeafVote = 20; // leave the descent loop when fewer lanes than this are descending (16..24 measure the same)
 
 constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
+constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path for records that every descending lane shares
 constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
 
 // Lane state of kTraceWide lives in ONE register, the next thing to visit: a child word of
@@ -587,6 +588,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
     const uint32_t   lane = __lane_id();
     const bool       shadowDirFromStream = flags & kFlagShadowDirFromStream;
     const bool       firstBounce = flags & kFlagFirstBounce;
+    const bool       uniformFetch = flags & kFlagUniformFetch;
 
     // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
     // shard of its block and moves on round-robin when a shard is dry.
@@ -705,15 +707,43 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             if (static_cast<int32_t>(node) >= 0)
             {
                 if (COUNT) ++recordFetches;
-                const float4*  n = wide.nodes + 4 * static_cast<size_t>(node);
-                // 56 of the record's 64 bytes: the L1 -> VGPR return path (64 B/clk/CU, TD_TD_BUSY > 85 % in every
-                // bounce) is what bounds this kernel, so nothing is loaded that is not used
-                const float4   q0 = n[0], q1 = n[1], q2 = n[2];
-                // (the pointer goes through an empty asm so that the compiler forgets its 16-byte alignment and
-                // cannot widen the 8-byte load back to a dwordx4)
-                const uint2* wordPtr = reinterpret_cast<const uint2*>(n + 3);
-                asm volatile("" : "+v"(wordPtr));
-                const uint2 words = *wordPtr;
+                float4 q0, q1, q2;
+                uint2  words;
+                // With the pixel-major, direction-sorted slot order the 64 rays of a wave are one pixel's samples, and at
+                // bounce 1 (and for the first steps of any freshly filled wave) every descending lane sits at the SAME
+                // record.  Then the record comes through the scalar cache with three s_load instructions instead of
+                // 4 x 64 per-lane vector loads of one line: no vector-L1 traffic at all for that step.  Same bytes, same
+                // arithmetic -- only the path the record takes to the registers differs.
+                const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
+                if (uniformFetch && __ballot(node != uNode) == 0ull)
+                {
+                    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                    const float4* un = wide.nodes + 4 * static_cast<size_t>(uNode);
+                    u8v           a;
+                    u4v           b;
+                    u2v           c;
+                    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&s"(a), "=&s"(b), "=&s"(c)
+                                 : "s"(un)
+                                 : "memory");
+                    q0 = make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3));
+                    q1 = make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7));
+                    q2 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+                    words = make_uint2(c.x, c.y);
+                }
+                else
+                {
+                    const float4* n = wide.nodes + 4 * static_cast<size_t>(node);
+                    // 56 of the record's 64 bytes: nothing is loaded that is not used
+                    q0 = n[0], q1 = n[1], q2 = n[2];
+                    // (the pointer goes through an empty asm so that the compiler forgets its 16-byte alignment and
+                    // cannot widen the 8-byte load back to a dwordx4)
+                    const uint2* wordPtr = reinterpret_cast<const uint2*>(n + 3);
+                    asm volatile("" : "+v"(wordPtr));
+                    words = *wordPtr;
+                }
                 const uint32_t axis = (words.x >> kWideAxisShift) & 3u;
                 const uint32_t word0 = words.x & ~(3u << kWideAxisShift), word1 = words.y;
                 float          t0, t1;
@@ -1359,6 +1389,7 @@ struct Renderer::Impl
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
     bool                   optSampleSort = true, optAccumulateRuns = true;
+    int                    optUniformFetch = 1; // scalar-cache record fetch for wave-uniform steps: 1 = always (r02 A/B: 5924 -> 6086 Mrays/s), 0 = never, -1 = bounces 1-2 only
     DeviceBuffer<uint32_t> samplePerm;
     uint32_t optSlotGroupShift = 0; // see FrameParams::slotGroupShift (r02 A/B on the atrium, Mrays/s: sample-major 5282; unsorted g = 6: 5416, 2: 5507, 0: 5450; with sorted samples g = 2: 5519, 1: 5589, 0: 5650)
     RenderStats hostStats;
@@ -1617,6 +1648,7 @@ struct Renderer::Impl
             uint32_t* countOut = queueCounts.ptr + kLine * bounce;
             uint32_t* cursorClosest = cursors + kLine * kShards * 2 * (bounce - 1);
             uint32_t* cursorShadow = cursorClosest + kLine * kShards;
+            const uint32_t uniformFlag = (optUniformFetch < 0 ? bounce <= 2 : optUniformFetch > 0) ? kFlagUniformFetch : 0u;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
                 {
@@ -1627,16 +1659,16 @@ struct Renderer::Impl
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
                 else
                     hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, 0u);
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
             }, bounce - 1);
             launchTimed(2, [&] {
                 hipLaunchKernelGGL(kShade, dim3(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
                                    (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u));
             });
-            const uint32_t shadowFlags = bounce == 1 ? kFlagFirstBounce : 0u;
+            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag;
             launchTimed(3, [&] {
                 if (traversalVariant == 0)
                 {
@@ -2085,6 +2117,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);
     else if (name == "sample_sort") mImpl->optSampleSort = value != 0;
     else if (name == "accumulate_runs") mImpl->optAccumulateRuns = value != 0;
+    else if (name == "uniform_fetch") mImpl->optUniformFetch = static_cast<int>(value);
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
