@@ -529,6 +529,7 @@ constexpr uint32_t kRefillMin = 40; // refill once this many lanes are idle (r02
 constexpr uint32_t kLeafVote = 20; // leave the descent loop when fewer lanes than this are descending (16..24 measure the same)
 
 constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
+constexpr uint32_t kFlagUniformTri = 8u;          // the same for the triangles of a leaf phase
 constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path for records that every descending lane shares
 constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
 
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
     const uint32_t   lane = __lane_id();
     const bool       shadowDirFromStream = flags & kFlagShadowDirFromStream;
     const bool       firstBounce = flags & kFlagFirstBounce;
-    const bool       uniformFetch = flags & kFlagUniformFetch;
+    const bool       uniformFetch = flags & kFlagUniformFetch, uniformTri = flags & kFlagUniformTri;
 
     // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
     // shard of its block and moves on round-robin when a shard is dry.
@@ -836,12 +837,30 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             {
                 if (COUNT) ++wLeaf;
                 const uint32_t tri = first + i;
-                const v3f      a = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri);
-                const v3f      b = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 1);
-                const v3f      c = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 2);
+                Vec3           p0, p1, p2;
+                // the same triangle in every lane of this leaf phase (one pixel's samples reaching the same leaf): scalar cache
+                const uint32_t uTri = __builtin_amdgcn_readfirstlane(tri);
+                if (uniformTri && __ballot(tri != uTri) == 0ull)
+                {
+                    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                    const float4* ut = scene.triangles + kTriStride * static_cast<size_t>(uTri);
+                    u8v           ab;
+                    u4v           cc;
+                    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ab), "=&s"(cc) : "s"(ut) : "memory");
+                    p0 = vec3(__uint_as_float(ab.s0), __uint_as_float(ab.s1), __uint_as_float(ab.s2));
+                    p1 = vec3(__uint_as_float(ab.s4), __uint_as_float(ab.s5), __uint_as_float(ab.s6));
+                    p2 = vec3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
+                }
+                else
+                {
+                    const v3f a = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri);
+                    const v3f b = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 1);
+                    const v3f c = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 2);
+                    p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
+                }
                 if (COUNT) ++rayTris;
                 TriangleHit th;
-                const Vec3  p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
                 if (intersectTriangle(vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, p0, p1, p2, rayTMax, th))
                 {
                     if (ANY_HIT)
@@ -1389,7 +1408,7 @@ struct Renderer::Impl
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
     bool                   optSampleSort = true, optAccumulateRuns = true;
-    int                    optUniformFetch = 1; // scalar-cache record fetch for wave-uniform steps: 1 = always (r02 A/B: 5924 -> 6086 Mrays/s), 0 = never, -1 = bounces 1-2 only
+    int                    optUniformFetch = 2; // scalar-cache fetch for wave-uniform steps: 0 = never (5 878 Mrays/s), 1 = records (6 039), 2 = records + leaf triangles (6 059), -1 = records at bounces 1-2 only
     DeviceBuffer<uint32_t> samplePerm;
     uint32_t optSlotGroupShift = 0; // see FrameParams::slotGroupShift (r02 A/B on the atrium, Mrays/s: sample-major 5282; unsorted g = 6: 5416, 2: 5507, 0: 5450; with sorted samples g = 2: 5519, 1: 5589, 0: 5650)
     RenderStats hostStats;
@@ -1648,7 +1667,7 @@ struct Renderer::Impl
             uint32_t* countOut = queueCounts.ptr + kLine * bounce;
             uint32_t* cursorClosest = cursors + kLine * kShards * 2 * (bounce - 1);
             uint32_t* cursorShadow = cursorClosest + kLine * kShards;
-            const uint32_t uniformFlag = (optUniformFetch < 0 ? bounce <= 2 : optUniformFetch > 0) ? kFlagUniformFetch : 0u;
+            const uint32_t uniformFlag = ((optUniformFetch < 0 ? bounce <= 2 : optUniformFetch > 0) ? kFlagUniformFetch : 0u) | (optUniformFetch >= 2 ? kFlagUniformTri : 0u);
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
                 {
