@@ -185,6 +185,12 @@ def main():
         ids = [rf.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         comm = rf.TileComm(ids[0], rank, world, local_rank)
+    exchange = "none" if world == 1 else "C++ RCCL exchange (rf_renderer_gather_frame: grouped ncclSend/ncclRecv + device un-tile)"
+
+    def all_ranks_ok(ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
 
     W, H, K, WU, B = args.width, args.height, max(args.steps, 1), max(args.warmup, 0), args.bounces
     spp, warm_spp = SPP_PER_STEP * K, SPP_PER_STEP * WU
@@ -196,6 +202,37 @@ def main():
     sky = rf.make_sky()
     r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25), pt.scene(), device_ordinal=local_rank)
     r.set_tile_shard(rank, world)
+    accum = None
+    if comm is not None:
+        # self-test of the exchange before anything is timed.  The C++ path has only ever run at world size 1 on the
+        # builder's single-GPU boxes; should it throw here on any rank, every rank falls back -- loudly, and named in the JSON
+        # line -- to the round-1 plumbing (torch.distributed.gather of the compact buffers + host un-tile) so that a
+        # scaling curve still exists.  (A hang cannot be caught; the layout arithmetic both sides share is tested under gloo.)
+        err = ""
+        try:
+            r.gather_frame(comm, 0)
+            r.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = str(e)
+        if not all_ranks_ok(err == ""):
+            log(f"[bench] rank {rank}: C++ RCCL exchange FAILED ({err or 'on another rank'}); falling back to torch.distributed.gather")
+            exchange = f"FALLBACK torch.distributed.gather + host un-tile (the C++ RCCL exchange failed: {err or 'on another rank'})"
+            comm.close()
+            comm = None
+            from rayfinder_amd.sharding import shard_layout
+            _, max_tiles = shard_layout(W, H, rank, world)
+            accum = torch.zeros((max_tiles * 1024, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+            r.bind_accumulation_buffer(accum.data_ptr(), accum.numel() * 4)
+
+    def exchange_frame():
+        if comm is not None:
+            r.gather_frame(comm, 0)
+            return None
+        if accum is not None:
+            from rayfinder_amd.sharding import gather_device
+            r.synchronize()
+            return gather_device(accum, rank, world)
+        return None
 
     def barrier():
         r.synchronize()
@@ -208,8 +245,7 @@ def main():
     r.set_option("reserve_samples", spp)
     if warm_spp:
         r.render(warm_spp)
-    if comm is not None:
-        r.gather_frame(comm, 0)
+    exchange_frame()
     r.synchronize()
     # restart the accumulation (frameCount keeps counting: the timed frames are warm_spp .. warm_spp + spp - 1, i.e. the
     # sample indices 0..spp-1 rotated by warm_spp)
@@ -224,8 +260,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     r.render(spp)
-    if comm is not None:
-        r.gather_frame(comm, 0)
+    parts = exchange_frame()
     r.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -252,7 +287,13 @@ def main():
     # the frame of the timed region (read-back outside the timed region for every N)
     image = None
     if rank == 0:
-        image = comm.read_frame(r, W, H) if comm is not None else r.read_accumulation()[0]
+        if comm is not None:
+            image = comm.read_frame(r, W, H)
+        elif parts is not None:
+            from rayfinder_amd.sharding import assemble
+            image = assemble(parts, W, H, world)
+        else:
+            image = r.read_accumulation()[0]
 
     # counting pass (untimed): node visits / triangle tests of exactly the timed frames on this rank
     cs = None
@@ -333,7 +374,7 @@ def main():
                                    f"{SPP_PER_STEP} spp per step x {K} steps = {spp} spp, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
                        "spp_per_step": SPP_PER_STEP, "spp": spp,
                        "scene_triangles": info.get("triangles"), "scene_textures": info.get("textures"), "scene_digest": info.get("digest"),
-                       "sharding": f"32x32 tiles, scrambled round-robin over {world} rank(s), one RCCL gather (grouped ncclSend/ncclRecv + device un-tile) at frame end" if world > 1 else "none"},
+                       "sharding": f"32x32 tiles, scrambled round-robin over {world} rank(s), one exchange at frame end: {exchange}" if world > 1 else "none"},
             "timed_region_s": round(elapsed, 4),
             "paths_per_s": round(paths_total / elapsed, 1),
             "rays": {"closest": int(closest_total), "shadow": int(shadow_total), "abandoned": int(abandoned_total)},
