@@ -374,7 +374,7 @@ def main():
                                    f"{SPP_PER_STEP} spp per step x {K} steps = {spp} spp, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
                        "spp_per_step": SPP_PER_STEP, "spp": spp,
                        "scene_triangles": info.get("triangles"), "scene_textures": info.get("textures"), "scene_digest": info.get("digest"),
-                       "sharding": f"32x32 tiles, scrambled round-robin over {world} rank(s), one exchange at frame end: {exchange}" if world > 1 else "none"},
+                       "sharding": f"32x32 tiles along a Z-order curve dealt round-robin (rotated per block) over {world} rank(s), one exchange at frame end: {exchange}" if world > 1 else "none"},
             "timed_region_s": round(elapsed, 4),
             "paths_per_s": round(paths_total / elapsed, 1),
             "rays": {"closest": int(closest_total), "shadow": int(shadow_total), "abandoned": int(abandoned_total)},

@@ -692,13 +692,35 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             if (static_cast<int32_t>(node) >= 0)
             {
                 if (COUNT) ++recordFetches;
+                uint2 words;
+                float t0, t1;
+                bool  ok0, ok1, hasNaN = false;
+#if defined(RF_ABLATE)
                 float4 q0, q1, q2;
-                uint2  words;
+#endif
+                // both boxes of the record against the lane's ray; class B rays (0 * inf possible) also check that the packed
+                // test is the reference's here (rf_wide.hpp)
+                const auto slabStep = [&](float4 a0, float4 a1, float4 a2) {
+                    float far0, far1;
+                    slabPairBounds(pr, a0, a1, a2, t0, far0, t1, far1);
+                    // (the four results are pinned here so that the min/max chains stay in the basic block of their products:
+                    // behind the rare branch below, the compiler no longer knows the products to be canonical and spends twelve
+                    // v_max x,x on quieting them)
+                    asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1));
+                    if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2);
+                    ok0 = t0 <= far0 && far0 > 0.0f;
+                    ok1 = t1 <= far1 && far1 > 0.0f;
+#if defined(RF_ABLATE)
+                    q0 = a0, q1 = a1, q2 = a2;
+#endif
+                };
                 // With the pixel-major, direction-sorted slot order the 64 rays of a wave are one pixel's samples, and at
                 // bounce 1 (and for the first steps of any freshly filled wave) every descending lane sits at the SAME
                 // record.  Then the record comes through the scalar cache with three s_load instructions instead of
                 // 4 x 64 per-lane vector loads of one line: no vector-L1 traffic at all for that step.  Same bytes, same
-                // arithmetic -- only the path the record takes to the registers differs.
+                // arithmetic -- only the path the record takes to the registers differs.  The slab arithmetic is issued
+                // inside each branch, so that on this one its box operands stay in SGPRs (bounce 1 is VALU-issue bound:
+                // copying the 14 dwords into VGPRs first cost 14 of the ~85 VALU instructions of a step).
                 const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
                 if (uniformFetch && __ballot(node != uNode) == 0ull)
                 {
@@ -713,36 +735,34 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
                                  : "=&s"(a), "=&s"(b), "=&s"(c)
                                  : "s"(un)
                                  : "memory");
-                    q0 = make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3));
-                    q1 = make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7));
-                    q2 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+                    slabStep(make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
+                             make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)),
+                             make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)));
                     words = make_uint2(c.x, c.y);
                 }
                 else
                 {
                     const float4* n = wide.nodes + 4 * static_cast<size_t>(node);
                     // 56 of the record's 64 bytes: nothing is loaded that is not used
-                    q0 = n[0], q1 = n[1], q2 = n[2];
+                    const float4 v0 = n[0], v1 = n[1], v2 = n[2];
                     // (the pointer goes through an empty asm so that the compiler forgets its 16-byte alignment and
-                    // cannot widen the 8-byte load back to a dwordx4)
+                    // cannot widen the 8-byte load back to a dwordx4; it comes back as a GLOBAL pointer -- a generic one
+                    // makes the load a flat_load, which also counts against lgkmcnt)
                     const uint2* wordPtr = reinterpret_cast<const uint2*>(n + 3);
                     asm volatile("" : "+v"(wordPtr));
-                    words = *wordPtr;
+                    typedef const unsigned long long __attribute__((address_space(1)))* GlobalWordPtr;
+                    const unsigned long long both = *(GlobalWordPtr)(wordPtr);
+                    words = make_uint2(static_cast<uint32_t>(both), static_cast<uint32_t>(both >> 32));
+                    slabStep(v0, v1, v2);
                 }
                 const uint32_t axis = (words.x >> kWideAxisShift) & 3u;
                 const uint32_t word0 = words.x & ~(3u << kWideAxisShift), word1 = words.y;
-                float          t0, t1;
-                bool           ok0, ok1;
-                slabPair(pr, q0, q1, q2, ok0, t0, ok1, t1);
-                if (__builtin_expect((negMask & 8u) != 0u, 0))
+                if (__builtin_expect(hasNaN, 0))
                 {
                     // class B ray: a 0 * inf product means the packed test is not the reference's here
-                    if (slabPairHasNaN(pr, q0, q1, q2))
-                    {
-                        needScalar = true;
-                        ok0 = ok1 = false;
-                        stackSize = 0; // -> popNext() ends the ray; it is redone below
-                    }
+                    needScalar = true;
+                    ok0 = ok1 = false;
+                    stackSize = 0; // -> popNext() ends the ray; it is redone below
                 }
 #if defined(RF_ABLATE) && RF_ABLATE == 1
                 {   // ablation: the slab arithmetic twice more (result kept alive, never different)
@@ -933,6 +953,262 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// kTracePacket: 64 consecutive queue entries = ONE packet that walks the tree in lockstep.
+//
+// With the pixel-major, direction-sorted slot order the 64 rays of a wave at bounce 1 are 64 samples of one pixel:
+// (almost) one origin, one direction.  Such a wave does not need 64 private traversals.  The packet runs the
+// reference's depth-first order ONCE -- wave-uniform node, wave-uniform stack, records and triangles through the
+// scalar cache (s_load: no vector-L1 traffic for the tree at all), scalar branches -- and every lane carries only its
+// own ray, its own rayTMax and an `active` bit:
+//
+//   at a record:   hitN/hitF per lane as in kTraceWide (P(child) && tmin < rayTMax, for lanes active at this node);
+//                  any lane enters near -> the packet enters near with active = hitN, and far is pushed (if any lane
+//                  hits it) with EVERY lane's own tmin (+inf for lanes that do not hit it); no lane near but some far
+//                  -> the packet enters far directly; none -> pop
+//   at a pop:      active = (the lane's stored tmin < the lane's rayTMax NOW) -- the reference's test at pop time;
+//                  an entry no lane wants is skipped
+//   at a leaf:     the active lanes test the leaf's triangles in order.
+//
+// A lane is active at a node iff its own traversal would visit that node, and the nodes at which it is active come in
+// its own depth-first order PROVIDED the near/far order is the lane's: the order is dirNeg[splitAxis] (wgsl:409-417),
+// so a closest-hit packet is formed of lanes with equal direction signs (a wave with mixed signs -- pixels on the
+// screen's axes -- runs one pass per sign pattern).  Its rayTMax therefore evolves exactly as in the reference and
+// hit{triangle,u,v,t} are bit-identical.  Any-hit packets take all lanes at once and choose the order by vote (the
+// visibility bit does not depend on the order: see NEAREST_FIRST above); an occluded lane drops out with rayTMax = -inf.
+// Rays that are not class A (rf_wide.hpp), and the members of a packet whose shared stack outgrows kPacketDepth, are
+// redone by the scalar reference-ordered traversal, as in kTraceWide.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPacketDepth = 24; // shared stack entries per wave (<= 64): per-lane tmin [depth][lane] in LDS + one child word per entry
+
+template<bool ANY_HIT>
+__global__ __launch_bounds__(kBlock, 6) void kTracePacket(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
+                                                          const uint32_t* queue, const uint32_t* queueCount, DeviceCounters* counters, float tMax, uint32_t flags)
+{
+    __shared__ float    sTMin[kPacketDepth * kBlock];
+    const uint32_t      count = *queueCount;
+    const uint32_t      lane = __lane_id(), wave = threadIdx.x >> 6;
+    const bool          shadowDirFromStream = flags & kFlagShadowDirFromStream;
+    const bool          firstBounce = flags & kFlagFirstBounce;
+    const float         kInf = __uint_as_float(0x7F800000u);
+    float* const        myTMin = sTMin + threadIdx.x;
+    const uint32_t      numChunks = (count + 63u) / 64u;
+    const uint32_t      totalWaves = gridDim.x * (kBlock / 64);
+
+    for (uint32_t chunkIdx = blockIdx.x * (kBlock / 64) + wave; chunkIdx < numChunks; chunkIdx += totalWaves)
+    {
+        const uint32_t idx = chunkIdx * 64u + lane;
+        const bool     valid = idx < count;
+        uint32_t       slot = 0;
+        Vec3           o = vec3(0.0f, 0.0f, 0.0f), dir = vec3(0.0f, 0.0f, 1.0f);
+        if (valid)
+        {
+            slot = loadQ(queue + idx);
+            o = load3s(ps.rayO + slot);
+            if (ANY_HIT && !shadowDirFromStream)
+            {
+                const Vec3 nz = load3s(ps.noise + slot);
+                dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
+            }
+            else dir = load3s(ps.rayD + slot);
+        }
+        const RayPrep   ray = prepareRay(o, dir);
+        const PackedRay pr = packRay(ray);
+        const uint32_t  rayClass = classifyRay(ray);
+        const uint32_t  negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2);
+        bool            needScalar = valid && rayClass != kRayPlain;
+        const bool      regular = valid && rayClass == kRayPlain;
+        float           rootTMin;
+        const bool      rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin);
+        ClosestHit      best{};
+        best.triangle = kMiss;
+        float resultT = tMax;  // closest: t of the hit (tMax: none); any-hit: -inf once occluded
+        bool  occluded = false;
+
+        unsigned long long todo = __ballot(regular);
+        while (todo != 0ull)
+        {
+            // members of this pass: closest-hit -- the lanes that share the first waiting lane's direction signs
+            bool member = regular;
+            if (!ANY_HIT)
+            {
+                const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(todo))) - 1u;
+                const uint32_t uNeg = __builtin_amdgcn_readlane(negMask, leader);
+                member = regular && ((todo >> lane) & 1ull) != 0ull && negMask == uNeg;
+            }
+            const unsigned long long memberMask = __ballot(member);
+            todo &= ~memberMask;
+            const uint32_t passNeg = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(negMask, static_cast<uint32_t>(__ffsll(static_cast<long long>(memberMask))) - 1u));
+
+            float limit = member ? tMax : -kInf; // the lane's rayTMax; -inf: every comparison `t < limit` fails
+            bool  active = rootOk && rootTMin < limit;
+            if (__ballot(active) == 0ull) continue;
+            uint32_t node = wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u;
+            int      depth = 0;
+            bool     overflow = false;
+            uint32_t wordStack = 0; // the shared stack's child words: entry d lives in lane d of this register (v_writelane / v_readlane)
+            for (;;)
+            {
+                node = __builtin_amdgcn_readfirstlane(node);
+                bool popNow = false;
+                if (static_cast<int32_t>(node) >= 0)
+                {
+                    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                    const float4* un = wide.nodes + 4 * static_cast<size_t>(node);
+                    u8v           a;
+                    u4v           b;
+                    u2v           c;
+                    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&s"(a), "=&s"(b), "=&s"(c)
+                                 : "s"(un)
+                                 : "memory");
+                    const float4   q0 = make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3));
+                    const float4   q1 = make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7));
+                    const float4   q2 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+                    const uint32_t axis = (c.x >> kWideAxisShift) & 3u;
+                    const uint32_t word0 = c.x & ~(3u << kWideAxisShift), word1 = c.y;
+                    float          t0, t1;
+                    bool           ok0, ok1;
+                    slabPair(pr, q0, q1, q2, ok0, t0, ok1, t1);
+                    const bool hit0 = active && ok0 && t0 < limit, hit1 = active && ok1 && t1 < limit;
+                    const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
+                    // which child is "near": the reference's split-axis order (closest-hit), a vote (any-hit)
+                    bool secondFirst;
+                    if (ANY_HIT) secondFirst = 2 * __popcll(__ballot(hit0 && hit1 && t1 < t0)) > __popcll(m0 & m1);
+                    else secondFirst = ((passNeg >> axis) & 1u) != 0u;
+                    const unsigned long long mN = secondFirst ? m1 : m0, mF = secondFirst ? m0 : m1;
+                    const uint32_t           nearWord = secondFirst ? word1 : word0, farWord = secondFirst ? word0 : word1;
+                    const bool               hitN = secondFirst ? hit1 : hit0, hitF = secondFirst ? hit0 : hit1;
+                    const float              tF = secondFirst ? t0 : t1;
+                    if (mN != 0ull)
+                    {
+                        if (mF != 0ull)
+                        {
+                            if (depth >= kPacketDepth)
+                            {
+                                overflow = true;
+                                break;
+                            }
+                            myTMin[depth * kBlock] = hitF ? tF : kInf;
+                            {
+                                // v_writelane takes its lane select from m0 when the value is an SGPR too (constant-bus limit); m0 is put back
+                                uint32_t keepM0;
+                                asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                             : "+v"(wordStack), "=&s"(keepM0)
+                                             : "s"(farWord), "s"(depth));
+                            }
+                            ++depth;
+                        }
+                        node = nearWord;
+                        active = hitN;
+                    }
+                    else if (mF != 0ull)
+                    {
+                        node = farWord;
+                        active = hitF;
+                    }
+                    else popNow = true;
+                }
+                else
+                {
+                    // ---- leaf: the active lanes test its triangles in order
+                    uint32_t first = node & ((1u << kWideIndexBits) - 1u), n = ((node >> kWideIndexBits) & 7u) + 1u;
+                    if (n == 8u)
+                    {
+                        const uint2 big = wide.bigLeaves[first];
+                        first = __builtin_amdgcn_readfirstlane(big.x);
+                        n = __builtin_amdgcn_readfirstlane(big.y);
+                    }
+                    for (uint32_t i = 0; i < n; ++i)
+                    {
+                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                        const uint32_t tri = first + i;
+                        const float4*  ut = scene.triangles + kTriStride * static_cast<size_t>(tri);
+                        u8v            ab;
+                        u4v            cc;
+                        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ab), "=&s"(cc) : "s"(ut) : "memory");
+                        const Vec3 p0 = vec3(__uint_as_float(ab.s0), __uint_as_float(ab.s1), __uint_as_float(ab.s2));
+                        const Vec3 p1 = vec3(__uint_as_float(ab.s4), __uint_as_float(ab.s5), __uint_as_float(ab.s6));
+                        const Vec3 p2 = vec3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
+                        TriangleHit th;
+                        if (active && intersectTriangle(o, dir, p0, p1, p2, limit, th))
+                        {
+                            if (ANY_HIT)
+                            {
+                                occluded = true;
+                                limit = -kInf;
+                                active = false;
+                            }
+                            else
+                            {
+                                limit = th.t;
+                                best.u = th.u;
+                                best.v = th.v;
+                                best.triangle = tri;
+                            }
+                        }
+                    }
+                    if (ANY_HIT && __ballot(member && !occluded) == 0ull) break; // every member has its answer
+                    popNow = true;
+                }
+                if (popNow)
+                {
+                    bool found = false;
+                    while (depth > 0)
+                    {
+                        --depth;
+                        const float tm = myTMin[depth * kBlock];
+                        active = tm < limit;
+                        if (__ballot(active) != 0ull)
+                        {
+                            node = __builtin_amdgcn_readlane(wordStack, static_cast<uint32_t>(depth));
+                            found = true;
+                            break;
+                        }
+                    }
+                    if (!found) break;
+                }
+            }
+            if (overflow)
+            {
+                // deeper than the shared stack: the members of this pass are redone one by one
+                if (member)
+                {
+                    needScalar = true;
+                    best.triangle = kMiss;
+                    occluded = false;
+                }
+            }
+            else if (member) resultT = limit;
+        }
+
+        if (needScalar)
+        {
+            TraversalCounters c2;
+            atomicAdd(&counters->scalarRedo[ANY_HIT ? 1 : 0], 1ull);
+            best.triangle = kMiss;
+            occluded = traverse<ANY_HIT, false, 0>(scene, o, dir, tMax, nullptr, best, c2);
+            if (c2.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
+            resultT = best.triangle != kMiss ? best.t : tMax;
+        }
+        if (valid)
+        {
+            if (ANY_HIT)
+            {
+                const float visibility = occluded ? 0.0f : 1.0f;
+                const Vec3  add = (load3s(ps.pending + slot) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3  radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add;
+                store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
+            }
+            else store4s(ps.hit + slot, __uint_as_float(best.triangle), best.u, best.v, resultT);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
+}
 
 // Query path: offset hit points of a hit stream (the render path does this in kShade).
 __global__ void kHitPoints(DeviceScene scene, const float4* hit, float4* rayO, uint32_t n)
@@ -1288,14 +1564,18 @@ struct DeviceBuffer
     ~DeviceBuffer() { release(); }
 };
 
-uint32_t scramble(uint32_t v)
+// Morton (Z-order) key of a tile position
+uint32_t tileMortonKey(uint32_t tx, uint32_t ty)
 {
-    v ^= v >> 16;
-    v *= 0x7feb352du;
-    v ^= v >> 15;
-    v *= 0x846ca68bu;
-    v ^= v >> 16;
-    return v;
+    const auto spread = [](uint32_t v) {
+        v &= 0xFFFFu;
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        v = (v | (v << 1)) & 0x55555555u;
+        return v;
+    };
+    return spread(tx) | (spread(ty) << 1);
 }
 } // namespace
 
@@ -1307,12 +1587,18 @@ std::vector<uint32_t> tilesForRank(uint32_t width, uint32_t height, uint32_t ran
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
     if (worldSize > 1)
     {
-        // scrambled order dealt round-robin: neighbouring tiles (similar cost: sky vs interior)
-        // land on different ranks, and every rank gets n/world +-1 tiles
-        std::stable_sort(order.begin(), order.end(), [](uint32_t a, uint32_t b) { return scramble(a) < scramble(b); });
+        // Tiles walked along a Z-order curve; each run of `world` consecutive tiles of the curve -- a compact block of the image
+        // (4x2 tiles for 8 ranks, 2x2 for 4) -- is split over all ranks, and the deal is rotated by one rank from block to block so
+        // that no rank always gets the same corner of a block (tile cost has a vertical gradient: a fixed position is a
+        // systematic bias).  Every rank gets n/world +-1 tiles.  Neighbouring tiles cost about the same (sky vs interior), so the
+        // ranks' loads are stratified samples of the frame: on the atrium at 1080p the busiest of 8 ranks traces 1.0 % more rays
+        // than the mean, against 3.0 % for the hashed deal used before (3.6 % unrotated); the strong-scaling time is the
+        // slowest rank's.
+        std::stable_sort(order.begin(), order.end(), [tilesX](uint32_t a, uint32_t b) { return tileMortonKey(a % tilesX, a / tilesX) < tileMortonKey(b % tilesX, b / tilesX); });
     }
     std::vector<uint32_t> mine;
-    for (uint32_t i = rank; i < n; i += worldSize) mine.push_back(order[i]);
+    for (uint32_t i = 0; i < n; ++i)
+        if ((i % worldSize + i / worldSize) % worldSize == rank) mine.push_back(order[i]);
     std::sort(mine.begin(), mine.end());
     return mine;
 }
@@ -1392,6 +1678,8 @@ struct Renderer::Impl
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
     bool                   optSampleSort = true, optAccumulateRuns = true;
+    uint32_t               optExtraLds = 0;      // experiment: dynamic LDS bytes added to the kTraceWide launches (lowers the occupancy)
+    uint32_t               optPacketBounces = 0; // bounces 1..n traced by kTracePacket (one wave = one lockstep packet) instead of kTraceWide
     int                    optUniformFetch = 2; // scalar-cache fetch for wave-uniform steps: 0 = never (5 878 Mrays/s), 1 = records (6 039), 2 = records + leaf triangles (6 059), -1 = records at bounces 1-2 only
     DeviceBuffer<uint32_t> samplePerm;
     uint32_t optSlotGroupShift = 0; // see FrameParams::slotGroupShift (r02 A/B on the atrium, Mrays/s: sample-major 5282; unsorted g = 6: 5416, 2: 5507, 0: 5450; with sorted samples g = 2: 5519, 1: 5589, 0: 5650)
@@ -1663,8 +1951,10 @@ struct Renderer::Impl
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
+                else if (bounce <= optPacketBounces)
+                    hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
                 else
-                    hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                    hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
             }, bounce - 1);
             launchTimed(2, [&] {
@@ -1680,13 +1970,16 @@ struct Renderer::Impl
                     else
                         hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
                 }
+                else if (!counting && bounce <= optPacketBounces)
+                    hipLaunchKernelGGL((kTracePacket<true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, counters.ptr, kTMax,
+                                       shadowFlags & kFlagFirstBounce);
                 else if (shadowNearestFirst)
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                     else
-                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                 }
                 else if (counting)
@@ -1845,6 +2138,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, 0));
         m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
         if (const char* v = std::getenv("RF_TRAVERSAL_VARIANT")) m.traversalVariant = std::atoi(v);
+        if (const char* v = std::getenv("RF_PACKET_BOUNCES")) m.optPacketBounces = static_cast<uint32_t>(std::max(std::atoi(v), 0)); // experiments: whole test suite through kTracePacket
         if (!m.wideUsable) m.traversalVariant = 0;
     }
 
@@ -2121,6 +2415,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "sample_sort") mImpl->optSampleSort = value != 0;
     else if (name == "accumulate_runs") mImpl->optAccumulateRuns = value != 0;
     else if (name == "uniform_fetch") mImpl->optUniformFetch = static_cast<int>(value);
+    else if (name == "packet_bounces") mImpl->optPacketBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
@@ -2134,6 +2429,16 @@ void Renderer::setOption(const std::string& name, int64_t value)
     }
     else if (name == "query_variant") mImpl->queryVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
     else if (name == "persistent_blocks") mImpl->wideBlocks = static_cast<uint32_t>(value);
+    else if (name == "extra_lds")
+    {
+        Impl& m = *mImpl;
+        m.optExtraLds = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+        hipDeviceProp_t prop{};
+        RF_HIP(hipGetDeviceProperties(&prop, m.device));
+        int perCu = 0;
+        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, m.optExtraLds));
+        m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
+    }
     else throw std::invalid_argument("unknown option " + name);
 }
 void Renderer::setTiming(bool enabled) { mImpl->timing = enabled; }

@@ -88,7 +88,7 @@ struct RenderStats
 
 constexpr uint32_t kTileSize = 32; // shard tile edge in pixels (32x32 = 16 waves of 8x8 pixels)
 
-// Deterministic tile -> rank assignment (scrambled round-robin, equal counts +-1).
+// Deterministic tile -> rank assignment (tiles along a Z-order curve dealt round-robin: equal counts +-1, every compact block of the image split over all ranks).
 std::vector<uint32_t> tilesForRank(uint32_t width, uint32_t height, uint32_t rank, uint32_t worldSize);
 // compact tile-major float4 buffer -> row-major width*height*4 image (pixels of other ranks' tiles untouched)
 void untileHost(const float* compact, const uint32_t* tileIds, uint32_t numTiles, uint32_t width, uint32_t height, float* image);

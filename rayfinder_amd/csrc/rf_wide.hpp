@@ -184,7 +184,8 @@ __device__ __forceinline__ PackedRay packRay(const RayPrep& r)
 }
 
 // q0 = {c0.lo.xyz, c0.hi.x}  q1 = {c0.hi.yz, c1.lo.xy}  q2 = {c1.lo.z, c1.hi.xyz}
-__device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q1, float4 q2, bool& ok0, float& tmin0, bool& ok1, float& tmin1)
+// slabPairBounds: max3(near) / min3(far) of both boxes; slabPair: P and tmin from them.
+__device__ __forceinline__ void slabPairBounds(const PackedRay& r, float4 q0, float4 q1, float4 q2, float& near0, float& far0, float& near1, float& far1)
 {
     const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY; // c0: t(lo.x), t(lo.y)
     const v2f b = (v2f{q0.z, q0.w} - r.oZX) * r.iZX; // c0: t(lo.z), t(hi.x)
@@ -192,14 +193,17 @@ __device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q
     const v2f d = (v2f{q1.z, q1.w} - r.oXY) * r.iXY; // c1: t(lo.x), t(lo.y)
     const v2f e = (v2f{q2.x, q2.y} - r.oZX) * r.iZX; // c1: t(lo.z), t(hi.x)
     const v2f f = (v2f{q2.z, q2.w} - r.oYZ) * r.iYZ; // c1: t(hi.y), t(hi.z)
-    const float near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.y), __builtin_fminf(a.y, c.x)), __builtin_fminf(b.x, c.y));
-    const float far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.y), __builtin_fmaxf(a.y, c.x)), __builtin_fmaxf(b.x, c.y));
-    const float near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d.x, e.y), __builtin_fminf(d.y, f.x)), __builtin_fminf(e.x, f.y));
-    const float far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d.x, e.y), __builtin_fmaxf(d.y, f.x)), __builtin_fmaxf(e.x, f.y));
-    ok0 = near0 <= far0 && far0 > 0.0f;
-    ok1 = near1 <= far1 && far1 > 0.0f;
-    tmin0 = near0;
-    tmin1 = near1;
+    near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.y), __builtin_fminf(a.y, c.x)), __builtin_fminf(b.x, c.y));
+    far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.y), __builtin_fmaxf(a.y, c.x)), __builtin_fmaxf(b.x, c.y));
+    near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d.x, e.y), __builtin_fminf(d.y, f.x)), __builtin_fminf(e.x, f.y));
+    far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d.x, e.y), __builtin_fmaxf(d.y, f.x)), __builtin_fmaxf(e.x, f.y));
+}
+__device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q1, float4 q2, bool& ok0, float& tmin0, bool& ok1, float& tmin1)
+{
+    float far0, far1;
+    slabPairBounds(r, q0, q1, q2, tmin0, far0, tmin1, far1);
+    ok0 = tmin0 <= far0 && far0 > 0.0f;
+    ok1 = tmin1 <= far1 && far1 > 0.0f;
 }
 
 // Class B lanes only: is any of the twelve slab products of this record NaN (0 * inf)?
