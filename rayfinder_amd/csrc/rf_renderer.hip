@@ -162,7 +162,8 @@ __device__ __forceinline__ bool localPixelToXY(const FrameParams& fp, const uint
 constexpr int kItems = 4; // queue entries per thread in the per-entry kernels
 
 template<int ITEMS>
-__device__ __forceinline__ void blockAppend(const bool (&keep)[ITEMS], const uint32_t (&slot)[ITEMS], uint32_t* queue, uint32_t* count, uint32_t* sScratch)
+__device__ __forceinline__ void blockAppend(const bool (&keep)[ITEMS], const uint32_t (&slot)[ITEMS], uint32_t* queue, uint32_t* count, uint32_t* sScratch,
+                                            uint32_t (*position)[ITEMS] = nullptr)
 {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     uint32_t       offs[ITEMS];
@@ -186,7 +187,10 @@ __device__ __forceinline__ void blockAppend(const bool (&keep)[ITEMS], const uin
     for (uint32_t w = 0; w < wave; ++w) base += sScratch[w];
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k)
+    {
         if (keep[k]) queue[base + offs[k]] = slot[k];
+        if (position) (*position)[k] = base + offs[k]; // where the entry went (meaningful where keep[k])
+    }
     __syncthreads(); // sScratch may be reused by the next append
 }
 
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
         ClosestHit     h;
         traverse<false, COUNT>(scene, vec3(o.x, o.y, o.z), vec3(d.x, d.y, d.z), kTMax, &sStack[threadIdx.x], h, tc);
         if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-        ps.hit[slot] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f);
+        ps.hit[i] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f); // by QUEUE position (dense), not by slot
         if (h.triangle != kMiss) ps.rayO[slot] = make_float4(h.p.x, h.p.y, h.p.z, 0.0f);
     }
     if (COUNT)
@@ -370,9 +374,12 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
     const bool isLastBounce = (bounceFlags & kShadeLastBounce) != 0u, isFirstBounce = (bounceFlags & kShadeFirstBounce) != 0u;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
   {
+    // Pass 1: which entries hit, which left the scene -> both output queues are appended FIRST, so that every surviving path
+    // knows its position in the next queue before it is shaded: what only the next two launches read (the NEE term) is
+    // written there, densely, instead of at the path's slot (whose neighbours are mostly dead by bounce 3).
     bool       isHit[kItems], isMiss[kItems];
-    uint32_t   slots[kItems], missEntries[kItems];
-#pragma unroll 1
+    uint32_t   slots[kItems], missEntries[kItems], outPos[kItems];
+#pragma unroll
     for (int k = 0; k < kItems; ++k)
     {
         const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
@@ -382,14 +389,22 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         const uint32_t slot = queue[i];
         slots[k] = slot;
         missEntries[k] = isFirstBounce ? (slot | 0x80000000u) : slot;
-        const float4   h = ps.hit[slot];
+        const uint32_t tri = __float_as_uint(ps.hit[i].x); // hit records sit at QUEUE positions (dense)
+        isMiss[k] = tri == kMiss; // the path ends in the sky: evaluated densely by kSky at the end of the batch
+        isHit[k] = tri != kMiss;
+    }
+    blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch, &outPos);
+    blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
+
+    // Pass 2: shade the hits
+#pragma unroll 1
+    for (int k = 0; k < kItems; ++k)
+    {
+        if (!isHit[k]) continue;
+        const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
+        const uint32_t slot = slots[k];
+        const float4   h = ps.hit[i];
         const uint32_t tri = __float_as_uint(h.x);
-        if (tri == kMiss)
-        {
-            isMiss[k] = true; // the path ends in the sky: evaluated densely by kSky at the end of the batch
-            continue;
-        }
-        isHit[k] = true;
         // everything this stage needs of the triangle sits in ONE 128-byte record (positions + packed attributes): one L2 line
         // per shaded hit instead of a triangle line and an attribute line (kShade 56.1 -> 53.0 ms per 128 spp)
         const float4* rec = scene.shadeRecords + 8 * static_cast<size_t>(tri);
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         const Vec3 brdf = albedo * kFrac1Pi;
         const Vec3 reflectance = brdf * dot(n, lightDirection);
         const Vec3 pend = (throughput * lightIntensity) * reflectance;
-        ps.pending[slot] = make_float4(pend.x, pend.y, pend.z, 0.0f);
+        ps.pending[outPos[k]] = make_float4(pend.x, pend.y, pend.z, 0.0f); // read by the shadow launch at the same queue position
 
         if (!isLastBounce)
         {
@@ -435,8 +450,6 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             ps.thr[slot] = make_float4(t2.x, t2.y, t2.z, 0.0f);
         }
     }
-    blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch);
-    blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
   }
 }
 
@@ -483,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
         const bool     occluded = traverse<true, COUNT>(scene, vec3(o.x, o.y, o.z), l, kTMax, &sStack[threadIdx.x], h, tc);
         if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
         const float    visibility = occluded ? 0.0f : 1.0f;
-        const float4   pend = ps.pending[slot];
+        const float4   pend = ps.pending[i]; // by queue position (written there by kShade)
         const Vec3     rad0 = firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot); // bounce 1: radiance is still 0 (wgsl:183)
         // wgsl:203  radiance += ((throughput*L)*reflectance) * visibility * SOLAR_INV_PDF
         const Vec3 add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
@@ -561,7 +574,7 @@ constexpr int wideStackDepth()
 }
 
 template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false>
-__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
+__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
                                                                                         const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
                                                                                         DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
                                                                                         uint32_t chunk, float tMax, uint32_t flags)
@@ -584,6 +597,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
 
     uint32_t  node = kNodeIdle;
     uint32_t  slot = 0;
+    uint32_t  resultIndex = 0; // queue position of the lane's ray
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
@@ -653,6 +667,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             {
                 slot = loadQ(queue + chunkPos + rankInIdle);
                 const Vec3 o = load3s(ps.rayO + slot);
+                resultIndex = chunkPos + rankInIdle; // queue position: where the hit record goes (dense for kShade) / where the NEE term waits
                 Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
                 {
@@ -910,14 +925,14 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : 6) void kTr
             if (ANY_HIT)
             {
                 const float  visibility = occluded ? 0.0f : 1.0f;
-                const Vec3   add = (load3s(ps.pending + slot) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3   add = (load3s(ps.pending + resultIndex) * visibility) * __uint_as_float(kSolarInvPdfBits);
                 const Vec3   radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add; // bounce 1: still 0 (wgsl:183)
                 store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
             }
             else
             {
                 // .w = t of the hit (rayTMax == best.t then); read by the query path only
-                store4s(ps.hit + slot, __uint_as_float(best.triangle), best.u, best.v, rayTMax);
+                store4s(ps.hit + resultIndex, __uint_as_float(best.triangle), best.u, best.v, rayTMax);
             }
             node = kNodeIdle;
         }
@@ -1200,11 +1215,11 @@ __global__ __launch_bounds__(kBlock, 6) void kTracePacket(DeviceScene scene, Wid
             if (ANY_HIT)
             {
                 const float visibility = occluded ? 0.0f : 1.0f;
-                const Vec3  add = (load3s(ps.pending + slot) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3  add = (load3s(ps.pending + idx) * visibility) * __uint_as_float(kSolarInvPdfBits);
                 const Vec3  radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add;
                 store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
             }
-            else store4s(ps.hit + slot, __uint_as_float(best.triangle), best.u, best.v, resultT);
+            else store4s(ps.hit + idx, __uint_as_float(best.triangle), best.u, best.v, resultT);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));

@@ -39,7 +39,14 @@ constexpr uint32_t kWideLeafBit = 0x80000000u;
 constexpr uint32_t kWideIndexBits = 26;  // record / first-triangle / big-leaf index
 constexpr uint32_t kWideAxisShift = 29;  // bits 30..29 of the FIRST child word carry the node's split axis
 constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is interior
-constexpr int      kWideLdsStack = 12;      // (child word, tmin) pairs per lane, all in LDS; deeper rays are redone by the scalar traversal
+#if defined(RF_EXP_WAVES)
+constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment builds: resident workgroups per CU of kTraceWide
+constexpr int      kWideLdsStack = 160 * 1024 / RF_EXP_WAVES / 2048; // as deep as the LDS allows at that occupancy (7: 11, 8: 10)
+#else
+constexpr int      kWideWaves = 6;
+constexpr int      kWideLdsStack = 12;
+#endif
+// kWideLdsStack: (child word, tmin) pairs per lane, all in LDS; deeper rays are redone by the scalar traversal
 
 struct WideScene
 {

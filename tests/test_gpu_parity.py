@@ -872,6 +872,39 @@ def test_slot_order_batching_and_accumulation_variants_give_identical_images(duc
             assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3])), (opts, max_paths)
 
 
+@pytest.mark.parametrize("packet_bounces", [1, 99])
+def test_lockstep_packet_traversal_gives_identical_images(duck_pt, duck_oracle, packet_bounces):
+    """kTracePacket (one wave = one packet walking the tree in lockstep: shared stack, scalar-cache fetches, per-lane rayTMax and
+    active bit) is a scheduling choice too: the image is the oracle's bit for bit, at bounce 1 only (where its waves are one
+    pixel's samples) and at every bounce (incoherent packets, mixed direction signs: several passes per wave); a tree deeper
+    than the packet's 24-entry shared stack hands its rays to the scalar traversal."""
+    W, H, spp, bounces = 150, 90, 23, 4
+    cam = rf.fly_camera(W, H)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.25, rf.aligned_sky_state(rf.make_sky()))
+    ref, _ = orc.render(duck_oracle.scene, rp, 0, spp)
+    r, _ = _renderer(duck_pt, W, H, spp, bounces, cam=cam)
+    r.set_option("packet_bounces", packet_bounces)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    r.close()
+    assert acc == spp
+    assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
+    # the 60-deep chain: every far child of the chain is pending at once
+    nodes, tris, attrs = _chain_scene(60)
+    sc = rf.scene_from_arrays(nodes, tris, attrs, [(np.array([0xFFFFFFFF], np.uint32), 1, 1)])
+    cam2 = rf.create_camera((0.2, 0.2, -5.0), (0.2, 0.2, 0.0), 0.0, 1.0, np.radians(20.0), 1.0)
+    images = []
+    for pk in (0, packet_bounces):
+        r = rf.ReferencePathTracer(rf.make_render_parameters(64, 64, cam2, 2, 2, rf.make_sky(), 1.0), sc)
+        r.set_option("packet_bounces", pk)
+        r.render(2)
+        images.append(r.read_accumulation()[0])
+        s = r.stats()
+        assert s["abandoned_rays"] == 0 and s["scalar_redo_rays"] > 0
+        r.close()
+    assert np.array_equal(bits(images[0]), bits(images[1]))
+
+
 def test_rf_render_cli_writes_the_tonemapped_image(duck_pt, tmp_path):
     """rf-render (the offline twin of the `pt` app, --gpus 1 path): its PNG holds exactly rf_renderer_read_tonemapped's texels."""
     import subprocess

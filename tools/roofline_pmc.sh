@@ -55,6 +55,33 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACH
   i=$((i+1)); pmc pmc$i "$BENCH" "$ctrs"
 done
 
+# ---- 2b. per bounce: the same counters per DISPATCH of the two traversal kernels (the launches of one batch are bounces 1..B)
+perdispatch() {   # tag, counters
+  local tag=$1 ctrs=$2
+  timeout 900 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/raw_$tag -o r -- $BENCH > /dev/null 2> $OUT/$tag.log
+  local f=$(find $OUT/raw_$tag -name '*counter_collection.csv' | head -1)
+  if [ -n "$f" ]; then
+python3 - "$f" > $OUT/${tag}.csv <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+d = collections.OrderedDict()
+for r in rows:
+    k = r.get("Kernel_Name", "")
+    kind = "closest" if "kTraceWide<false" in k else "shadow" if "kTraceWide<true" in k else None
+    if kind is None: continue
+    d.setdefault((kind, int(r["Dispatch_Id"])), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+names = sorted({c for v in d.values() for c in v})
+print("kernel,dispatch," + ",".join(names))
+for (kind, disp) in sorted(d, key=lambda t: (t[0], t[1])):
+    print(f"{kind},{disp}," + ",".join(repr(d[(kind, disp)].get(n, 0.0)) for n in names))
+PY
+  else echo "no output for $tag ($ctrs)"; tail -3 $OUT/$tag.log; fi
+  rm -rf $OUT/raw_$tag $OUT/$tag.log
+}
+perdispatch per_bounce_pmc1 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"
+perdispatch per_bounce_pmc2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU"
+perdispatch per_bounce_pmc3 "TCC_HIT_sum TCC_MISS_sum"
+
 # ---- 3. post-process
 python3 $REPO/tools/roofline_post.py $OUT
 ls -la $OUT

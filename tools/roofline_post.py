@@ -2,7 +2,9 @@
 """tools/roofline_post.py <dir>  -- turns the summaries tools/roofline_pmc.sh wrote into
      <dir>/calibration.json   counter / known-bytes ratios of the microbenchmark, per access pattern
      <dir>/pmc_per_ray.json   fabric-side bytes and vector-L1 accesses per ray of the closest-hit traversal kernel
-(the latter is what bench.py reads from profiles/pmc_per_ray.json).  Pure text processing; runs anywhere."""
+     <dir>/per_bounce.json    per bounce of the profiled batch: vector-L1 accesses per ray and per clock per CU, L1 -> L2 requests,
+                              L2 hit rate, VALU issue share (which unit binds where)
+(pmc_per_ray.json is what bench.py reads from profiles/pmc_per_ray.json).  Pure text processing; runs anywhere."""
 import json
 import os
 import re
@@ -124,3 +126,57 @@ per_ray = dict(
            "requests of the 8 L2s (Infinity-Cache hits included)")
 json.dump(per_ray, open(os.path.join(out, "pmc_per_ray.json"), "w"), indent=1)
 print(json.dumps(per_ray, indent=1))
+
+
+# ---------------------------------------------------------------- per bounce (per dispatch of the traversal kernels)
+def per_dispatch(path):
+    res = {}
+    if not os.path.exists(path):
+        return res
+    lines = open(path).read().strip().splitlines()
+    if not lines:
+        return res
+    names = lines[0].split(",")[2:]
+    for ln in lines[1:]:
+        f = ln.split(",")
+        res.setdefault(f[0], []).append(dict(zip(names, (float(x) for x in f[2:]))))
+    return res
+
+
+pb = {}
+for i in (1, 2, 3):
+    for kind, rows in per_dispatch(os.path.join(out, f"per_bounce_pmc{i}.csv")).items():
+        for j, row in enumerate(rows):
+            pb.setdefault(kind, {}).setdefault(j, {}).update(row)
+CUS, XCDS, SIMDS = 256, 8, 1024
+bounces = bench.get("per_bounce_rank0", [])
+nb = len(bounces)
+table = []
+for kind in ("closest", "shadow"):
+    rows = pb.get(kind, {})
+    if not rows or not nb:
+        continue
+    last = sorted(rows)[-nb:]          # the timed batch's launches are the last nb dispatches of the kernel
+    for b, j in zip(bounces, last):
+        c = rows[j]
+        rays = b[f"{kind}_rays"]
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / XCDS          # the counter is summed over the 8 XCDs
+        e = dict(kernel=kind, bounce=b["bounce"], rays=rays, ms=b[f"ms_{kind}"], gpu_cycles=round(cyc))
+        if rays and cyc:
+            e["l1_accesses_per_ray"] = round(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / rays, 1)
+            e["l1_accesses_per_clk_per_cu"] = round(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / cyc / CUS, 3)
+            e["l1_to_l2_requests_per_ray"] = round(c.get("TCP_TCC_READ_REQ_sum", 0.0) / rays, 2)
+            if "SQ_INSTS_VALU" in c:
+                e["valu_instructions_per_ray"] = round(c["SQ_INSTS_VALU"] / rays, 1)
+                e["valu_issue_share"] = round(c["SQ_INSTS_VALU"] * 4.0 / SIMDS / cyc, 3)     # 4 cycles per wave64 instruction per SIMD
+                e["salu_instructions_per_ray"] = round(c.get("SQ_INSTS_SALU", 0.0) / rays, 1)
+            if "TCC_HIT_sum" in c:
+                e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 3)
+        table.append(e)
+if table:
+    json.dump(dict(profile=os.path.basename(os.path.abspath(out)), spp_of_the_batch=bench["config"]["spp"],
+                   note="one row per launch of the timed batch; l1_accesses_per_clk_per_cu is against the ceiling of 1 (one vector-L1 tag access per clock "
+                        "per CU); valu_issue_share = wave instructions x 4 cycles / SIMD-cycles available", rows=table),
+              open(os.path.join(out, "per_bounce.json"), "w"), indent=1)
+    for e in table:
+        print(e)
