@@ -57,15 +57,24 @@ namespace
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " in " #expr);      \
     } while (0)
 
+// Path state.  What one launch writes for the NEXT launch to stream through lives at QUEUE positions: entry q of a
+// bounce's ray queue has its origin, direction, throughput, hit record and pending NEE term at index q of these arrays, so
+// that every launch reads and writes them densely, in queue order (coalesced), however few of the batch's paths are still
+// alive (by bounce 3 half of the slots are dead: slot-indexed, each surviving path cost a 64-byte line per stream).
+// Direction and throughput are double-buffered: kShade reads entry q of the bounce's arrays while other workgroups already
+// write entries of the next queue.  What belongs to the PATH for its whole life stays at its slot: the radiance sum
+// (read by the accumulation in sample order) and the blue-noise pair.
 struct PathStreams
 {
-    float4* rayO;    // origin.xyz (hit point after traceClosest)
-    float4* rayD;    // direction.xyz
-    float4* thr;     // throughput.rgb
-    float4* rad;     // radiance.rgb
-    float4* hit;     // {triangle bits, u, v, -}
-    float4* pending; // (throughput * solar radiance) * reflectance, waiting for visibility
-    float4* noise;   // {u.x, cos(2 pi u.y), sin(2 pi u.y), -}: the path's one blue-noise pair
+    float4* rayO;    // [queue position] origin.xyz of the ray to trace (kRaygen / kShade: the offset hit point)
+    float4* rayD;    // [queue position] direction.xyz, this bounce's
+    float4* thr;     // [queue position] throughput.rgb, this bounce's
+    float4* rad;     // [slot] radiance.rgb
+    float4* hit;     // [queue position] {triangle bits, u, v, t}
+    float4* pending; // [queue position] (throughput * solar radiance) * reflectance, waiting for visibility
+    float4* noise;   // [slot] {u.x, cos(2 pi u.y), sin(2 pi u.y), -}: the path's one blue-noise pair
+    float4* rayDOut; // [position in the NEXT queue] written by kShade
+    float4* thrOut;  // [position in the NEXT queue]
 };
 
 // 12-byte load of the xyz part of a float4 stream element (global_load_dwordx3): the L1 -> VGPR return path
@@ -244,9 +253,9 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
     __shared__ uint32_t sScratch[8];
     const uint32_t      total = fp.numSamples * fp.pixelsPadded;
     bool                keep[kItems];
-    uint32_t            slots[kItems];
-    uint32_t            numValid = 0;
-#pragma unroll 1
+    uint32_t            slots[kItems], pos[kItems], px[kItems], py[kItems], sample[kItems];
+    // pass 1: which slots are pixels of the image -> their positions in the first queue
+#pragma unroll
     for (int k = 0; k < kItems; ++k)
     {
         const uint32_t slot = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
@@ -254,40 +263,43 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
         uint32_t       x = 0, y = 0, sampleIdx = 0, lp = 0;
         if (valid) slotToSamplePixel(fp, slot, sampleIdx, lp);
         if (valid) valid = localPixelToXY(fp, tileIds, lp, x, y);
-        if (valid)
-        {
-            const uint32_t frame = fp.firstFrame + (fp.samplePerm ? fp.samplePerm[sampleIdx] : sampleIdx);
-            float          nx, ny;
-            animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
-
-            // fragment centre (wgsl:36-43); v runs down the image
-            const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(fp.width);
-            const float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(fp.height);
-            const float s = u + nx / static_cast<float>(fp.width);
-            const float t = (1.0f - v) + ny / static_cast<float>(fp.height);
-
-            const float phi = 2.0f * kPi * ny;
-            const float cosPhi = wCos(phi), sinPhi = wSin(phi);
-            const float r = rf_sqrt(nx);
-            const float lensX = fp.camera.lensRadius * (r * cosPhi);
-            const float lensY = fp.camera.lensRadius * (r * sinPhi);
-            const Vec3  origin = fp.camera.origin + (lensX * fp.camera.right + lensY * fp.camera.up);
-            const Vec3  dir = normalize(fp.camera.lowerLeftCorner + s * fp.camera.horizontal + t * fp.camera.vertical - origin);
-
-            // throughput = 1 and radiance = 0 (wgsl:183-184) are not stored: bounce 1 knows them (kFlagFirstBounce, the
-            // first-bounce bit of a miss-list entry), which saves 32 of the 80 bytes a path costs here and the reads back
-            ps.rayO[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
-            ps.rayD[slot] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-            ps.noise[slot] = make_float4(nx, cosPhi, sinPhi, 0.0f);
-            ++numValid;
-        }
         keep[k] = valid;
         slots[k] = slot;
+        px[k] = x, py[k] = y, sample[k] = sampleIdx;
     }
-    blockAppend<kItems>(keep, slots, queue, queueCount, sScratch);
+    blockAppend<kItems>(keep, slots, queue, queueCount, sScratch, &pos);
+    // pass 2: the rays, written at their queue positions
+#pragma unroll
+    for (int k = 0; k < kItems; ++k)
+    {
+        if (!keep[k]) continue;
+        const uint32_t x = px[k], y = py[k];
+        const uint32_t frame = fp.firstFrame + (fp.samplePerm ? fp.samplePerm[sample[k]] : sample[k]);
+        float          nx, ny;
+        animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
+
+        // fragment centre (wgsl:36-43); v runs down the image
+        const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(fp.width);
+        const float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(fp.height);
+        const float s = u + nx / static_cast<float>(fp.width);
+        const float t = (1.0f - v) + ny / static_cast<float>(fp.height);
+
+        const float phi = 2.0f * kPi * ny;
+        const float cosPhi = wCos(phi), sinPhi = wSin(phi);
+        const float r = rf_sqrt(nx);
+        const float lensX = fp.camera.lensRadius * (r * cosPhi);
+        const float lensY = fp.camera.lensRadius * (r * sinPhi);
+        const Vec3  origin = fp.camera.origin + (lensX * fp.camera.right + lensY * fp.camera.up);
+        const Vec3  dir = normalize(fp.camera.lowerLeftCorner + s * fp.camera.horizontal + t * fp.camera.vertical - origin);
+
+        // throughput = 1 and radiance = 0 (wgsl:183-184) are not stored: bounce 1 knows them (kFlagFirstBounce, kSky's
+        // first-bounce flag), which saves 32 of the 80 bytes a path costs here and the reads back
+        ps.rayO[pos[k]] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+        ps.rayD[pos[k]] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+        ps.noise[slots[k]] = make_float4(nx, cosPhi, sinPhi, 0.0f);
+    }
     // primary rays are counted on the host (samples x valid pixels of the shard): one atomic per wave on a single counter
     // was what bound this kernel -- 261 k waves at ~90 same-address atomics/us = 2.9 of its 3.2 ms (MI355X_MICROARCH.md "dequeue")
-    (void)numValid;
     (void)counters;
 }
 
@@ -302,14 +314,12 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
     TraversalCounters tc;
     if (i < count)
     {
-        const uint32_t slot = queue[i];
-        const float4   o = ps.rayO[slot];
-        const float4   d = ps.rayD[slot];
+        const float4   o = ps.rayO[i]; // path state of the ray sits at its queue position
+        const float4   d = ps.rayD[i];
         ClosestHit     h;
         traverse<false, COUNT>(scene, vec3(o.x, o.y, o.z), vec3(d.x, d.y, d.z), kTMax, &sStack[threadIdx.x], h, tc);
         if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-        ps.hit[i] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f); // by QUEUE position (dense), not by slot
-        if (h.triangle != kMiss) ps.rayO[slot] = make_float4(h.p.x, h.p.y, h.p.z, 0.0f);
+        ps.hit[i] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f); // (kShade rebuilds the offset hit point from it)
     }
     if (COUNT)
     {
@@ -386,11 +396,10 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         isHit[k] = isMiss[k] = false;
         slots[k] = missEntries[k] = 0;
         if (i >= count) continue;
-        const uint32_t slot = queue[i];
-        slots[k] = slot;
-        missEntries[k] = isFirstBounce ? (slot | 0x80000000u) : slot;
+        slots[k] = queue[i];
+        missEntries[k] = i; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there
         const uint32_t tri = __float_as_uint(ps.hit[i].x); // hit records sit at QUEUE positions (dense)
-        isMiss[k] = tri == kMiss; // the path ends in the sky: evaluated densely by kSky at the end of the batch
+        isMiss[k] = tri == kMiss; // the path ends in the sky: evaluated densely by this bounce's kSky launch
         isHit[k] = tri != kMiss;
     }
     blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch, &outPos);
@@ -414,9 +423,9 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             const Vec3 p0 = load3(rec), p1 = load3(rec + 1), p2 = load3(rec + 2);
             const Vec3 e1 = p1 - p0, e2 = p2 - p0;
             const Vec3 hp = offsetRay(p0 + h.y * e1 + h.z * e2, normalize(cross(e1, e2)));
-            ps.rayO[slot] = make_float4(hp.x, hp.y, hp.z, 0.0f);
+            ps.rayO[outPos[k]] = make_float4(hp.x, hp.y, hp.z, 0.0f); // (this bounce's origins have been consumed by the closest-hit launch)
         }
-        const Vec3  throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + slot); // wgsl:184
+        const Vec3  throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i); // wgsl:184
         const Vec3  nz = load3(ps.noise + slot);
         const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
         // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
@@ -446,35 +455,39 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             pixarOnb(n, bu, bv);
             const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
             const Vec3 t2 = throughput * albedo;
-            ps.rayD[slot] = make_float4(wi.x, wi.y, wi.z, 0.0f);
-            ps.thr[slot] = make_float4(t2.x, t2.y, t2.z, 0.0f);
+            ps.rayDOut[outPos[k]] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+            ps.thrOut[outPos[k]] = make_float4(t2.x, t2.y, t2.z, 0.0f);
         }
     }
   }
 }
 
-// Paths that left the scene (at any bounce of this batch): radiance += throughput * sky
-// (wgsl:212-228,247-275).  A terminated path's direction, throughput and radiance stay in place
-// until the batch ends, and all its NEE terms have been added by then, so one dense launch over
-// the batch's miss list replaces a divergent branch in every shade launch.
-__global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, const uint32_t* missQueue, const uint32_t* missCount)
+// Paths that left the scene at this bounce: radiance += throughput * sky (wgsl:212-228,247-275).  One dense launch per
+// bounce over that bounce's miss list (queue positions) instead of a divergent f64 branch inside kShade; it runs right
+// after kShade, while the bounce's direction / throughput arrays and its queue are still intact.  All NEE terms of the path
+// have been added by then (the shadow launch of the previous bounce is complete).  Grid-stride: the list length is only
+// known on the device, and a worst-case grid of empty workgroups per bounce would cost more than the work.
+__global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, const uint32_t* queue, const uint32_t* missQueue, const uint32_t* missCount,
+                                                uint32_t firstBounce)
 {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= *missCount) return;
-    const uint32_t entry = missQueue[i];
-    const uint32_t slot = entry & 0x7FFFFFFFu;
-    const bool     first = (entry >> 31) != 0u; // left the scene at bounce 1: throughput 1, radiance 0, neither in memory
-    const Vec3     v = load3(ps.rayD + slot);
-    const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + slot);
-    const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot);
-    const Vec3     s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
-    const float    theta = wAcos(v.y);
-    const float    gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
-    // cos(gamma) and |cos(theta)| do not depend on the channel: evaluated once instead of three times (same values)
-    const float cosGamma = wCos(gamma), cosTheta = fabsf(wCos(theta));
-    const Vec3  dome = vec3(skyRadiance(sky, cosTheta, gamma, cosGamma, 0), skyRadiance(sky, cosTheta, gamma, cosGamma, 1), skyRadiance(sky, cosTheta, gamma, cosGamma, 2));
-    const Vec3  radiance = rad + thr * dome;
-    ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    const uint32_t n = *missCount;
+    const bool     first = firstBounce != 0u; // left the scene at bounce 1: throughput 1, radiance 0, neither in memory
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    {
+        const uint32_t q = missQueue[i];
+        const uint32_t slot = queue[q];
+        const Vec3     v = load3(ps.rayD + q);
+        const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + q);
+        const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot);
+        const Vec3     s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
+        const float    theta = wAcos(v.y);
+        const float    gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
+        // cos(gamma) and |cos(theta)| do not depend on the channel: evaluated once instead of three times (same values)
+        const float cosGamma = wCos(gamma), cosTheta = fabsf(wCos(theta));
+        const Vec3  dome = vec3(skyRadiance(sky, cosTheta, gamma, cosGamma, 0), skyRadiance(sky, cosTheta, gamma, cosGamma, 1), skyRadiance(sky, cosTheta, gamma, cosGamma, 2));
+        const Vec3  radiance = rad + thr * dome;
+        ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+    }
 }
 
 template<bool COUNT>
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
     if (i < count)
     {
         const uint32_t slot = queue[i];
-        const float4   o = ps.rayO[slot];
+        const float4   o = ps.rayO[i];
         const float4   nz = ps.noise[slot];
         const Vec3     l = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
         ClosestHit     h;
@@ -665,16 +678,18 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
             if (node == kNodeIdle && rankInIdle < take)
             {
-                slot = loadQ(queue + chunkPos + rankInIdle);
-                const Vec3 o = load3s(ps.rayO + slot);
-                resultIndex = chunkPos + rankInIdle; // queue position: where the hit record goes (dense for kShade) / where the NEE term waits
+                // the ray's state sits at its QUEUE position: the lanes of a refill read consecutive elements (coalesced), and
+                // the closest-hit launch does not read the queue itself at all
+                resultIndex = chunkPos + rankInIdle;
+                if (ANY_HIT) slot = loadQ(queue + resultIndex); // the radiance sum and the blue-noise pair are the path's: by slot
+                const Vec3 o = load3s(ps.rayO + resultIndex);
                 Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
                 {
                     const Vec3 nz = load3s(ps.noise + slot);
                     dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
-                else dir = load3s(ps.rayD + slot);
+                else dir = load3s(ps.rayD + resultIndex);
                 const RayPrep ray = prepareRay(o, dir);
                 pr = packRay(ray);
                 rayDir = dir;
@@ -1019,14 +1034,14 @@ __global__ __launch_bounds__(kBlock, 6) void kTracePacket(DeviceScene scene, Wid
         Vec3           o = vec3(0.0f, 0.0f, 0.0f), dir = vec3(0.0f, 0.0f, 1.0f);
         if (valid)
         {
-            slot = loadQ(queue + idx);
-            o = load3s(ps.rayO + slot);
+            if (ANY_HIT) slot = loadQ(queue + idx);
+            o = load3s(ps.rayO + idx);
             if (ANY_HIT && !shadowDirFromStream)
             {
                 const Vec3 nz = load3s(ps.noise + slot);
                 dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
             }
-            else dir = load3s(ps.rayD + slot);
+            else dir = load3s(ps.rayD + idx);
         }
         const RayPrep   ray = prepareRay(o, dir);
         const PackedRay pr = packRay(ray);
@@ -1671,7 +1686,7 @@ struct Renderer::Impl
     uint64_t                validPixels = 0;     // pixels of this rank's tiles that lie inside the frame
     unsigned long long      primaryRaysHost = 0; // samples traced x validPixels since the last resetStats()
     uint64_t                maxPaths = 0;
-    DeviceBuffer<float4>    sRayO, sRayD, sThr, sRad, sHit, sPending, sNoise;
+    DeviceBuffer<float4>    sRayO, sRayD, sRayD2, sThr, sThr2, sRad, sHit, sPending, sNoise; // rayD / thr: double-buffered (PathStreams)
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
     DeviceBuffer<unsigned long long> bounceTotals; // 2 x kMaxBounceStats
@@ -1684,6 +1699,7 @@ struct Renderer::Impl
     bool counting = false, timing = false;
     int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
     uint32_t wideBlocks = 0;
+    uint32_t skyBlocks = 2048; // grid of the per-bounce kSky launches (grid-stride; set from the CU count)
     bool     wideUsable = true;
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
@@ -1741,7 +1757,9 @@ struct Renderer::Impl
         allocatedPaths = paths;
         sRayO.alloc(paths);
         sRayD.alloc(paths);
+        sRayD2.alloc(paths);
         sThr.alloc(paths);
+        sThr2.alloc(paths);
         sRad.alloc(paths);
         sHit.alloc(paths);
         sPending.alloc(paths);
@@ -1861,7 +1879,7 @@ struct Renderer::Impl
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
         const uint32_t count = static_cast<uint32_t>(n);
         RF_HIP(hipMemcpyAsync(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice, stream));
-        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr};
+        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr};
         const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
         if (shadow)
         {
@@ -1923,19 +1941,20 @@ struct Renderer::Impl
         const uint64_t paths = static_cast<uint64_t>(numSamples) * fp.pixelsPadded;
         const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
         primaryRaysHost += static_cast<unsigned long long>(numSamples) * validPixels;
-        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr};
+        // bounce b reads direction / throughput from buffer (b - 1) & 1 and kShade writes the next bounce's into the other one
+        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr};
         const uint32_t numBounces = fp.numBounces;
 
         BatchTiming bt{getEvent(), getEvent(), numSamples};
         RF_HIP(hipEventRecord(bt.start, stream));
 
         // device words, one per 64-byte line (they are all hot atomics): [0, B]: queue lengths per
-        // bounce; [B+1]: miss-list length; then two work cursors per bounce for the traversal launches
+        // bounce; [B+1, 2B]: miss-list length per bounce; then two work cursors per bounce for the traversal launches
         constexpr uint32_t kLine = kLineWords;
-        const uint32_t words = kLine * (numBounces + 2) + kLine * kShards * 2 * numBounces;
+        const uint32_t words = kLine * (2 * numBounces + 1) + kLine * kShards * 2 * numBounces;
         if (queueCounts.count < words) queueCounts.alloc(words);
-        uint32_t* const missCount = queueCounts.ptr + kLine * (numBounces + 1);
-        uint32_t* const cursors = queueCounts.ptr + kLine * (numBounces + 2);
+        uint32_t* const missCounts = queueCounts.ptr + kLine * (numBounces + 1);
+        uint32_t* const cursors = queueCounts.ptr + kLine * (2 * numBounces + 1);
         const uint32_t  itemBlocks = static_cast<uint32_t>((paths + kBlock * kItems - 1) / (kBlock * kItems));
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
 
@@ -1972,9 +1991,12 @@ struct Renderer::Impl
                     hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
             }, bounce - 1);
+            uint32_t* const missCount = missCounts + kLine * (bounce - 1);
             launchTimed(2, [&] {
                 hipLaunchKernelGGL(kShade, dim3(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
                                    (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u));
+                // the paths that left the scene at this bounce, while its direction / throughput arrays and queue are intact
+                hipLaunchKernelGGL(kSky, dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, qIn, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
             });
             const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag;
             launchTimed(3, [&] {
@@ -2005,8 +2027,9 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
             }, bounce - 1);
             std::swap(qIn, qOut);
+            std::swap(ps.rayD, ps.rayDOut);
+            std::swap(ps.thr, ps.thrOut);
         }
-        launchTimed(2, [&] { hipLaunchKernelGGL(kSky, dim3(blocks), dim3(kBlock), 0, stream, sky, ps, missQueue.ptr, missCount); });
         hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr);
         launchTimed(4, [&] {
             if (fp.slotGroupShift == 0u && numSamples > 4u && numSamples <= kAccMaxSamples && optAccumulateRuns)
@@ -2152,6 +2175,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         int perCu = 0;
         RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, 0));
         m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
+        m.skyBlocks = 8u * static_cast<uint32_t>(prop.multiProcessorCount);
         if (const char* v = std::getenv("RF_TRAVERSAL_VARIANT")) m.traversalVariant = std::atoi(v);
         if (const char* v = std::getenv("RF_PACKET_BOUNCES")) m.optPacketBounces = static_cast<uint32_t>(std::max(std::atoi(v), 0)); // experiments: whole test suite through kTracePacket
         if (!m.wideUsable) m.traversalVariant = 0;
