@@ -57,6 +57,11 @@ namespace
             throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " in " #expr);      \
     } while (0)
 
+struct __attribute__((packed, aligned(4))) P3
+{
+    float x, y, z;
+};
+
 // Path state.  What one launch writes for the NEXT launch to stream through lives at QUEUE positions: entry q of a
 // bounce's ray queue has its origin, direction, throughput, hit record and pending NEE term at index q of these arrays, so
 // that every launch reads and writes them densely, in queue order (coalesced), however few of the batch's paths are still
@@ -66,15 +71,15 @@ namespace
 // (read by the accumulation in sample order) and the blue-noise pair.
 struct PathStreams
 {
-    float4* rayO;    // [queue position] origin.xyz of the ray to trace (kRaygen / kShade: the offset hit point)
-    float4* rayD;    // [queue position] direction.xyz, this bounce's
-    float4* thr;     // [queue position] throughput.rgb, this bounce's
+    P3*     rayO;    // [queue position] origin.xyz of the ray to trace (kRaygen / kShade: the offset hit point)
+    P3*     rayD;    // [queue position] direction.xyz, this bounce's
+    P3*     thr;     // [queue position] throughput.rgb, this bounce's
     float4* rad;     // [slot] radiance.rgb
     float4* hit;     // [queue position] {triangle bits, u, v, t}
-    float4* pending; // [queue position] (throughput * solar radiance) * reflectance, waiting for visibility
+    P3*     pending; // [queue position] (throughput * solar radiance) * reflectance, waiting for visibility
     float4* noise;   // [slot] {u.x, cos(2 pi u.y), sin(2 pi u.y), -}: the path's one blue-noise pair
-    float4* rayDOut; // [position in the NEXT queue] written by kShade
-    float4* thrOut;  // [position in the NEXT queue]
+    P3*     rayDOut; // [position in the NEXT queue] written by kShade
+    P3*     thrOut;  // [position in the NEXT queue]
 };
 
 // 12-byte load of the xyz part of a float4 stream element (global_load_dwordx3): the L1 -> VGPR return path
@@ -85,10 +90,24 @@ __device__ __forceinline__ Vec3 load3(const float4* p)
     const v3f v = *reinterpret_cast<const v3f*>(p);
     return vec3(v.x, v.y, v.z);
 }
+// The queue-position arrays hold PACKED xyz triples (12-byte stride, global_load/store_dwordx3 at 4-byte alignment): they are
+// streamed densely by every launch, so a quarter of their bytes would be padding otherwise.
+__device__ __forceinline__ Vec3 load3(const P3* p)
+{
+    const P3 v = *p;
+    return vec3(v.x, v.y, v.z);
+}
+__device__ __forceinline__ void store3(P3* p, Vec3 v)
+{
+    P3 o;
+    o.x = v.x, o.y = v.y, o.z = v.z;
+    *p = o;
+}
 
 // Path-state accesses of the traversal kernels (queue entry, origin, direction, result: touched once per ray).  A build with
 // the non-temporal hint on them measured 1 % slower (shadow kernel 32.2 -> 33.3 ms per 32 spp), so they are plain.
 __device__ __forceinline__ Vec3     load3s(const float4* p) { return load3(p); }
+__device__ __forceinline__ Vec3     load3s(const P3* p) { return load3(p); }
 __device__ __forceinline__ uint32_t loadQ(const uint32_t* p) { return *p; }
 __device__ __forceinline__ void     store4s(float4* p, float x, float y, float z, float w) { *p = make_float4(x, y, z, w); }
 
@@ -294,8 +313,8 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
 
         // throughput = 1 and radiance = 0 (wgsl:183-184) are not stored: bounce 1 knows them (kFlagFirstBounce, kSky's
         // first-bounce flag), which saves 32 of the 80 bytes a path costs here and the reads back
-        ps.rayO[pos[k]] = make_float4(origin.x, origin.y, origin.z, 0.0f);
-        ps.rayD[pos[k]] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+        store3(ps.rayO + pos[k], origin);
+        store3(ps.rayD + pos[k], dir);
         ps.noise[slots[k]] = make_float4(nx, cosPhi, sinPhi, 0.0f);
     }
     // primary rays are counted on the host (samples x valid pixels of the shard): one atomic per wave on a single counter
@@ -314,10 +333,10 @@ __global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathS
     TraversalCounters tc;
     if (i < count)
     {
-        const float4   o = ps.rayO[i]; // path state of the ray sits at its queue position
-        const float4   d = ps.rayD[i];
-        ClosestHit     h;
-        traverse<false, COUNT>(scene, vec3(o.x, o.y, o.z), vec3(d.x, d.y, d.z), kTMax, &sStack[threadIdx.x], h, tc);
+        const Vec3 o = load3(ps.rayO + i); // path state of the ray sits at its queue position
+        const Vec3 d = load3(ps.rayD + i);
+        ClosestHit h;
+        traverse<false, COUNT>(scene, o, d, kTMax, &sStack[threadIdx.x], h, tc);
         if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
         ps.hit[i] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f); // (kShade rebuilds the offset hit point from it)
     }
@@ -423,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             const Vec3 p0 = load3(rec), p1 = load3(rec + 1), p2 = load3(rec + 2);
             const Vec3 e1 = p1 - p0, e2 = p2 - p0;
             const Vec3 hp = offsetRay(p0 + h.y * e1 + h.z * e2, normalize(cross(e1, e2)));
-            ps.rayO[outPos[k]] = make_float4(hp.x, hp.y, hp.z, 0.0f); // (this bounce's origins have been consumed by the closest-hit launch)
+            store3(ps.rayO + outPos[k], hp); // (this bounce's origins have been consumed by the closest-hit launch)
         }
         const Vec3  throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i); // wgsl:184
         const Vec3  nz = load3(ps.noise + slot);
@@ -444,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
         const Vec3 brdf = albedo * kFrac1Pi;
         const Vec3 reflectance = brdf * dot(n, lightDirection);
         const Vec3 pend = (throughput * lightIntensity) * reflectance;
-        ps.pending[outPos[k]] = make_float4(pend.x, pend.y, pend.z, 0.0f); // read by the shadow launch at the same queue position
+        store3(ps.pending + outPos[k], pend); // read by the shadow launch at the same queue position
 
         if (!isLastBounce)
         {
@@ -455,8 +474,8 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             pixarOnb(n, bu, bv);
             const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
             const Vec3 t2 = throughput * albedo;
-            ps.rayDOut[outPos[k]] = make_float4(wi.x, wi.y, wi.z, 0.0f);
-            ps.thrOut[outPos[k]] = make_float4(t2.x, t2.y, t2.z, 0.0f);
+            store3(ps.rayDOut + outPos[k], wi);
+            store3(ps.thrOut + outPos[k], t2);
         }
     }
   }
@@ -502,17 +521,17 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
     if (i < count)
     {
         const uint32_t slot = queue[i];
-        const float4   o = ps.rayO[i];
+        const Vec3     o = load3(ps.rayO + i);
         const float4   nz = ps.noise[slot];
         const Vec3     l = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
         ClosestHit     h;
-        const bool     occluded = traverse<true, COUNT>(scene, vec3(o.x, o.y, o.z), l, kTMax, &sStack[threadIdx.x], h, tc);
+        const bool     occluded = traverse<true, COUNT>(scene, o, l, kTMax, &sStack[threadIdx.x], h, tc);
         if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
         const float    visibility = occluded ? 0.0f : 1.0f;
-        const float4   pend = ps.pending[i]; // by queue position (written there by kShade)
+        const Vec3     pend = load3(ps.pending + i); // by queue position (written there by kShade)
         const Vec3     rad0 = firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot); // bounce 1: radiance is still 0 (wgsl:183)
         // wgsl:203  radiance += ((throughput*L)*reflectance) * visibility * SOLAR_INV_PDF
-        const Vec3 add = (vec3(pend.x, pend.y, pend.z) * visibility) * __uint_as_float(kSolarInvPdfBits);
+        const Vec3 add = (pend * visibility) * __uint_as_float(kSolarInvPdfBits);
         const Vec3 radiance = rad0 + add;
         ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     }
@@ -1241,7 +1260,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTracePacket(DeviceScene scene, Wid
 }
 
 // Query path: offset hit points of a hit stream (the render path does this in kShade).
-__global__ void kHitPoints(DeviceScene scene, const float4* hit, float4* rayO, uint32_t n)
+__global__ void kHitPoints(DeviceScene scene, const float4* hit, P3* rayO, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1249,7 +1268,7 @@ __global__ void kHitPoints(DeviceScene scene, const float4* hit, float4* rayO, u
     const uint32_t tri = __float_as_uint(h.x);
     if (tri == kMiss) return;
     const Vec3 hp = hitPoint(scene, tri, h.y, h.z);
-    rayO[i] = make_float4(hp.x, hp.y, hp.z, 0.0f);
+    store3(rayO + i, hp);
 }
 
 // Queue occupancy per bounce: Q[b-1] paths enter bounce b (closest-hit rays), Q[b] of them hit
@@ -1686,7 +1705,8 @@ struct Renderer::Impl
     uint64_t                validPixels = 0;     // pixels of this rank's tiles that lie inside the frame
     unsigned long long      primaryRaysHost = 0; // samples traced x validPixels since the last resetStats()
     uint64_t                maxPaths = 0;
-    DeviceBuffer<float4>    sRayO, sRayD, sRayD2, sThr, sThr2, sRad, sHit, sPending, sNoise; // rayD / thr: double-buffered (PathStreams)
+    DeviceBuffer<P3>        sRayO, sRayD, sRayD2, sThr, sThr2, sPending; // queue-position arrays, packed xyz; rayD / thr: double-buffered (PathStreams)
+    DeviceBuffer<float4>    sRad, sHit, sNoise;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
     DeviceBuffer<unsigned long long> bounceTotals; // 2 x kMaxBounceStats
@@ -1861,18 +1881,18 @@ struct Renderer::Impl
     {
         if (n > 0xFFFFFFFFull) throw std::runtime_error("too many rays");
         ensurePathState(n);
-        std::vector<float4>   o(n), d(n);
+        std::vector<P3>       o(n), d(n);
         std::vector<uint32_t> ids(n);
         for (uint64_t i = 0; i < n; ++i)
         {
-            o[i] = make_float4(rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2], 0.0f);
-            d[i] = make_float4(rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5], 0.0f);
+            o[i] = P3{rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2]};
+            d[i] = P3{rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5]};
             ids[i] = static_cast<uint32_t>(i);
         }
         // every copy goes through the handle's stream: ordered behind a batch that may still be in flight there
         RF_HIP(hipStreamSynchronize(stream));
-        RF_HIP(hipMemcpyAsync(sRayO.ptr, o.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream));
-        RF_HIP(hipMemcpyAsync(sRayD.ptr, d.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream));
+        RF_HIP(hipMemcpyAsync(sRayO.ptr, o.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
+        RF_HIP(hipMemcpyAsync(sRayD.ptr, d.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
         RF_HIP(hipMemcpyAsync(queueA.ptr, ids.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         const uint32_t words = kLineWords * (1 + kShards);
         if (queueCounts.count < words) queueCounts.alloc(words);
@@ -1884,8 +1904,8 @@ struct Renderer::Impl
         if (shadow)
         {
             // rad = 0, pending = 1: rad.x becomes visibility * SOLAR_INV_PDF
-            std::vector<float4> ones(n, make_float4(1.0f, 1.0f, 1.0f, 0.0f));
-            RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream));
+            std::vector<P3> ones(n, P3{1.0f, 1.0f, 1.0f});
+            RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
             RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
             if (shadowNearestFirst)
@@ -1907,8 +1927,10 @@ struct Renderer::Impl
         RF_HIP(hipMemcpy(out0.data(), shadow ? sRad.ptr : sHit.ptr, n * sizeof(float4), hipMemcpyDeviceToHost));
         if (!shadow)
         {
+            std::vector<P3> packed(n);
+            RF_HIP(hipMemcpy(packed.data(), sRayO.ptr, n * sizeof(P3), hipMemcpyDeviceToHost));
             out1.resize(n);
-            RF_HIP(hipMemcpy(out1.data(), sRayO.ptr, n * sizeof(float4), hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < n; ++i) out1[i] = make_float4(packed[i].x, packed[i].y, packed[i].z, 0.0f);
         }
     }
 
