@@ -314,7 +314,8 @@ def main():
     avg_ms = s["ms_closest"] / launches
     rays_per_launch = s["closest_rays"] / launches
     roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=None, kernel="kTraceWide<closest>",
-                    avg_launch_ms=round(avg_ms, 4), launches=launches, rays_per_launch=int(rays_per_launch), compulsory_hbm_bytes_per_ray=44)
+                    avg_launch_ms=round(avg_ms, 4), launches=launches, rays_per_launch=int(rays_per_launch),
+                    compulsory_hbm_bytes_per_ray=40)   # 12 B origin + 12 B direction in (packed, at the ray's queue position: no queue read), 16 B hit record out
     pmc_path = os.path.join(ROOT, "profiles", "pmc_per_ray.json")
     if os.path.exists(pmc_path):
         try:
@@ -346,8 +347,8 @@ def main():
             triangle_tests_per_ray=round(cs["closest_triangle_tests"] / max(cs["closest_rays"], 1), 2),
             shadow_kernel_GBps=round(bytes_shadow / max(s["ms_shadow"], 1e-9) / 1e6, 1),
             # what the kernel itself requests: 56 of the 64 B of a wide record (one record = both children of a reference node,
-            # leaves are never fetched) + 36 B per triangle + ray I/O
-            requested_GBps=round((44 * cs["closest_rays"] + 56 * cs["closest_record_fetches"] + 36 * cs["closest_triangle_tests"]) / max(s["ms_closest"], 1e-9) / 1e6, 1),
+            # leaves are never fetched) + 36 B per triangle + ray I/O (24 B in, 16 B out)
+            requested_GBps=round((40 * cs["closest_rays"] + 56 * cs["closest_record_fetches"] + 36 * cs["closest_triangle_tests"]) / max(s["ms_closest"], 1e-9) / 1e6, 1),
             record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2),
             note="SURVEY.md 8(d): 28 B ray in + 16 B hit out + 48 B per reference node visit + 48 B per triangle test; a cache rate (the BVH is "
                  "resident in L2 / Infinity Cache), reported for reference and not divided by the HBM peak")
