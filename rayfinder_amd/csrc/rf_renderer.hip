@@ -914,7 +914,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 }
                 if (COUNT) ++rayTris;
                 TriangleHit th;
-                if (intersectTriangle(vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, p0, p1, p2, rayTMax, th))
+                if (intersectTriangle(vec3(pr.oXY.x, pr.oXY.y, pr.oZ), rayDir, p0, p1, p2, rayTMax, th))
                 {
                     if (ANY_HIT)
                     {
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 TraversalCounters c2;
                 atomicAdd(&counters->scalarRedo[ANY_HIT ? 1 : 0], 1ull);
                 best.triangle = kMiss;
-                occluded = traverse<ANY_HIT, COUNT, 0>(scene, vec3(pr.oXY.x, pr.oXY.y, pr.oZX.x), rayDir, tMax, nullptr, best, c2);
+                occluded = traverse<ANY_HIT, COUNT, 0>(scene, vec3(pr.oXY.x, pr.oXY.y, pr.oZ), rayDir, tMax, nullptr, best, c2);
                 if (c2.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
                 rayTMax = best.triangle != kMiss ? best.t : tMax;
                 rayNodes = c2.nodesVisited;

@@ -9,8 +9,10 @@
 //
 //   * one record per INTERIOR node holding BOTH children's boxes (16 dwords = 64 B, 64-B aligned:
 //     one cache line, four dwordx4 loads, one dependent fetch per two box tests), laid out
-//     {c0.lo.xyz c0.hi.xyz c1.lo.xyz c1.hi.xyz | word0 word1 - -} so that consecutive float
-//     pairs are (x,y) (z,x) (y,z): six v_pk_add_f32 + six v_pk_mul_f32 do all twelve slab planes;
+//     {c0.lo.xy c0.hi.xy | c0.lo.z c0.hi.z c1.lo.z c1.hi.z | c1.lo.xy c1.hi.xy | word0 word1 - -} so that
+//     consecutive float pairs are (x,y) or (z,z): six v_pk_add_f32 + six v_pk_mul_f32 do all twelve slab
+//     planes, and the lane holds its ray ONCE ((x,y) as a register pair, z splatted by op_sel) -- the
+//     (x,y) (z,x) (y,z) pairing of a plain xyz order needs every component in two pairs, 6 VGPRs more;
 //   * the near child (reference order: dirNeg[splitAxis], wgsl:409-417) is handled at once; the
 //     far child is pushed together with its tmin only if P holds, and when popped it is accepted
 //     iff tmin < rayTMax *then* -- exactly the test the reference performs at pop time;
@@ -94,10 +96,10 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         const size_t   c0 = i + 1, c1 = n.secondChildOffset;
         const BvhNode &a = nodes[c0], &b = nodes[c1];
         float4*        w = &out.nodes[4 * static_cast<size_t>(wideIndex[i])];
-        // 12 box floats back to back so that the device forms (x,y) (z,x) (y,z) pairs for packed f32 math
-        w[0] = make_float4(a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, a.aabb.max.x);
-        w[1] = make_float4(a.aabb.max.y, a.aabb.max.z, b.aabb.min.x, b.aabb.min.y);
-        w[2] = make_float4(b.aabb.min.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z);
+        // 12 box floats as (x,y) and (z,z) pairs for packed f32 math (see the layout note above)
+        w[0] = make_float4(a.aabb.min.x, a.aabb.min.y, a.aabb.max.x, a.aabb.max.y);
+        w[1] = make_float4(a.aabb.min.z, a.aabb.max.z, b.aabb.min.z, b.aabb.max.z);
+        w[2] = make_float4(b.aabb.min.x, b.aabb.min.y, b.aabb.max.x, b.aabb.max.y);
         // 14 dwords are read per step: 12 box floats + the two child words (the split axis rides in the first word)
         w[3] = make_float4(bitsFloat(childWord(c0) | ((n.splitAxis & 3u) << kWideAxisShift)), bitsFloat(childWord(c1)), 0.0f, 0.0f);
         // the packed slab test assumes ordered, finite boxes (always true for boxes of real triangles)
@@ -158,8 +160,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct PackedRay
 {
-    v2f oXY, oZX, oYZ; // origin, in the pairings of the record's 12 floats
-    v2f iXY, iZX, iYZ; // 1 / direction
+    v2f   oXY, iXY; // origin and 1 / direction: x, y as a register pair
+    float oZ, iZ;   // z (splatted into both halves of a packed operand)
 };
 
 enum RayClass : uint32_t
@@ -182,28 +184,27 @@ __device__ __forceinline__ PackedRay packRay(const RayPrep& r)
 {
     PackedRay p;
     p.oXY = v2f{r.origin.x, r.origin.y};
-    p.oZX = v2f{r.origin.z, r.origin.x};
-    p.oYZ = v2f{r.origin.y, r.origin.z};
     p.iXY = v2f{r.invDir.x, r.invDir.y};
-    p.iZX = v2f{r.invDir.z, r.invDir.x};
-    p.iYZ = v2f{r.invDir.y, r.invDir.z};
+    p.oZ = r.origin.z;
+    p.iZ = r.invDir.z;
     return p;
 }
 
-// q0 = {c0.lo.xyz, c0.hi.x}  q1 = {c0.hi.yz, c1.lo.xy}  q2 = {c1.lo.z, c1.hi.xyz}
+// q0 = {c0.lo.xy, c0.hi.xy}  q1 = {c0.lo.z, c0.hi.z, c1.lo.z, c1.hi.z}  q2 = {c1.lo.xy, c1.hi.xy}
 // slabPairBounds: max3(near) / min3(far) of both boxes; slabPair: P and tmin from them.
 __device__ __forceinline__ void slabPairBounds(const PackedRay& r, float4 q0, float4 q1, float4 q2, float& near0, float& far0, float& near1, float& far1)
 {
+    const v2f oZZ = v2f{r.oZ, r.oZ}, iZZ = v2f{r.iZ, r.iZ};
     const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY; // c0: t(lo.x), t(lo.y)
-    const v2f b = (v2f{q0.z, q0.w} - r.oZX) * r.iZX; // c0: t(lo.z), t(hi.x)
-    const v2f c = (v2f{q1.x, q1.y} - r.oYZ) * r.iYZ; // c0: t(hi.y), t(hi.z)
-    const v2f d = (v2f{q1.z, q1.w} - r.oXY) * r.iXY; // c1: t(lo.x), t(lo.y)
-    const v2f e = (v2f{q2.x, q2.y} - r.oZX) * r.iZX; // c1: t(lo.z), t(hi.x)
-    const v2f f = (v2f{q2.z, q2.w} - r.oYZ) * r.iYZ; // c1: t(hi.y), t(hi.z)
-    near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.y), __builtin_fminf(a.y, c.x)), __builtin_fminf(b.x, c.y));
-    far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.y), __builtin_fmaxf(a.y, c.x)), __builtin_fmaxf(b.x, c.y));
-    near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d.x, e.y), __builtin_fminf(d.y, f.x)), __builtin_fminf(e.x, f.y));
-    far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(d.x, e.y), __builtin_fmaxf(d.y, f.x)), __builtin_fmaxf(e.x, f.y));
+    const v2f b = (v2f{q0.z, q0.w} - r.oXY) * r.iXY; // c0: t(hi.x), t(hi.y)
+    const v2f c = (v2f{q1.x, q1.y} - oZZ) * iZZ;     // c0: t(lo.z), t(hi.z)
+    const v2f d = (v2f{q1.z, q1.w} - oZZ) * iZZ;     // c1: t(lo.z), t(hi.z)
+    const v2f e = (v2f{q2.x, q2.y} - r.oXY) * r.iXY; // c1: t(lo.x), t(lo.y)
+    const v2f f = (v2f{q2.z, q2.w} - r.oXY) * r.iXY; // c1: t(hi.x), t(hi.y)
+    near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)), __builtin_fminf(c.x, c.y));
+    far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(c.x, c.y));
+    near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(e.x, f.x), __builtin_fminf(e.y, f.y)), __builtin_fminf(d.x, d.y));
+    far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(e.x, f.x), __builtin_fmaxf(e.y, f.y)), __builtin_fmaxf(d.x, d.y));
 }
 __device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q1, float4 q2, bool& ok0, float& tmin0, bool& ok1, float& tmin1)
 {
@@ -216,12 +217,13 @@ __device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q
 // Class B lanes only: is any of the twelve slab products of this record NaN (0 * inf)?
 __device__ __forceinline__ bool slabPairHasNaN(const PackedRay& r, float4 q0, float4 q1, float4 q2)
 {
+    const v2f oZZ = v2f{r.oZ, r.oZ}, iZZ = v2f{r.iZ, r.iZ};
     const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY;
-    const v2f b = (v2f{q0.z, q0.w} - r.oZX) * r.iZX;
-    const v2f c = (v2f{q1.x, q1.y} - r.oYZ) * r.iYZ;
-    const v2f d = (v2f{q1.z, q1.w} - r.oXY) * r.iXY;
-    const v2f e = (v2f{q2.x, q2.y} - r.oZX) * r.iZX;
-    const v2f f = (v2f{q2.z, q2.w} - r.oYZ) * r.iYZ;
+    const v2f b = (v2f{q0.z, q0.w} - r.oXY) * r.iXY;
+    const v2f c = (v2f{q1.x, q1.y} - oZZ) * iZZ;
+    const v2f d = (v2f{q1.z, q1.w} - oZZ) * iZZ;
+    const v2f e = (v2f{q2.x, q2.y} - r.oXY) * r.iXY;
+    const v2f f = (v2f{q2.z, q2.w} - r.oXY) * r.iXY;
     return __builtin_isunordered(a.x, a.y) || __builtin_isunordered(b.x, b.y) || __builtin_isunordered(c.x, c.y) ||
            __builtin_isunordered(d.x, d.y) || __builtin_isunordered(e.x, e.y) || __builtin_isunordered(f.x, f.y);
 }
