@@ -605,7 +605,7 @@ constexpr int wideStackDepth()
     return (COUNT && !NEAREST_FIRST) ? 28 : kWideLdsStack;
 }
 
-template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false>
+template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
                                                                                         const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
                                                                                         DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
@@ -613,6 +613,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 {
     constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
     constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
+    static_assert(!(COMPACT && COUNT), "the compact-record variant has no counting build");
     __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
@@ -630,6 +631,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     uint32_t  node = kNodeIdle;
     uint32_t  slot = 0;
     uint32_t  resultIndex = 0; // queue position of the lane's ray
+    // COMPACT: t-values of the x planes of the node the lane is about to visit, in hand when it enters the node straight from its
+    // parent's step (rf_wide.hpp, compact-capable records); a lane that arrives from the stack or starts at the root reads them
+    float tOuterLo = 0.0f, tOuterHi = 0.0f;
+    bool  haveOuter = false;
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
@@ -651,6 +656,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 
     // Pop entries until one passes `tmin < rayTMax` (the reference's box test at pop time).
     auto popNext = [&]() {
+        if (COMPACT) haveOuter = false;
         node = kNodeDone;
         while (stackSize > 0)
         {
@@ -718,6 +724,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 stackSize = 0;
                 best.triangle = kMiss;
                 occluded = false;
+                if (COMPACT) haveOuter = false;
                 rayNodes = 1; // the root visit (wgsl:379-382)
                 rayTris = 0;
                 rayStackHigh = 0;
@@ -763,6 +770,63 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     q0 = a0, q1 = a1, q2 = a2;
 #endif
                 };
+                float c0LoX = 0.0f, c0HiX = 0.0f, c1LoX = 0.0f, c1HiX = 0.0f; // COMPACT: the children's x-plane t-values
+                if constexpr (COMPACT)
+                {
+                    // Compact-capable records: three dwordx4 per step; the fourth piece (the node's own x planes) only for lanes that
+                    // do not carry them -- 11 % of the steps (after a pop, at the root).
+                    const auto compactStep = [&](float4 a0, float4 a1, float4 a2) {
+                        words = make_uint2(__float_as_uint(a2.x), __float_as_uint(a2.z));
+                        const bool selLo = (words.y & (1u << kWideAxisShift)) != 0u, selHi = (words.y & (2u << kWideAxisShift)) != 0u;
+                        words.y &= ~(3u << kWideAxisShift);
+                        float far0, far1;
+                        slabPairCompactBounds(pr, a0, a1, a2, tOuterLo, tOuterHi, selLo, selHi, t0, far0, t1, far1, c0LoX, c0HiX, c1LoX, c1HiX);
+                        asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1)); // (min/max chains stay with their products: see slabStep)
+                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairCompactHasNaN(pr, a0, a1, a2, c0LoX, c0HiX, c1LoX, c1HiX);
+                        ok0 = t0 <= far0 && far0 > 0.0f;
+                        ok1 = t1 <= far1 && far1 > 0.0f;
+                    };
+                    const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
+                    if (uniformFetch && __ballot(node != uNode) == 0ull)
+                    {
+                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                        const float4* un = wide.compact + 4 * static_cast<size_t>(uNode);
+                        u8v           a;
+                        u4v           b;
+                        u2v           c;
+                        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&s"(a), "=&s"(b), "=&s"(c)
+                                     : "s"(un)
+                                     : "memory");
+                        if (!haveOuter)
+                        {
+                            tOuterLo = (__uint_as_float(c.x) - pr.oXY.x) * pr.iXY.x;
+                            tOuterHi = (__uint_as_float(c.y) - pr.oXY.x) * pr.iXY.x;
+                        }
+                        compactStep(make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
+                                    make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)),
+                                    make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)));
+                    }
+                    else
+                    {
+                        const float4* n = wide.compact + 4 * static_cast<size_t>(node);
+                        const float4  v0 = n[0], v1 = n[1], v2 = n[2];
+                        if (!haveOuter)
+                        {
+                            const uint2* outerPtr = reinterpret_cast<const uint2*>(n + 3);
+                            asm volatile("" : "+v"(outerPtr)); // (see the words load of the plain layout below: an 8-byte global load, not widened)
+                            typedef const unsigned long long __attribute__((address_space(1)))* GlobalWordPtr;
+                            const unsigned long long both = *(GlobalWordPtr)(outerPtr);
+                            tOuterLo = (__uint_as_float(static_cast<uint32_t>(both)) - pr.oXY.x) * pr.iXY.x;
+                            tOuterHi = (__uint_as_float(static_cast<uint32_t>(both >> 32)) - pr.oXY.x) * pr.iXY.x;
+                        }
+                        compactStep(v0, v1, v2);
+                    }
+                }
+                else
+                {
                 // With the pixel-major, direction-sorted slot order the 64 rays of a wave are one pixel's samples, and at
                 // bounce 1 (and for the first steps of any freshly filled wave) every descending lane sits at the SAME
                 // record.  Then the record comes through the scalar cache with three s_load instructions instead of
@@ -803,6 +867,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     const unsigned long long both = *(GlobalWordPtr)(wordPtr);
                     words = make_uint2(static_cast<uint32_t>(both), static_cast<uint32_t>(both >> 32));
                     slabStep(v0, v1, v2);
+                }
                 }
                 const uint32_t axis = (words.x >> kWideAxisShift) & 3u;
                 const uint32_t word0 = words.x & ~(3u << kWideAxisShift), word1 = words.y;
@@ -863,6 +928,13 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     if (hit0 || hit1)
                     {
                         node = firstWord;
+                        if (COMPACT)
+                        {
+                            // the child entered straight from this step: its own x-plane t-values travel with the lane
+                            tOuterLo = second ? c1LoX : c0LoX;
+                            tOuterHi = second ? c1HiX : c0HiX;
+                            haveOuter = true;
+                        }
                         if (both && !push(otherWord, otherT))
                         {
                             needScalar = true;
@@ -1675,7 +1747,7 @@ struct Renderer::Impl
     int         device = 0;
     hipStream_t stream = nullptr;
 
-    DeviceBuffer<float4>            nodes, triangles, wideNodes;
+    DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact;
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
     DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
@@ -1729,6 +1801,9 @@ struct Renderer::Impl
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
     bool                   optSampleSort = true, optAccumulateRuns = true;
+    uint32_t               optCompactFromBounce = 3;       // closest-hit launches of bounce >= this use the compact-capable records (0: never)
+    uint32_t               optCompactShadowFromBounce = 2; // ... and the shadow launches of bounce >= this
+    bool                   optQueryCompact = false;        // the ray-query entry points use the compact-capable records too (tests)
     uint32_t               optExtraLds = 0;      // experiment: dynamic LDS bytes added to the kTraceWide launches (lowers the occupancy)
     uint32_t               optPacketBounces = 0; // bounces 1..n traced by kTracePacket (one wave = one lockstep packet) instead of kTraceWide
     int                    optUniformFetch = 2; // scalar-cache fetch for wave-uniform steps: 0 = never (5 878 Mrays/s), 1 = records (6 039), 2 = records + leaf triangles (6 059), -1 = records at bounces 1-2 only
@@ -1908,7 +1983,10 @@ struct Renderer::Impl
             RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
             RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
-            if (shadowNearestFirst)
+            if (shadowNearestFirst && optQueryCompact && wide.compact != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, true, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (shadowNearestFirst)
                 hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
             else
@@ -1917,8 +1995,12 @@ struct Renderer::Impl
         }
         else
         {
-            hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                               queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+            if (optQueryCompact && wide.compact != nullptr)
+                hipLaunchKernelGGL((kTraceWide<false, false, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+            else
+                hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
             hipLaunchKernelGGL(kHitPoints, dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
         }
         RF_HIP(hipGetLastError());
@@ -2009,6 +2091,9 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
                 else if (bounce <= optPacketBounces)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
+                else if (wide.compact != nullptr && optCompactFromBounce != 0u && bounce >= optCompactFromBounce)
+                    hipLaunchKernelGGL((kTraceWide<false, false, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
                 else
                     hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
@@ -2036,6 +2121,9 @@ struct Renderer::Impl
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                    else if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce)
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                     else
                         hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
@@ -2103,6 +2191,12 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         m.wideNodes.upload(wb.nodes.data(), wb.nodes.size());
         m.bigLeaves.upload(wb.bigLeaves.data(), wb.bigLeaves.size());
         m.wide.nodes = m.wideNodes.ptr;
+        m.wide.compact = nullptr;
+        if (wb.compactUsable && !wb.compact.empty())
+        {
+            m.wideCompact.upload(wb.compact.data(), wb.compact.size());
+            m.wide.compact = m.wideCompact.ptr;
+        }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
         m.wide.rootHi = wb.rootHi;
@@ -2476,6 +2570,9 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "sample_sort") mImpl->optSampleSort = value != 0;
     else if (name == "accumulate_runs") mImpl->optAccumulateRuns = value != 0;
     else if (name == "uniform_fetch") mImpl->optUniformFetch = static_cast<int>(value);
+    else if (name == "compact_from_bounce") mImpl->optCompactFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "compact_shadow_from_bounce") mImpl->optCompactShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "query_compact") mImpl->optQueryCompact = value != 0;
     else if (name == "packet_bounces") mImpl->optPacketBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major

@@ -53,6 +53,7 @@ constexpr int      kWideLdsStack = 12;
 struct WideScene
 {
     const float4* nodes;     // 4 float4 per interior node
+    const float4* compact;   // the same records in the compact-capable layout (see buildWide), or nullptr
     const uint2*  bigLeaves; // {first triangle, count}
     float4        rootLo;    // root box (w unused)
     float4        rootHi;
@@ -63,6 +64,8 @@ struct WideScene
 struct WideBuild
 {
     std::vector<float4> nodes;
+    std::vector<float4> compact;       // compact-capable layout of the same records; empty when !compactUsable
+    bool                compactUsable = true; // every node's x planes are attained by one of its children (true for boxes built as unions)
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
@@ -102,6 +105,30 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         w[2] = make_float4(b.aabb.min.x, b.aabb.min.y, b.aabb.max.x, b.aabb.max.y);
         // 14 dwords are read per step: 12 box floats + the two child words (the split axis rides in the first word)
         w[3] = make_float4(bitsFloat(childWord(c0) | ((n.splitAxis & 3u) << kWideAxisShift)), bitsFloat(childWord(c1)), 0.0f, 0.0f);
+        // Compact-capable layout (kTraceWide<..., COMPACT>).  A node's box is the union of its children's, so each of its planes
+        // is attained by (at least) one child; a lane that enters the node straight from its parent's step has the t-values of
+        // the node's own planes in hand.  For the two x planes the record therefore names only the OTHER child's value ("inner")
+        // and which child that is (bits 30..29 of the second child word), which leaves everything a step needs in 12 dwords:
+        //     {innerLoX c0.lo.y innerHiX c0.hi.y | c0.lo.z c0.hi.z c1.lo.z c1.hi.z | word0 c1.lo.y word1 c1.hi.y | outerLoX outerHiX - -}
+        // = three dwordx4 instead of 3 + 1 loads per step, i.e. three vector-L1 tag accesses instead of four -- the unit the deep
+        // bounces exhaust.  The fourth piece (the shared values themselves) is read only by a lane that arrives from the stack or
+        // starts at the root.  Same planes, same (value - o) * inv per plane: bit-identical decisions.
+        {
+            if (out.compact.empty()) out.compact.resize(out.nodes.size());
+            float4*    c = &out.compact[4 * static_cast<size_t>(wideIndex[i])];
+            const bool loFromA = a.aabb.min.x == n.aabb.min.x, loFromB = b.aabb.min.x == n.aabb.min.x; // which child attains the node's min.x
+            const bool hiFromA = a.aabb.max.x == n.aabb.max.x, hiFromB = b.aabb.max.x == n.aabb.max.x;
+            if (!(loFromA || loFromB) || !(hiFromA || hiFromB)) out.compactUsable = false;
+            const uint32_t selLo = loFromA ? 1u : 0u, selHi = hiFromA ? 1u : 0u; // 1: child 1 holds the inner value (child 0 shares the node's plane)
+            const float    innerLo = selLo ? b.aabb.min.x : a.aabb.min.x, outerLo = selLo ? a.aabb.min.x : b.aabb.min.x;
+            const float    innerHi = selHi ? b.aabb.max.x : a.aabb.max.x, outerHi = selHi ? a.aabb.max.x : b.aabb.max.x;
+            const uint32_t w0 = childWord(c0) | ((n.splitAxis & 3u) << kWideAxisShift), w1 = childWord(c1);
+            if ((w1 & (3u << kWideAxisShift)) != 0u) out.compactUsable = false; // (cannot happen: those bits are free in the second word)
+            c[0] = make_float4(innerLo, a.aabb.min.y, innerHi, a.aabb.max.y);
+            c[1] = make_float4(a.aabb.min.z, a.aabb.max.z, b.aabb.min.z, b.aabb.max.z);
+            c[2] = make_float4(bitsFloat(w0), b.aabb.min.y, bitsFloat(w1 | (selLo << kWideAxisShift) | (selHi << (kWideAxisShift + 1))), b.aabb.max.y);
+            c[3] = make_float4(outerLo, outerHi, 0.0f, 0.0f);
+        }
         // the packed slab test assumes ordered, finite boxes (always true for boxes of real triangles)
         const float lo[6] = {a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, b.aabb.min.x, b.aabb.min.y, b.aabb.min.z};
         const float hi[6] = {a.aabb.max.x, a.aabb.max.y, a.aabb.max.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z};
@@ -109,6 +136,8 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
             if (!(std::fabs(lo[k]) < 1e30f && std::fabs(hi[k]) < 1e30f && lo[k] <= hi[k])) out.boxesRegular = false;
     }
     if (out.bigLeaves.empty()) out.bigLeaves.push_back(make_uint2(0, 0));
+    if (!out.boxesRegular) out.compactUsable = false;
+    if (!out.compactUsable || numInterior == 0) out.compact.clear();
     return out;
 }
 
@@ -212,6 +241,41 @@ __device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q
     slabPairBounds(r, q0, q1, q2, tmin0, far0, tmin1, far1);
     ok0 = tmin0 <= far0 && far0 > 0.0f;
     ok1 = tmin1 <= far1 && far1 > 0.0f;
+}
+
+// The compact-capable record (buildWide): q0 = {innerLoX c0.lo.y innerHiX c0.hi.y}  q1 = {c0.lo.z c0.hi.z c1.lo.z c1.hi.z}
+// q2 = {word0 c1.lo.y word1 c1.hi.y}; tOuterLo / tOuterHi = (value - o.x) * inv.x of the node's own x planes (carried from the
+// parent's step or computed from the record's fourth piece); selLo / selHi: child 1 holds the inner value.  Outputs as
+// slabPairBounds plus the four x-plane t-values of the children (what the lane carries into the child it enters).
+// (The x lanes of the two products on q2 work on the child words' bit patterns: never read.)
+__device__ __forceinline__ void slabPairCompactBounds(const PackedRay& r, float4 q0, float4 q1, float4 q2, float tOuterLo, float tOuterHi, bool selLo, bool selHi,
+                                                      float& near0, float& far0, float& near1, float& far1, float& c0LoX, float& c0HiX, float& c1LoX, float& c1HiX)
+{
+    const v2f oZZ = v2f{r.oZ, r.oZ}, iZZ = v2f{r.iZ, r.iZ};
+    const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY; // t(innerLoX), c0: t(lo.y)
+    const v2f b = (v2f{q0.z, q0.w} - r.oXY) * r.iXY; // t(innerHiX), c0: t(hi.y)
+    const v2f c = (v2f{q1.x, q1.y} - oZZ) * iZZ;     // c0: t(lo.z), t(hi.z)
+    const v2f d = (v2f{q1.z, q1.w} - oZZ) * iZZ;     // c1: t(lo.z), t(hi.z)
+    const v2f e = (v2f{q2.x, q2.y} - r.oXY) * r.iXY; // -, c1: t(lo.y)
+    const v2f f = (v2f{q2.z, q2.w} - r.oXY) * r.iXY; // -, c1: t(hi.y)
+    c0LoX = selLo ? tOuterLo : a.x;
+    c1LoX = selLo ? a.x : tOuterLo;
+    c0HiX = selHi ? tOuterHi : b.x;
+    c1HiX = selHi ? b.x : tOuterHi;
+    near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(c0LoX, c0HiX), __builtin_fminf(a.y, b.y)), __builtin_fminf(c.x, c.y));
+    far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(c0LoX, c0HiX), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(c.x, c.y));
+    near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(c1LoX, c1HiX), __builtin_fminf(e.y, f.y)), __builtin_fminf(d.x, d.y));
+    far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(c1LoX, c1HiX), __builtin_fmaxf(e.y, f.y)), __builtin_fmaxf(d.x, d.y));
+}
+
+// Class B lanes only: is any of the twelve slab products of this compact-capable record NaN (0 * inf)?  (The four x-plane values are
+// the step's own; the other eight are recomputed here, in the rare path.)
+__device__ __forceinline__ bool slabPairCompactHasNaN(const PackedRay& r, float4 q0, float4 q1, float4 q2, float c0LoX, float c0HiX, float c1LoX, float c1HiX)
+{
+    const float ay = (q0.y - r.oXY.y) * r.iXY.y, by = (q0.w - r.oXY.y) * r.iXY.y, ey = (q2.y - r.oXY.y) * r.iXY.y, fy = (q2.w - r.oXY.y) * r.iXY.y;
+    const float cx = (q1.x - r.oZ) * r.iZ, cy = (q1.y - r.oZ) * r.iZ, dx = (q1.z - r.oZ) * r.iZ, dy = (q1.w - r.oZ) * r.iZ;
+    return __builtin_isunordered(c0LoX, c0HiX) || __builtin_isunordered(c1LoX, c1HiX) || __builtin_isunordered(ay, by) || __builtin_isunordered(cx, cy) ||
+           __builtin_isunordered(dx, dy) || __builtin_isunordered(ey, fy);
 }
 
 // Class B lanes only: is any of the twelve slab products of this record NaN (0 * inf)?

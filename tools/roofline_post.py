@@ -93,10 +93,16 @@ print(json.dumps(factors, indent=1))
 # ---------------------------------------------------------------- the bench command
 bench = json.loads(open(os.path.join(out, "bench_under_trace.json")).read().strip().splitlines()[-1])
 pm = merged("pmc", 7)
-K = "kTraceWide<false, false, false>"
-k = pm.get(K)
-if not k:
-    raise SystemExit(f"{K} not found in the PMC summaries: {list(pm)}")
+# The closest-hit traversal is one kernel template in two instantiations: kTraceWide<false, false, false, false> (bounces 1-2, plain
+# 64-byte records) and kTraceWide<false, false, false, true> (bounces >= 3, compact-capable records).  Their dispatches are summed.
+KS = [n for n in pm if n.startswith("kTraceWide<false, false, false")]
+if not KS:
+    raise SystemExit(f"no closest-hit kTraceWide instantiation in the PMC summaries: {list(pm)}")
+k = {"_dispatches": sum(pm[n]["_dispatches"] for n in KS)}
+for n in KS:
+    for c, v in pm[n].items():
+        if c != "_dispatches":
+            k[c] = k.get(c, 0.0) + v * pm[n]["_dispatches"] / k["_dispatches"]        # average over ALL closest-hit dispatches
 # rays behind the counters: every dispatch of the kernel in the profiled process = warm-up + timed steps (the counting pass
 # is off); the same frame is traced throughout, so rays scale with the samples.  `rays` = rays per AVERAGE dispatch.
 timed_rays = bench["roofline"]["rays_per_launch"] * bench["roofline"]["launches"]
@@ -110,7 +116,7 @@ write = k["WRITE_SIZE"] * 1024.0 / rays
 fc = factors["fetch_calibration"] or 1.0
 wc = factors["write_calibration"] or 1.0
 per_ray = dict(
-    profile=os.path.basename(os.path.abspath(out)), kernel="kTraceWide<closest>", workload=f"{name} {W}x{H}x{B}",
+    profile=os.path.basename(os.path.abspath(out)), kernel="kTraceWide<closest>", instantiations={n: pm[n]["_dispatches"] for n in KS}, workload=f"{name} {W}x{H}x{B}",
     rays_per_average_dispatch=round(rays), dispatches_averaged=k["_dispatches"], steps=bench["steps"], warmup=bench["warmup"],
     fetch_size_bytes_per_ray=round(fetch, 2), write_size_bytes_per_ray=round(write, 2),
     fetch_calibration=round(fc, 4), write_calibration=round(wc, 4),
