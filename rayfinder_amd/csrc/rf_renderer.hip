@@ -605,7 +605,7 @@ constexpr int wideStackDepth()
     return (COUNT && !NEAREST_FIRST) ? 28 : kWideLdsStack;
 }
 
-template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, bool COMPACT = false>
+template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, int COMPACT = 0>
 __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
                                                                                         const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
                                                                                         DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 {
     constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
     constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
-    static_assert(!(COMPACT && COUNT), "the compact-record variant has no counting build");
+    static_assert(!(COMPACT != 0 && COUNT), "the compact-record variants have no counting build");
     __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
@@ -635,6 +635,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // parent's step (rf_wide.hpp, compact-capable records); a lane that arrives from the stack or starts at the root reads them
     float tOuterLo = 0.0f, tOuterHi = 0.0f;
     bool  haveOuter = false;
+    // COMPACT == 2 (32-byte records): the t-values of all six planes of that node's box
+    BoxT  own{};
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
@@ -656,7 +658,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 
     // Pop entries until one passes `tmin < rayTMax` (the reference's box test at pop time).
     auto popNext = [&]() {
-        if (COMPACT) haveOuter = false;
+        if (COMPACT != 0) haveOuter = false;
         node = kNodeDone;
         while (stackSize > 0)
         {
@@ -724,7 +726,13 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 stackSize = 0;
                 best.triangle = kMiss;
                 occluded = false;
-                if (COMPACT) haveOuter = false;
+                if (COMPACT == 1) haveOuter = false;
+                if (COMPACT == 2)
+                {
+                    // the root's own box is a kernel argument: no fetch for it
+                    own = boxPlaneT(pr, make_float4(wide.rootLo.x, wide.rootLo.y, wide.rootHi.x, wide.rootHi.y), wide.rootLo.z, wide.rootHi.z);
+                    haveOuter = true;
+                }
                 rayNodes = 1; // the root visit (wgsl:379-382)
                 rayTris = 0;
                 rayStackHigh = 0;
@@ -771,16 +779,61 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 #endif
                 };
                 float c0LoX = 0.0f, c0HiX = 0.0f, c1LoX = 0.0f, c1HiX = 0.0f; // COMPACT: the children's x-plane t-values
-                if constexpr (COMPACT)
+                BoxT  c0b{}, c1b{};                                             // COMPACT == 2: all six
+                if constexpr (COMPACT == 2)
+                {
+                    // 32-byte records: two dwordx4 per step; the node's own box (second array) only for lanes that arrive from the stack
+                    const auto hotStep = [&](float4 h0, float4 h1) {
+                        words = make_uint2(__float_as_uint(h1.z), __float_as_uint(h1.w));
+                        float far0, far1;
+                        slabPairHotBounds(pr, h0, h1.x, h1.y, words.x, words.y, own, t0, far0, t1, far1, c0b, c1b);
+                        asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1)); // (min/max chains stay with their products: see slabStep)
+                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = boxPairHasNaN(c0b, c1b);
+                        ok0 = t0 <= far0 && far0 > 0.0f;
+                        ok1 = t1 <= far1 && far1 > 0.0f;
+                        words.x &= ~(3u << 24);
+                        words.y &= ~((3u << 24) | (3u << kWideAxisShift));
+                    };
+                    const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
+                    if (uniformFetch && __ballot(node != uNode) == 0ull)
+                    {
+                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                        const float4* un = wide.hot + 2 * static_cast<size_t>(uNode);
+                        const float4* uo = wide.own + 2 * static_cast<size_t>(uNode);
+                        u8v           a, b;
+                        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(un), "s"(uo) : "memory");
+                        if (!haveOuter)
+                            own = boxPlaneT(pr, make_float4(__uint_as_float(b.s0), __uint_as_float(b.s1), __uint_as_float(b.s2), __uint_as_float(b.s3)), __uint_as_float(b.s4),
+                                            __uint_as_float(b.s5));
+                        hotStep(make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
+                                make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)));
+                    }
+                    else
+                    {
+                        const float4* n = wide.hot + 2 * static_cast<size_t>(node);
+                        const float4  v0 = n[0], v1 = n[1];
+                        if (!haveOuter)
+                        {
+                            const float4* o = wide.own + 2 * static_cast<size_t>(node);
+                            const float4  o0 = o[0];
+                            const uint2*  zPtr = reinterpret_cast<const uint2*>(o + 1);
+                            asm volatile("" : "+v"(zPtr)); // (an 8-byte global load, not widened: see the words load of the plain layout below)
+                            typedef const unsigned long long __attribute__((address_space(1)))* GlobalWordPtr;
+                            const unsigned long long both = *(GlobalWordPtr)(zPtr);
+                            own = boxPlaneT(pr, o0, __uint_as_float(static_cast<uint32_t>(both)), __uint_as_float(static_cast<uint32_t>(both >> 32)));
+                        }
+                        hotStep(v0, v1);
+                    }
+                }
+                else if constexpr (COMPACT == 1)
                 {
                     // Compact-capable records: three dwordx4 per step; the fourth piece (the node's own x planes) only for lanes that
                     // do not carry them -- 11 % of the steps (after a pop, at the root).
                     const auto compactStep = [&](float4 a0, float4 a1, float4 a2) {
                         words = make_uint2(__float_as_uint(a2.x), __float_as_uint(a2.z));
-                        const bool selLo = (words.y & (1u << kWideAxisShift)) != 0u, selHi = (words.y & (2u << kWideAxisShift)) != 0u;
-                        words.y &= ~(3u << kWideAxisShift);
                         float far0, far1;
-                        slabPairCompactBounds(pr, a0, a1, a2, tOuterLo, tOuterHi, selLo, selHi, t0, far0, t1, far1, c0LoX, c0HiX, c1LoX, c1HiX);
+                        slabPairCompactBounds(pr, a0, a1, a2, tOuterLo, tOuterHi, words.y, t0, far0, t1, far1, c0LoX, c0HiX, c1LoX, c1HiX);
+                        words.y &= ~(3u << kWideAxisShift);
                         asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1)); // (min/max chains stay with their products: see slabStep)
                         if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairCompactHasNaN(pr, a0, a1, a2, c0LoX, c0HiX, c1LoX, c1HiX);
                         ok0 = t0 <= far0 && far0 > 0.0f;
@@ -928,11 +981,19 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     if (hit0 || hit1)
                     {
                         node = firstWord;
-                        if (COMPACT)
+                        if (COMPACT == 1)
                         {
                             // the child entered straight from this step: its own x-plane t-values travel with the lane
                             tOuterLo = second ? c1LoX : c0LoX;
                             tOuterHi = second ? c1HiX : c0HiX;
+                            haveOuter = true;
+                        }
+                        if (COMPACT == 2)
+                        {
+                            // ... all six of them with the 32-byte records
+                            own.loX = second ? c1b.loX : c0b.loX, own.loY = second ? c1b.loY : c0b.loY;
+                            own.hiX = second ? c1b.hiX : c0b.hiX, own.hiY = second ? c1b.hiY : c0b.hiY;
+                            own.loZ = second ? c1b.loZ : c0b.loZ, own.hiZ = second ? c1b.hiZ : c0b.hiZ;
                             haveOuter = true;
                         }
                         if (both && !push(otherWord, otherT))
@@ -1747,7 +1808,7 @@ struct Renderer::Impl
     int         device = 0;
     hipStream_t stream = nullptr;
 
-    DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact;
+    DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact, wideHot, wideOwn;
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
     DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
@@ -1803,7 +1864,8 @@ struct Renderer::Impl
     bool                   optSampleSort = true, optAccumulateRuns = true;
     uint32_t               optCompactFromBounce = 3;       // closest-hit launches of bounce >= this use the compact-capable records (0: never)
     uint32_t               optCompactShadowFromBounce = 2; // ... and the shadow launches of bounce >= this
-    bool                   optQueryCompact = false;        // the ray-query entry points use the compact-capable records too (tests)
+    uint32_t               optHotFromBounce = 0, optHotShadowFromBounce = 0; // the 32-byte records (all six planes carried) from this bounce on (0: never); takes precedence
+    int                    optQueryCompact = 0;            // the ray-query entry points use the compact-capable (1) / 32-byte (2) records too (tests)
     uint32_t               optExtraLds = 0;      // experiment: dynamic LDS bytes added to the kTraceWide launches (lowers the occupancy)
     uint32_t               optPacketBounces = 0; // bounces 1..n traced by kTracePacket (one wave = one lockstep packet) instead of kTraceWide
     int                    optUniformFetch = 2; // scalar-cache fetch for wave-uniform steps: 0 = never (5 878 Mrays/s), 1 = records (6 039), 2 = records + leaf triangles (6 059), -1 = records at bounces 1-2 only
@@ -1983,8 +2045,11 @@ struct Renderer::Impl
             RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
             RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
-            if (shadowNearestFirst && optQueryCompact && wide.compact != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, true, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+            if (shadowNearestFirst && optQueryCompact == 2 && wide.hot != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (shadowNearestFirst && optQueryCompact == 1 && wide.compact != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
             else if (shadowNearestFirst)
                 hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
@@ -1995,8 +2060,11 @@ struct Renderer::Impl
         }
         else
         {
-            if (optQueryCompact && wide.compact != nullptr)
-                hipLaunchKernelGGL((kTraceWide<false, false, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+            if (optQueryCompact == 2 && wide.hot != nullptr)
+                hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+            else if (optQueryCompact == 1 && wide.compact != nullptr)
+                hipLaunchKernelGGL((kTraceWide<false, false, false, 1>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
             else
                 hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
@@ -2091,8 +2159,11 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
                 else if (bounce <= optPacketBounces)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
+                else if (wide.hot != nullptr && optHotFromBounce != 0u && bounce >= optHotFromBounce)
+                    hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
                 else if (wide.compact != nullptr && optCompactFromBounce != 0u && bounce >= optCompactFromBounce)
-                    hipLaunchKernelGGL((kTraceWide<false, false, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                    hipLaunchKernelGGL((kTraceWide<false, false, false, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
                 else
                     hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
@@ -2122,8 +2193,11 @@ struct Renderer::Impl
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                    else if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce)
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                     else if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce)
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
                     else
                         hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
@@ -2196,6 +2270,14 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         {
             m.wideCompact.upload(wb.compact.data(), wb.compact.size());
             m.wide.compact = m.wideCompact.ptr;
+        }
+        m.wide.hot = m.wide.own = nullptr;
+        if (wb.hotUsable && !wb.hot.empty())
+        {
+            m.wideHot.upload(wb.hot.data(), wb.hot.size());
+            m.wideOwn.upload(wb.own.data(), wb.own.size());
+            m.wide.hot = m.wideHot.ptr;
+            m.wide.own = m.wideOwn.ptr;
         }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
@@ -2572,7 +2654,9 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "uniform_fetch") mImpl->optUniformFetch = static_cast<int>(value);
     else if (name == "compact_from_bounce") mImpl->optCompactFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "compact_shadow_from_bounce") mImpl->optCompactShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
-    else if (name == "query_compact") mImpl->optQueryCompact = value != 0;
+    else if (name == "query_compact") mImpl->optQueryCompact = static_cast<int>(value);
+    else if (name == "hot_from_bounce") mImpl->optHotFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "hot_shadow_from_bounce") mImpl->optHotShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "packet_bounces") mImpl->optPacketBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major

@@ -54,6 +54,8 @@ struct WideScene
 {
     const float4* nodes;     // 4 float4 per interior node
     const float4* compact;   // the same records in the compact-capable layout (see buildWide), or nullptr
+    const float4* hot;       // 2 float4 per interior node: the 32-byte records of the all-planes-carried layout (see buildWide), or nullptr
+    const float4* own;       // 2 float4 per interior node: the node's own box {lo.x lo.y hi.x hi.y} {lo.z hi.z - -} (read after a pop only)
     const uint2*  bigLeaves; // {first triangle, count}
     float4        rootLo;    // root box (w unused)
     float4        rootHi;
@@ -66,6 +68,8 @@ struct WideBuild
     std::vector<float4> nodes;
     std::vector<float4> compact;       // compact-capable layout of the same records; empty when !compactUsable
     bool                compactUsable = true; // every node's x planes are attained by one of its children (true for boxes built as unions)
+    std::vector<float4> hot, own;      // the 32-byte layout (all six planes carried) and the nodes' own boxes; empty when !hotUsable
+    bool                hotUsable = true; // every plane of every node is attained by a child AND every index fits 24 bits
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
@@ -122,12 +126,49 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
             const uint32_t selLo = loFromA ? 1u : 0u, selHi = hiFromA ? 1u : 0u; // 1: child 1 holds the inner value (child 0 shares the node's plane)
             const float    innerLo = selLo ? b.aabb.min.x : a.aabb.min.x, outerLo = selLo ? a.aabb.min.x : b.aabb.min.x;
             const float    innerHi = selHi ? b.aabb.max.x : a.aabb.max.x, outerHi = selHi ? a.aabb.max.x : b.aabb.max.x;
-            const uint32_t w0 = childWord(c0) | ((n.splitAxis & 3u) << kWideAxisShift), w1 = childWord(c1);
+            const uint32_t w0 = floatBits(w[3].x), w1 = floatBits(w[3].y); // the plain record's child words (split axis in word0)
             if ((w1 & (3u << kWideAxisShift)) != 0u) out.compactUsable = false; // (cannot happen: those bits are free in the second word)
             c[0] = make_float4(innerLo, a.aabb.min.y, innerHi, a.aabb.max.y);
             c[1] = make_float4(a.aabb.min.z, a.aabb.max.z, b.aabb.min.z, b.aabb.max.z);
             c[2] = make_float4(bitsFloat(w0), b.aabb.min.y, bitsFloat(w1 | (selLo << kWideAxisShift) | (selHi << (kWideAxisShift + 1))), b.aabb.max.y);
             c[3] = make_float4(outerLo, outerHi, 0.0f, 0.0f);
+        }
+        // The 32-byte layout (kTraceWide<..., COMPACT = 2>) takes the same idea to all six planes: the lane carries the t-values
+        // of the whole box of the node it enters from its parent's step, and a step reads
+        //     {innerLoX innerLoY innerHiX innerHiY | innerLoZ innerHiZ word0 word1}
+        // = TWO dwordx4 (two vector-L1 tag accesses, one 32-byte piece of a line: two records per 64-byte L2 request, four per
+        // 128-byte line) with six selector bits in the child words: bits 25..24 of word0 = {lo.x, lo.y}, bits 25..24 of
+        // word1 = {hi.x, hi.y}, bits 30..29 of word1 = {lo.z, hi.z}; selector 1: child 0 shares the node's plane and child 1 holds
+        // the inner value.  The index fields shrink to 24 bits for it.  The node's own box sits in a second array that only
+        // a lane arriving from the stack reads (the root's box is a kernel argument).
+        {
+            if (out.hot.empty())
+            {
+                out.hot.resize(out.nodes.size() / 2);
+                out.own.resize(out.nodes.size() / 2);
+            }
+            float4*        h = &out.hot[2 * static_cast<size_t>(wideIndex[i])];
+            float4*        o = &out.own[2 * static_cast<size_t>(wideIndex[i])];
+            const float    nv[6] = {n.aabb.min.x, n.aabb.min.y, n.aabb.max.x, n.aabb.max.y, n.aabb.min.z, n.aabb.max.z};
+            const float    av[6] = {a.aabb.min.x, a.aabb.min.y, a.aabb.max.x, a.aabb.max.y, a.aabb.min.z, a.aabb.max.z};
+            const float    bv[6] = {b.aabb.min.x, b.aabb.min.y, b.aabb.max.x, b.aabb.max.y, b.aabb.min.z, b.aabb.max.z};
+            float          inner[6];
+            uint32_t       sel[6];
+            for (int k = 0; k < 6; ++k)
+            {
+                const bool fromA = av[k] == nv[k], fromB = bv[k] == nv[k];
+                if (!(fromA || fromB)) out.hotUsable = false;
+                sel[k] = fromA ? 1u : 0u;
+                inner[k] = fromA ? bv[k] : av[k];
+            }
+            uint32_t w0 = floatBits(w[3].x), w1 = floatBits(w[3].y); // the plain record's child words (split axis in word0)
+            if (((w0 | w1) & (3u << 24)) != 0u) out.hotUsable = false; // an index that needs more than 24 bits
+            w0 |= (sel[0] << 25) | (sel[1] << 24);
+            w1 |= (sel[2] << 25) | (sel[3] << 24) | (sel[4] << 30) | (sel[5] << 29);
+            h[0] = make_float4(inner[0], inner[1], inner[2], inner[3]);
+            h[1] = make_float4(inner[4], inner[5], bitsFloat(w0), bitsFloat(w1));
+            o[0] = make_float4(nv[0], nv[1], nv[2], nv[3]);
+            o[1] = make_float4(nv[4], nv[5], 0.0f, 0.0f);
         }
         // the packed slab test assumes ordered, finite boxes (always true for boxes of real triangles)
         const float lo[6] = {a.aabb.min.x, a.aabb.min.y, a.aabb.min.z, b.aabb.min.x, b.aabb.min.y, b.aabb.min.z};
@@ -138,6 +179,12 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
     if (out.bigLeaves.empty()) out.bigLeaves.push_back(make_uint2(0, 0));
     if (!out.boxesRegular) out.compactUsable = false;
     if (!out.compactUsable || numInterior == 0) out.compact.clear();
+    if (!out.boxesRegular) out.hotUsable = false;
+    if (!out.hotUsable || numInterior == 0)
+    {
+        out.hot.clear();
+        out.own.clear();
+    }
     return out;
 }
 
@@ -243,12 +290,28 @@ __device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q
     ok1 = tmin1 <= far1 && far1 > 0.0f;
 }
 
+// (v_bfi_b32 / v_min_f32 / v_max3_f32 ... are written out: the carried t-values reach this block through phi nodes, the compiler
+// no longer knows them to be canonical and would spend twelve `v_max x, x` on quieting them in front of its own min / max;
+// none of them is a signalling NaN -- they are products -- and a quiet NaN means a class B ray, which is redone anyway.)
+__device__ __forceinline__ float isaMin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float isaMax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float isaMax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float isaMin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// bit `BIT` of `word` set ? a : b, as a bitwise select under the sign-extended bit (v_bfe_i32 + v_bfi_b32 per pair of selects)
+template<int BIT>
+__device__ __forceinline__ void swapUnderBit(uint32_t word, float shared, float inner, float& child0, float& child1)
+{
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "n"(BIT));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(child0) : "v"(m), "v"(shared), "v"(inner));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(child1) : "v"(m), "v"(inner), "v"(shared));
+}
 // The compact-capable record (buildWide): q0 = {innerLoX c0.lo.y innerHiX c0.hi.y}  q1 = {c0.lo.z c0.hi.z c1.lo.z c1.hi.z}
 // q2 = {word0 c1.lo.y word1 c1.hi.y}; tOuterLo / tOuterHi = (value - o.x) * inv.x of the node's own x planes (carried from the
 // parent's step or computed from the record's fourth piece); selLo / selHi: child 1 holds the inner value.  Outputs as
 // slabPairBounds plus the four x-plane t-values of the children (what the lane carries into the child it enters).
 // (The x lanes of the two products on q2 work on the child words' bit patterns: never read.)
-__device__ __forceinline__ void slabPairCompactBounds(const PackedRay& r, float4 q0, float4 q1, float4 q2, float tOuterLo, float tOuterHi, bool selLo, bool selHi,
+__device__ __forceinline__ void slabPairCompactBounds(const PackedRay& r, float4 q0, float4 q1, float4 q2, float tOuterLo, float tOuterHi, uint32_t word1,
                                                       float& near0, float& far0, float& near1, float& far1, float& c0LoX, float& c0HiX, float& c1LoX, float& c1HiX)
 {
     const v2f oZZ = v2f{r.oZ, r.oZ}, iZZ = v2f{r.iZ, r.iZ};
@@ -258,14 +321,50 @@ __device__ __forceinline__ void slabPairCompactBounds(const PackedRay& r, float4
     const v2f d = (v2f{q1.z, q1.w} - oZZ) * iZZ;     // c1: t(lo.z), t(hi.z)
     const v2f e = (v2f{q2.x, q2.y} - r.oXY) * r.iXY; // -, c1: t(lo.y)
     const v2f f = (v2f{q2.z, q2.w} - r.oXY) * r.iXY; // -, c1: t(hi.y)
-    c0LoX = selLo ? tOuterLo : a.x;
-    c1LoX = selLo ? a.x : tOuterLo;
-    c0HiX = selHi ? tOuterHi : b.x;
-    c1HiX = selHi ? b.x : tOuterHi;
-    near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(c0LoX, c0HiX), __builtin_fminf(a.y, b.y)), __builtin_fminf(c.x, c.y));
-    far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(c0LoX, c0HiX), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(c.x, c.y));
-    near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(c1LoX, c1HiX), __builtin_fminf(e.y, f.y)), __builtin_fminf(d.x, d.y));
-    far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(c1LoX, c1HiX), __builtin_fmaxf(e.y, f.y)), __builtin_fmaxf(d.x, d.y));
+    swapUnderBit<kWideAxisShift>(word1, tOuterLo, a.x, c0LoX, c1LoX);
+    swapUnderBit<kWideAxisShift + 1>(word1, tOuterHi, b.x, c0HiX, c1HiX);
+    near0 = isaMax3(isaMin(c0LoX, c0HiX), isaMin(a.y, b.y), isaMin(c.x, c.y));
+    far0 = isaMin3(isaMax(c0LoX, c0HiX), isaMax(a.y, b.y), isaMax(c.x, c.y));
+    near1 = isaMax3(isaMin(c1LoX, c1HiX), isaMin(e.y, f.y), isaMin(d.x, d.y));
+    far1 = isaMin3(isaMax(c1LoX, c1HiX), isaMax(e.y, f.y), isaMax(d.x, d.y));
+}
+
+// The 32-byte record (buildWide): h0 = {innerLoX innerLoY innerHiX innerHiY}, h1 = {innerLoZ innerHiZ word0 word1}.  `own` = the
+// t-values (value - o) * inv of the six planes of the node's own box, carried from the parent's step (or computed from the
+// own-box array after a pop / from the root box at refill).  Per plane the selector bit says which child shares the node's plane
+// (1: child 0) -- the other one gets the record's inner value.  Same planes and the same product per plane as slabPairBounds().
+struct BoxT
+{
+    float loX, loY, hiX, hiY, loZ, hiZ;
+};
+__device__ __forceinline__ BoxT boxPlaneT(const PackedRay& r, float4 q0, float q1x, float q1y) // q0 = {lo.x lo.y hi.x hi.y}, q1 = {lo.z hi.z}
+{
+    const v2f oZZ = v2f{r.oZ, r.oZ}, iZZ = v2f{r.iZ, r.iZ};
+    const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY;
+    const v2f b = (v2f{q0.z, q0.w} - r.oXY) * r.iXY;
+    const v2f c = (v2f{q1x, q1y} - oZZ) * iZZ;
+    return BoxT{a.x, a.y, b.x, b.y, c.x, c.y};
+}
+__device__ __forceinline__ void slabPairHotBounds(const PackedRay& r, float4 h0, float h1x, float h1y, uint32_t w0, uint32_t w1, const BoxT& own,
+                                                  float& near0, float& far0, float& near1, float& far1, BoxT& c0, BoxT& c1)
+{
+    const BoxT inner = boxPlaneT(r, h0, h1x, h1y);
+    swapUnderBit<25>(w0, own.loX, inner.loX, c0.loX, c1.loX);
+    swapUnderBit<24>(w0, own.loY, inner.loY, c0.loY, c1.loY);
+    swapUnderBit<25>(w1, own.hiX, inner.hiX, c0.hiX, c1.hiX);
+    swapUnderBit<24>(w1, own.hiY, inner.hiY, c0.hiY, c1.hiY);
+    swapUnderBit<30>(w1, own.loZ, inner.loZ, c0.loZ, c1.loZ);
+    swapUnderBit<29>(w1, own.hiZ, inner.hiZ, c0.hiZ, c1.hiZ);
+    near0 = isaMax3(isaMin(c0.loX, c0.hiX), isaMin(c0.loY, c0.hiY), isaMin(c0.loZ, c0.hiZ));
+    far0 = isaMin3(isaMax(c0.loX, c0.hiX), isaMax(c0.loY, c0.hiY), isaMax(c0.loZ, c0.hiZ));
+    near1 = isaMax3(isaMin(c1.loX, c1.hiX), isaMin(c1.loY, c1.hiY), isaMin(c1.loZ, c1.hiZ));
+    far1 = isaMin3(isaMax(c1.loX, c1.hiX), isaMax(c1.loY, c1.hiY), isaMax(c1.loZ, c1.hiZ));
+}
+// Class B lanes only: is any of the twelve slab products of the step NaN (0 * inf)?
+__device__ __forceinline__ bool boxPairHasNaN(const BoxT& c0, const BoxT& c1)
+{
+    return __builtin_isunordered(c0.loX, c0.hiX) || __builtin_isunordered(c0.loY, c0.hiY) || __builtin_isunordered(c0.loZ, c0.hiZ) ||
+           __builtin_isunordered(c1.loX, c1.hiX) || __builtin_isunordered(c1.loY, c1.hiY) || __builtin_isunordered(c1.loZ, c1.hiZ);
 }
 
 // Class B lanes only: is any of the twelve slab products of this compact-capable record NaN (0 * inf)?  (The four x-plane values are

@@ -153,15 +153,17 @@ def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tm
     for nearest_first in (1, 0):
         r.set_option("shadow_nearest_first", nearest_first)
         assert np.array_equal(r.occluded_rays(rays, tmax), cpu_vis), nearest_first
-    # the compact-capable records (three vector loads per descending step, the node's own x planes carried from the parent's
-    # step): the same planes and products, so the same bits on the same hostile rays
-    r.set_option("query_compact", 1)
+    # the compact-capable records (1: three vector loads per descending step, the node's own x planes carried from the parent's
+    # step; 2: 32-byte records, two loads, all six planes carried): the same planes and products, so the same bits on the same
+    # hostile rays
     r.set_option("shadow_nearest_first", 1)
-    gpu_c = r.intersect_rays(rays, tmax)
-    assert np.array_equal(gpu_c["hit"], cpu["hit"]) and np.array_equal(gpu_c["tri"], cpu["tri"])
-    for k in ("t", "uv", "p"):
-        assert np.array_equal(bits(gpu_c[k]), bits(cpu[k])), ("compact", k)
-    assert np.array_equal(r.occluded_rays(rays, tmax), cpu_vis), "compact"
+    for mode in (1, 2):
+        r.set_option("query_compact", mode)
+        gpu_c = r.intersect_rays(rays, tmax)
+        assert np.array_equal(gpu_c["hit"], cpu["hit"]) and np.array_equal(gpu_c["tri"], cpu["tri"]), mode
+        for k in ("t", "uv", "p"):
+            assert np.array_equal(bits(gpu_c[k]), bits(cpu[k])), ("compact", mode, k)
+        assert np.array_equal(r.occluded_rays(rays, tmax), cpu_vis), ("compact", mode)
     r.set_option("query_compact", 0)
     r.set_option("query_variant", 0)
     assert np.array_equal(r.intersect_rays(rays, tmax)["tri"], cpu["tri"])
@@ -625,9 +627,12 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
     sky = rf.make_sky(turbidity=float(rng.uniform(1, 10)), albedo=tuple(rng.uniform(0, 1, 3)), sun_zenith_degrees=float(rng.uniform(0, 89)),
                       sun_azimuth_degrees=float(rng.uniform(0, 360)))
     r, params = _renderer(pt, W, H, spp, bounces, cam=cam, sky=sky, exposure=0.5)
-    if seed % 2:                                                # every launch on the compact-capable records (default: the deeper bounces only)
+    if seed % 3 == 1:                                           # every launch on the compact-capable records (default: the deeper bounces only)
         r.set_option("compact_from_bounce", 1)
         r.set_option("compact_shadow_from_bounce", 1)
+    if seed % 3 == 2:                                           # ... on the 32-byte records
+        r.set_option("hot_from_bounce", 1)
+        r.set_option("hot_shadow_from_bounce", 1)
     r.render(spp)
     img, acc = r.read_accumulation()
     assert acc == spp
@@ -874,7 +879,8 @@ def test_slot_order_batching_and_accumulation_variants_give_identical_images(duc
     variants = [dict(), dict(slot_group_shift=-1), dict(slot_group_shift=2), dict(slot_group_shift=6, sample_sort=0), dict(sample_sort=0),
                 dict(accumulate_runs=0), dict(shade_blocks=7), dict(slot_group_shift=10, accumulate_runs=0),
                 dict(compact_from_bounce=0, compact_shadow_from_bounce=0), dict(compact_from_bounce=1, compact_shadow_from_bounce=1),
-                dict(compact_from_bounce=1, compact_shadow_from_bounce=1, uniform_fetch=0)]
+                dict(compact_from_bounce=1, compact_shadow_from_bounce=1, uniform_fetch=0),
+                dict(hot_from_bounce=1, hot_shadow_from_bounce=1), dict(hot_from_bounce=2, hot_shadow_from_bounce=1, uniform_fetch=0)]
     for opts in variants:
         for max_paths in (0, 5 * 15 * 1024):                  # default batch (all 23 samples at once) / 5 samples per batch -> 5, 5, 5, 4, 4
             r, _ = _renderer(duck_pt, W, H, spp, bounces, cam=cam, max_paths_in_flight=max_paths)
