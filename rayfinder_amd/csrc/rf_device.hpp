@@ -259,6 +259,22 @@ __device__ __forceinline__ float wPow(float x, float y)
 {
     return static_cast<float>(pow(static_cast<double>(x), static_cast<double>(y)));
 }
+// pow(x, 1.5f) of the sky model's Mie term (three per path that leaves the scene; the f64 pow is by far the most expensive call
+// of kSky).  x * sqrt(x) in f64 is within 1.5 ulp(f64) of x^1.5 (correctly rounded sqrt, one rounded product), so it rounds to the
+// same f32 as the correctly rounded result unless it lies within a few ulp(f64) of an f32 rounding boundary -- the bit pattern
+// 1000..0 in the 29 mantissa bits an f32 drops; only then (8 of 2^29 arguments) is the real pow() evaluated.  Same value for
+// every input: negative x gives NaN on both routes, -0 gives +0, inf gives inf; f32-subnormal results take the pow() route.
+__device__ __forceinline__ float wPow15(float x)
+{
+    const double   xd = static_cast<double>(x);
+    const double   y = xd * sqrt(xd);
+    const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(y));
+    const uint32_t low = static_cast<uint32_t>(bits) & 0x1FFFFFFFu;           // the mantissa bits below an f32's last place
+    const uint32_t dist = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low; // distance from the rounding boundary, in ulp(f64)
+    const bool     normalF32 = y >= 1.1754943508222875e-38 || y == 0.0;       // (below that the f32 grid is coarser than assumed here)
+    if (__builtin_expect(dist > 8u && normalF32, 1)) return static_cast<float>(y);
+    return static_cast<float>(pow(xd, 1.5));
+}
 __device__ __forceinline__ float wFract(float x) { return x - floorf(x); }
 
 constexpr float kPi = 3.1415927f;       // wgsl:68
@@ -293,7 +309,7 @@ __device__ __forceinline__ float skyRadiance(const SkyStateGpu& sky, float cosTh
     const float  cosGamma2 = cosGamma * cosGamma;
     const float  expM = wExp(p[4] * gamma);
     const float  mieLhs = 1.0f + cosGamma2;
-    const float  mieRhs = wPow(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma, 1.5f);
+    const float  mieRhs = wPow15(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma);
     const float  mie = mieLhs / mieRhs;
     const float  zenith = rf_sqrt(cosTheta);
     const float  lhs = 1.0f + p[0] * wExp(p[1] / (cosTheta + 0.01f));

@@ -203,6 +203,33 @@ def test_duck_render_vs_oracle_full_frame(duck_pt, duck_oracle):
     assert int((got != want).sum()) == 0 and ((bgra >> 24) == 255).all()
 
 
+@pytest.mark.parametrize("sky_kw", [dict(), dict(turbidity=9.5, albedo=(0.9, 0.1, 0.4), sun_zenith_degrees=82.0, sun_azimuth_degrees=200.0),
+                                    dict(turbidity=1.2, albedo=(0.0, 0.0, 0.0), sun_zenith_degrees=3.0, sun_azimuth_degrees=10.0)])
+def test_sky_dome_bit_exact_over_many_directions(sky_kw):
+    """Nearly every path of this frame ends in the sky at bounce 1 or 2: half a million evaluations of the sky model per
+    channel (acos / cos / exp in f64 rounded once; the Mie term's pow(x, 1.5) through its x * sqrt(x) route with the
+    rounding-boundary guard, rf_device.hpp wPow15) against the oracle's libm calls, bit for bit."""
+    tris = np.array([[[-0.3, -1.0, -0.3], [0.3, -1.0, -0.3], [0.0, -1.0, 0.3]], [[-3.0, -1.5, -3.0], [3.0, -1.5, -3.0], [0.0, -1.5, 3.0]]], np.float32)
+    n = len(tris)
+    normals = np.tile(np.array([0.0, 1.0, 0.0], np.float32), (n, 3, 1))
+    uvs = np.zeros((n, 3, 2), np.float32)
+    pt = rf.PtFormat.from_triangles(tris.reshape(n, 9), normals.reshape(n, 9), uvs.reshape(n, 6), np.zeros(n, np.uint32), [(np.array([0xFFC0C0C0], np.uint32), 1, 1)])
+    W, H, spp, bounces = 512, 384, 3, 2
+    cam = rf.create_camera((0.0, 0.2, 0.0), (0.3, 1.0, 0.2), 0.0, 1.0, float(orc.degrees_to_radians(110.0)), W / H)
+    sky = rf.make_sky(**sky_kw)
+    r, _ = _renderer(pt, W, H, spp, bounces, cam=cam, sky=sky, exposure=0.5)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    s = r.stats()
+    r.close()
+    assert acc == spp
+    sc, _ = oracle_scene_from_pt(pt)
+    ref, st = orc.render(sc, orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.5, rf.aligned_sky_state(sky)), 0, spp)
+    assert s["closest_rays"] == st.closestRays
+    assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
+    assert float((ref[..., :3] > 0).mean()) > 0.9                      # the frame really is sky
+
+
 def test_lens_sampling_and_other_sky_parameters(duck_pt, duck_oracle):
     """Thin-lens camera (aperture > 0), low sun, turbid sky, odd frame size (edge tiles)."""
     W, H, spp, bounces = 150, 90, 8, 3
