@@ -684,30 +684,40 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         if (!exhausted && idleCount >= refillMin)
         {
             if (COUNT) ++wRefill;
-            while (chunkPos == chunkEnd && !exhausted)
-            {
-                const uint32_t shardBegin = shard * shardLen, shardEnd = min(shardBegin + shardLen, count);
-                uint32_t       base = 0;
-                if (lane == 0) base = shardBegin < count ? atomicAdd(cursor + shard * kLineWords, chunk) : shardLen;
-                base = shardBegin + __shfl(base, 0);
-                if (base >= shardEnd)
-                {
-                    shard = (shard + 1) % kShards;
-                    if (++shardsTried == kShards) exhausted = true;
-                }
-                else
-                {
-                    chunkPos = base;
-                    chunkEnd = min(base + chunk, shardEnd);
-                }
-            }
-            const uint32_t take = min(idleCount, chunkEnd - chunkPos);
+            // queue positions for the idle lanes, in lane order; a refill that reaches the end of the wave's chunk goes on in the
+            // next one (it used to stop there and leave the remaining lanes idle until the next refill: one refill in three)
             const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
-            if (node == kNodeIdle && rankInIdle < take)
+            uint32_t       assigned = 0, myPos = 0xFFFFFFFFu;
+            while (assigned < idleCount)
+            {
+                while (chunkPos == chunkEnd && !exhausted)
+                {
+                    const uint32_t shardBegin = shard * shardLen, shardEnd = min(shardBegin + shardLen, count);
+                    uint32_t       base = 0;
+                    if (lane == 0) base = shardBegin < count ? atomicAdd(cursor + shard * kLineWords, chunk) : shardLen;
+                    base = shardBegin + __shfl(base, 0);
+                    if (base >= shardEnd)
+                    {
+                        shard = (shard + 1) % kShards;
+                        if (++shardsTried == kShards) exhausted = true;
+                    }
+                    else
+                    {
+                        chunkPos = base;
+                        chunkEnd = min(base + chunk, shardEnd);
+                    }
+                }
+                if (chunkPos == chunkEnd) break; // the queue is dry
+                const uint32_t take = min(idleCount - assigned, chunkEnd - chunkPos);
+                if (rankInIdle - assigned < take) myPos = chunkPos + (rankInIdle - assigned); // (unsigned: false for ranks below `assigned`)
+                chunkPos += take;
+                assigned += take;
+            }
+            if (node == kNodeIdle && myPos != 0xFFFFFFFFu)
             {
                 // the ray's state sits at its QUEUE position: the lanes of a refill read consecutive elements (coalesced), and
                 // the closest-hit launch does not read the queue itself at all
-                resultIndex = chunkPos + rankInIdle;
+                resultIndex = myPos;
                 if (ANY_HIT) slot = loadQ(queue + resultIndex); // the radiance sum and the blue-noise pair are the path's: by slot
                 const Vec3 o = load3s(ps.rayO + resultIndex);
                 Vec3       dir;
@@ -741,7 +751,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
                 node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
             }
-            chunkPos += take;
         }
         if (__ballot(node != kNodeIdle) == 0ull)
         {
