@@ -1866,6 +1866,8 @@ struct Renderer::Impl
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
+    uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
+    uint32_t optRefillMinDeep = 22, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at 22 idle lanes
     // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
@@ -2155,6 +2157,12 @@ struct Renderer::Impl
             uint32_t* cursorClosest = cursors + kLine * kShards * 2 * (bounce - 1);
             uint32_t* cursorShadow = cursorClosest + kLine * kShards;
             const uint32_t uniformFlag = ((optUniformFetch < 0 ? bounce <= 2 : optUniformFetch > 0) ? kFlagUniformFetch : 0u) | (optUniformFetch >= 2 ? kFlagUniformTri : 0u);
+            // incoherent closest-hit launches refill earlier: their rays differ most in length, so lanes go idle sooner (per-bounce
+            // sweep, profiles/r02_final/bounce_sweep*.log: bounces 3-8 -4 % at 20-24 idle lanes, bounces 1-2 and the shadow launches +6 .. +10 %)
+            // ... and the coherent launches of the first bounces, whose rays are short and alike, claim larger chunks (one cursor atomic = one
+            // wave-wide stall: bounce 1 -4 % at 256 entries, the deep bounces +0.5 %)
+            const uint32_t chunkNow = bounce <= optChunkEarlyBounces ? optChunkEarly : optChunk;
+            const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? optRefillMinDeep : optRefillMin;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
                 {
@@ -2165,18 +2173,18 @@ struct Renderer::Impl
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
+                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (bounce <= optPacketBounces)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
                 else if (wide.hot != nullptr && optHotFromBounce != 0u && bounce >= optHotFromBounce)
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
+                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (wide.compact != nullptr && optCompactFromBounce != 0u && bounce >= optCompactFromBounce)
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
+                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else
                     hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, uniformFlag);
+                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
             launchTimed(2, [&] {
@@ -2201,23 +2209,23 @@ struct Renderer::Impl
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce)
                         hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce)
                         hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else
                         hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                 else
                     hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, optChunk, kTMax, shadowFlags);
+                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
             }, bounce - 1);
             std::swap(qIn, qOut);
             std::swap(ps.rayD, ps.rayDOut);
@@ -2655,9 +2663,13 @@ void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
 void Renderer::setOption(const std::string& name, int64_t value)
 {
     if (name == "traversal_variant") mImpl->traversalVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
-    else if (name == "refill_min") mImpl->optRefillMin = static_cast<uint32_t>(value);
+    else if (name == "refill_min") mImpl->optRefillMin = mImpl->optRefillMinDeep = static_cast<uint32_t>(value); // (both: a sweep of one value covers every launch)
+    else if (name == "refill_min_deep") mImpl->optRefillMinDeep = static_cast<uint32_t>(value);
+    else if (name == "refill_deep_from_bounce") mImpl->optRefillDeepFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 1));
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
-    else if (name == "chunk") mImpl->optChunk = static_cast<uint32_t>(value);
+    else if (name == "chunk") mImpl->optChunk = mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20)); // (both, as refill_min)
+    else if (name == "chunk_early") mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20));
+    else if (name == "chunk_early_bounces") mImpl->optChunkEarlyBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "sample_sort") mImpl->optSampleSort = value != 0;
     else if (name == "accumulate_runs") mImpl->optAccumulateRuns = value != 0;
     else if (name == "uniform_fetch") mImpl->optUniformFetch = static_cast<int>(value);
