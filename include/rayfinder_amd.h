@@ -167,7 +167,20 @@ RF_API int rf_renderer_read_deferred(rf_renderer* r, float* sample_rgb, float* a
 /* Statistics (replaces the ImGui perf read-out, src/pt/main.cpp:251-257). */
 RF_API int rf_renderer_set_counting(rf_renderer* r, int enabled);
 RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
-/* Tuning knobs for A/B measurements ("traversal_variant": 0 | 1); never change results. */
+/* Tuning knobs for A/B measurements; none of them changes a result (every combination is covered by the -m gpu parity tests).
+ *   traversal_variant 0 | 2            one-ray-per-thread kernels over the 32-byte nodes | persistent kernels over the 64-byte records (default)
+ *   compact_from_bounce, compact_shadow_from_bounce   first bounce whose closest-hit / shadow launch reads the compact-capable records
+ *                                      (three loads per descending step; defaults 3 / 2; 0 = never)
+ *   hot_from_bounce, hot_shadow_from_bounce           the same for the 32-byte records (two loads per step; default 0 = never)
+ *   refill_min, refill_min_deep, refill_deep_from_bounce   idle lanes at which a wave refills (40; 22 for closest-hit launches from bounce 3 on)
+ *   leaf_vote                          descending lanes below which a wave processes its parked leaves (20)
+ *   chunk, chunk_early, chunk_early_bounces   queue entries per cursor claim (128; 256 at bounces 1-2)
+ *   uniform_fetch 0 | 1 | 2 | -1       scalar-cache fetch of wave-uniform records (1), and leaf triangles (2, default); -1: bounces 1-2 only
+ *   shadow_nearest_first 0 | 1         any-hit child order: the reference's split-axis order | nearer slab entry first (default)
+ *   packet_bounces n                   bounces 1..n traced by lockstep wave packets (default 0)
+ *   slot_group_shift, sample_sort, accumulate_runs, shade_blocks, reserve_samples, persistent_blocks, extra_lds
+ *                                      path-slot order, accumulation kernel, grid sizes, occupancy experiments
+ *   query_variant 0 | 2, query_compact 0 | 1 | 2      kernels / record layout behind rf_renderer_intersect_rays / _occluded_rays (tests) */
 RF_API int rf_renderer_set_option(rf_renderer* r, const char* name, int64_t value);
 RF_API int rf_renderer_reset_stats(rf_renderer* r);
 RF_API int rf_renderer_get_stats(rf_renderer* r, rf_stats* out);

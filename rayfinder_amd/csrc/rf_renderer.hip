@@ -854,7 +854,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                         typedef uint32_t u8v __attribute__((ext_vector_type(8)));
                         typedef uint32_t u4v __attribute__((ext_vector_type(4)));
                         typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-                        const float4* un = wide.compact + 4 * static_cast<size_t>(uNode);
+                        // a wave-uniform step costs no vector-L1 access whatever the layout: it reads the PLAIN record through the scalar
+                        // cache and pays nothing for the selects -- the children's x-plane t-values are four of its twelve products
+                        const float4* un = wide.nodes + 4 * static_cast<size_t>(uNode);
                         u8v           a;
                         u4v           b;
                         u2v           c;
@@ -862,14 +864,16 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                                      : "=&s"(a), "=&s"(b), "=&s"(c)
                                      : "s"(un)
                                      : "memory");
-                        if (!haveOuter)
-                        {
-                            tOuterLo = (__uint_as_float(c.x) - pr.oXY.x) * pr.iXY.x;
-                            tOuterHi = (__uint_as_float(c.y) - pr.oXY.x) * pr.iXY.x;
-                        }
-                        compactStep(make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
-                                    make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)),
-                                    make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)));
+                        const float4 a0 = make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
+                                     a1 = make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)),
+                                     a2 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+                        float        far0, far1;
+                        slabPairBoundsX(pr, a0, a1, a2, t0, far0, t1, far1, c0LoX, c0HiX, c1LoX, c1HiX);
+                        asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1)); // (min/max chains stay with their products: see slabStep)
+                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2);
+                        ok0 = t0 <= far0 && far0 > 0.0f;
+                        ok1 = t1 <= far1 && far1 > 0.0f;
+                        words = make_uint2(c.x, c.y);
                     }
                     else
                     {

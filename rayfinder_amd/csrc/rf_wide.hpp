@@ -282,6 +282,23 @@ __device__ __forceinline__ void slabPairBounds(const PackedRay& r, float4 q0, fl
     near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(e.x, f.x), __builtin_fminf(e.y, f.y)), __builtin_fminf(d.x, d.y));
     far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(e.x, f.x), __builtin_fmaxf(e.y, f.y)), __builtin_fmaxf(d.x, d.y));
 }
+// slabPairBounds that also hands out the four x-plane products (what a lane carries into the child it enters, compact-capable records)
+__device__ __forceinline__ void slabPairBoundsX(const PackedRay& r, float4 q0, float4 q1, float4 q2, float& near0, float& far0, float& near1, float& far1,
+                                                float& c0LoX, float& c0HiX, float& c1LoX, float& c1HiX)
+{
+    const v2f oZZ = v2f{r.oZ, r.oZ}, iZZ = v2f{r.iZ, r.iZ};
+    const v2f a = (v2f{q0.x, q0.y} - r.oXY) * r.iXY;
+    const v2f b = (v2f{q0.z, q0.w} - r.oXY) * r.iXY;
+    const v2f c = (v2f{q1.x, q1.y} - oZZ) * iZZ;
+    const v2f d = (v2f{q1.z, q1.w} - oZZ) * iZZ;
+    const v2f e = (v2f{q2.x, q2.y} - r.oXY) * r.iXY;
+    const v2f f = (v2f{q2.z, q2.w} - r.oXY) * r.iXY;
+    c0LoX = a.x, c0HiX = b.x, c1LoX = e.x, c1HiX = f.x;
+    near0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)), __builtin_fminf(c.x, c.y));
+    far0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(c.x, c.y));
+    near1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(e.x, f.x), __builtin_fminf(e.y, f.y)), __builtin_fminf(d.x, d.y));
+    far1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(e.x, f.x), __builtin_fmaxf(e.y, f.y)), __builtin_fmaxf(d.x, d.y));
+}
 __device__ __forceinline__ void slabPair(const PackedRay& r, float4 q0, float4 q1, float4 q2, bool& ok0, float& tmin0, bool& ok1, float& tmin1)
 {
     float far0, far1;
