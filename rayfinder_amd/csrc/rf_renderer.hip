@@ -609,7 +609,7 @@ template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, int COMPACT = 0>
 __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
                                                                                         const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
                                                                                         DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
-                                                                                        uint32_t chunk, float tMax, uint32_t flags)
+                                                                                        uint32_t chunkMax, float tMax, uint32_t flags)
 {
     constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
     constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
@@ -623,6 +623,11 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 
     // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
     // shard of its block and moves on round-robin when a shard is dry.
+    // entries per cursor claim: `chunkMax`, halved until every wave gets at least 8 claims (a short queue -- a small frame, a deep
+    // bounce of one rank's shard -- ends in a tail of half-empty waves otherwise), but not below 64: a claim is a wave-wide stall
+    // of a few microseconds, so fewer, larger claims win as long as the tail stays balanced
+    uint32_t chunk = chunkMax;
+    while (chunk > 64u && static_cast<unsigned long long>(chunk) * 8ull * gridDim.x * (kBlock / 64) > count) chunk >>= 1;
     const uint32_t shardLen = ((count + kShards - 1) / kShards + chunk - 1) / chunk * chunk;
     uint32_t       shard = blockIdx.x % kShards, shardsTried = 0;
     uint32_t       chunkPos = 0, chunkEnd = 0;

@@ -8,8 +8,12 @@ import rayfinder_amd as rf
 from rayfinder_amd import scenes
 spp = int(sys.argv[1]); variants = sys.argv[2:] or ["-"]
 defaults = dict(kv.split("=") for kv in os.environ.get("RF_OPT_DEFAULTS", "").split(",") if kv)
-pt, info = scenes.atrium()
-W, H, b = 1920, 1080, 8
+if os.environ.get("RF_SCENE", "atrium") == "duck":      # BASELINE.json config 2
+    pt = rf.PtFormat.from_gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "Duck.glb"))
+    W, H, b = 800, 600, 4
+else:
+    pt, info = scenes.atrium()
+    W, H, b = 1920, 1080, 8
 cam = rf.fly_camera(W, H)
 r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, b, rf.make_sky(), 0.25), pt.scene())
 r.render(spp); r.synchronize()
