@@ -266,6 +266,12 @@ RF_API int rf_build_bvh_gpu(const float* positions36, uint64_t num_triangles, vo
                             uint64_t* triangle_indices_out, int32_t* depth_out /* NULL ok */, int32_t device_ordinal,
                             float* build_ms_out /* NULL ok */);
 
+/* Host-only self-check of the render path's BVH record layouts for a flattened tree of 48-B nodes: the 64-byte
+ * "children in the parent" records, the compact-capable records and the 32-byte records are built as rf_renderer_create builds
+ * them and every variant must decode to the same child planes and child words.  *flags_out: bit 0 = boxes regular (wide
+ * layout usable), bit 1 = compact-capable records usable, bit 2 = 32-byte records usable.  No reference counterpart. */
+RF_API int rf_check_wide_layouts(const void* nodes48, uint64_t num_nodes, uint32_t* flags_out);
+
 /* Camera createCamera(origin, lookAt, aperture, focusDistance, vfov, aspectRatio)
  * (src/common/camera.cpp:7-42); vfov in radians (Angle::asRadians). */
 RF_API int rf_create_camera(const float origin[3], const float look_at[3], float aperture, float focus_distance,

@@ -101,6 +101,15 @@ def build_bvh(positions36):
     return nodes[:cnt.value].copy(), idx, depth.value
 
 
+def check_wide_layouts(nodes):
+    """rf_check_wide_layouts: the render path's record layouts of a flattened tree decode to the same child planes (host only).
+    -> {"regular": bool, "compact": bool, "hot": bool}; raises on a mismatch."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    flags = C.c_uint32(0)
+    check(lib.rf_check_wide_layouts(_ptr(nodes), nodes.shape[0], C.byref(flags)))
+    return {"regular": bool(flags.value & 1), "compact": bool(flags.value & 2), "hot": bool(flags.value & 4)}
+
+
 def texture_from_memory(data):
     """Texture::fromMemory (texture.cpp:12-54): PNG / JPEG bytes -> (BGRA u32 texels [h*w], width, height)."""
     buf = np.frombuffer(bytes(data), np.uint8)

@@ -511,6 +511,18 @@ int rf_build_bvh(const float* positions36, uint64_t num_triangles, void* nodes_o
     });
 }
 
+int rf_check_wide_layouts(const void* nodes48, uint64_t num_nodes, uint32_t* flags_out)
+{
+    return guarded([&] {
+        require(nodes48 && flags_out, "null argument");
+        std::span<const rf::BvhNode> nodes{static_cast<const rf::BvhNode*>(nodes48), static_cast<size_t>(num_nodes)};
+        // (the same structural check rf_renderer_create runs first: the layout builder follows child links blindly)
+        rf::validateScene(nodes, static_cast<size_t>(-1), {}, 0);
+        *flags_out = rf::checkWideLayouts(nodes);
+        return RF_OK;
+    });
+}
+
 int rf_build_bvh_gpu(const float* positions36, uint64_t num_triangles, void* nodes_out, uint64_t* num_nodes_out, uint64_t* triangle_indices_out,
                      int32_t* depth_out, int32_t device_ordinal, float* build_ms_out)
 {

@@ -2863,4 +2863,49 @@ void Renderer::occludedRays(const float* rays6, uint64_t numRays, float tMax, fl
     RF_HIP(hipStreamSynchronize(m.stream));
     RF_HIP(hipMemcpy(visibilityOut, vis.ptr, numRays * 4, hipMemcpyDeviceToHost));
 }
+uint32_t checkWideLayouts(std::span<const BvhNode> nodes)
+{
+    if (nodes.empty()) throw std::runtime_error("checkWideLayouts: no nodes");
+    const WideBuild wb = buildWide(nodes.data(), nodes.size());
+    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u);
+    const size_t    records = wb.nodes.size() / 4;
+    const auto      fail = [](size_t r, const char* what) { throw std::runtime_error("wide layout mismatch at record " + std::to_string(r) + ": " + what); };
+    for (size_t r = 0; r < records; ++r)
+    {
+        const float4* w = &wb.nodes[4 * r];
+        // child planes of the plain record, in the order {lo.x lo.y hi.x hi.y lo.z hi.z}
+        const float    c0[6] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y}, c1[6] = {w[2].x, w[2].y, w[2].z, w[2].w, w[1].z, w[1].w};
+        const uint32_t word0 = floatBits(w[3].x), word1 = floatBits(w[3].y);
+        float          own[6]; // the node's own box: the union of its children's (lo: min, hi: max)
+        for (int k = 0; k < 6; ++k) own[k] = (k == 0 || k == 1 || k == 4) ? std::min(c0[k], c1[k]) : std::max(c0[k], c1[k]);
+        if (!wb.compact.empty())
+        {
+            const float4*  c = &wb.compact[4 * r];
+            const uint32_t cw0 = floatBits(c[2].x), cw1 = floatBits(c[2].z);
+            const bool     selLo = (cw1 >> kWideAxisShift) & 1u, selHi = (cw1 >> (kWideAxisShift + 1)) & 1u;
+            const float    d0[6] = {selLo ? c[3].x : c[0].x, c[0].y, selHi ? c[3].y : c[0].z, c[0].w, c[1].x, c[1].y};
+            const float    d1[6] = {selLo ? c[0].x : c[3].x, c[2].y, selHi ? c[0].z : c[3].y, c[2].w, c[1].z, c[1].w};
+            for (int k = 0; k < 6; ++k)
+                if (!(d0[k] == c0[k]) || !(d1[k] == c1[k])) fail(r, "compact-capable record decodes to other planes");
+            if (cw0 != word0 || (cw1 & ~(3u << kWideAxisShift)) != word1) fail(r, "compact-capable record holds other child words");
+            if (!(c[3].x == own[0]) || !(c[3].y == own[2])) fail(r, "compact-capable record: outer x planes are not the node's");
+        }
+        if (!wb.hot.empty())
+        {
+            const float4*  h = &wb.hot[2 * r];
+            const float4*  o = &wb.own[2 * r];
+            const uint32_t hw0 = floatBits(h[1].z), hw1 = floatBits(h[1].w);
+            const float    inner[6] = {h[0].x, h[0].y, h[0].z, h[0].w, h[1].x, h[1].y}, outer[6] = {o[0].x, o[0].y, o[0].z, o[0].w, o[1].x, o[1].y};
+            const bool     sel[6] = {((hw0 >> 25) & 1u) != 0u, ((hw0 >> 24) & 1u) != 0u, ((hw1 >> 25) & 1u) != 0u,
+                                     ((hw1 >> 24) & 1u) != 0u, ((hw1 >> 30) & 1u) != 0u, ((hw1 >> 29) & 1u) != 0u};
+            for (int k = 0; k < 6; ++k)
+            {
+                if (!((sel[k] ? outer[k] : inner[k]) == c0[k]) || !((sel[k] ? inner[k] : outer[k]) == c1[k])) fail(r, "32-byte record decodes to other planes");
+                if (!(outer[k] == own[k])) fail(r, "own-box array does not hold the union of the children");
+            }
+            if ((hw0 & ~(3u << 24)) != word0 || (hw1 & ~((3u << 24) | (3u << kWideAxisShift))) != word1) fail(r, "32-byte record holds other child words");
+        }
+    }
+    return flags;
+}
 } // namespace rf

@@ -166,4 +166,10 @@ private:
     struct Impl;
     std::unique_ptr<Impl> mImpl;
 };
+
+// Host-only check of the render path's BVH layouts (rf_wide.hpp) for a flattened tree: builds the 64-byte records and their
+// compact-capable / 32-byte variants and verifies that every variant decodes to the same child planes and child words as the
+// plain record, and that the carried "own" planes are the union of the children's.  Returns bit 0: boxes regular (wide layout
+// usable), bit 1: compact-capable records usable, bit 2: 32-byte records usable; throws std::runtime_error on a mismatch.
+uint32_t checkWideLayouts(std::span<const BvhNode> nodes);
 } // namespace rf

@@ -514,3 +514,37 @@ def test_multi_material_gltf_with_external_uris_and_jpegs_bakes_like_the_indepen
     assert f"{len(nodes)} nodes" in out and "8 textures" in out
     data = open(path.replace(".gltf", ".pt"), "rb").read()
     assert data == pt.serialize() and rf.PtFormat.deserialize(data).serialize() == data
+
+
+# ------------------------------------------------------------------ round 2: the render path's record layouts (host side)
+@pytest.mark.parametrize("seed,n", [(1, 1), (2, 2), (3, 7), (4, 300), (5, 5000)])
+def test_wide_record_layouts_decode_to_the_same_planes(seed, n):
+    """The compact-capable records (the node's own x planes carried by the lane) and the 32-byte records (all six planes carried)
+    are re-encodings of the 64-byte "children in the parent" records: rf_check_wide_layouts rebuilds all three as
+    rf_renderer_create does and checks, on the host, that every variant decodes to the same twelve child planes and the same
+    child words, and that what a lane carries (the node's own planes) is the union of the children's."""
+    rng = np.random.default_rng(seed)
+    tris = (rng.uniform(-3, 3, (n, 1, 3)) + rng.normal(0, 0.3, (n, 3, 3))).astype(np.float32)
+    tris[: n // 4] = np.round(tris[: n // 4] * 2) / 2               # lattice coordinates: shared planes, zero-thickness boxes
+    nodes, _, _ = rf.build_bvh(tris.reshape(n, 9))
+    got = rf.check_wide_layouts(nodes)
+    assert got == {"regular": True, "compact": n > 1, "hot": n > 1}   # (a single-leaf tree has no interior record)
+
+
+def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(duck_oracle):
+    assert rf.check_wide_layouts(duck_oracle.nodes) == {"regular": True, "compact": True, "hot": True}
+    # a hand-made tree whose root box is LARGER than the union of its children: the lane cannot carry the node's planes,
+    # so the renderer falls back to the plain records
+    nodes = np.zeros(3, dtype=rf.NODE_DTYPE)
+    nodes[0]["min"] = (-5, -5, -5); nodes[0]["max"] = (5, 5, 5); nodes[0]["secondChildOffset"] = 2; nodes[0]["splitAxis"] = 0
+    for i, x in ((1, -1.0), (2, 1.0)):
+        nodes[i]["min"] = (x - 0.5, -0.5, -0.5); nodes[i]["max"] = (x + 0.5, 0.5, 0.5)
+        nodes[i]["trianglesOffset"] = i - 1; nodes[i]["triangleCount"] = 1; nodes[i]["splitAxis"] = 0xFFFFFFFF
+    assert rf.check_wide_layouts(nodes) == {"regular": True, "compact": False, "hot": False}
+    # non-finite boxes: the packed slab test is not used at all
+    nodes[1]["max"] = (np.inf, 0.5, 0.5)
+    assert rf.check_wide_layouts(nodes)["regular"] is False
+    # a broken child link is refused before any layout is built
+    nodes[0]["secondChildOffset"] = 7
+    with pytest.raises(Exception):
+        rf.check_wide_layouts(nodes)
