@@ -175,6 +175,8 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *   refill_min, refill_min_deep, refill_deep_from_bounce   idle lanes at which a wave refills (40; 22 for closest-hit launches from bounce 3 on)
  *   leaf_vote                          descending lanes below which a wave processes its parked leaves (20)
  *   chunk, chunk_early, chunk_early_bounces   queue entries per cursor claim (128; 256 at bounces 1-2)
+ *   shade_sort_from_bounce             first bounce whose shading stage appends each 1024-entry tile's surviving paths in the order of
+ *                                      the triangles they hit (default 3; 0 = never: input order)
  *   uniform_fetch 0 | 1 | 2 | -1       scalar-cache fetch of wave-uniform records (1), and leaf triangles (2, default); -1: bounces 1-2 only
  *   shadow_nearest_first 0 | 1         any-hit child order: the reference's split-axis order | nearer slab entry first (default)
  *   packet_bounces n                   bounces 1..n traced by lockstep wave packets (default 0)

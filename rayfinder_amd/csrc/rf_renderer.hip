@@ -386,11 +386,21 @@ __device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, const SunBasis
 constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
 
 
+// SORTED (option shade_sort_from_bounce): a tile's surviving paths are appended to the next queue in the order of the triangles they hit
+// (counting sort over kSortBins ranges of triangle ids in LDS; triangles are in BVH leaf order, so that is an order by region of the
+// scene) instead of input order: the 64 rays a wave of the next launches picks up then start close to each other.  The tile still
+// occupies ONE contiguous run of the queue, so queue order stays slot order at the scale of 1024 entries (what is indexed by slot --
+// the blue-noise triple, the radiance sum -- is touched by the same workgroups as before).  `sortScale`: bin of triangle t =
+// (t * sortScale) >> 32.
+constexpr uint32_t kSortBins = 256;
+template<bool SORTED>
 __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                   const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
-                                                  uint32_t* missCount, uint32_t bounceFlags)
+                                                  uint32_t* missCount, uint32_t bounceFlags, uint32_t sortScale)
 {
+    static_assert(kSortBins == kBlock, "one bin per thread");
     __shared__ uint32_t sScratch[8];
+    __shared__ uint32_t sHist[SORTED ? kSortBins : 1], sStart[SORTED ? kSortBins : 1], sPerm[SORTED ? kItems * kBlock : 1];
     __shared__ float    sLut[256];
     const uint32_t      count = *queueCount;
     // grid-stride over tiles of kItems * kBlock queue entries: the grid is capped (kShadeMaxBlocks), so late bounces, whose
@@ -407,21 +417,80 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
     // knows its position in the next queue before it is shaded: what only the next two launches read (the NEE term) is
     // written there, densely, instead of at the path's slot (whose neighbours are mostly dead by bounce 3).
     bool       isHit[kItems], isMiss[kItems];
-    uint32_t   slots[kItems], missEntries[kItems], outPos[kItems];
+    uint32_t   slots[kItems], missEntries[kItems], outPos[kItems], hitTri[kItems];
 #pragma unroll
     for (int k = 0; k < kItems; ++k)
     {
         const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
         isHit[k] = isMiss[k] = false;
         slots[k] = missEntries[k] = 0;
+        hitTri[k] = kMiss;
         if (i >= count) continue;
         slots[k] = queue[i];
         missEntries[k] = i; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there
         const uint32_t tri = __float_as_uint(ps.hit[i].x); // hit records sit at QUEUE positions (dense)
+        hitTri[k] = tri;
         isMiss[k] = tri == kMiss; // the path ends in the sky: evaluated densely by this bounce's kSky launch
         isHit[k] = tri != kMiss;
     }
-    blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch, &outPos);
+    if constexpr (SORTED)
+    {
+        // counting sort of the tile's hits by triangle range: rank inside the bin from an LDS counter, bin starts from a block scan
+        uint32_t bin[kItems], rank[kItems];
+        sHist[threadIdx.x] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+        {
+            bin[k] = rank[k] = 0u;
+            if (!isHit[k]) continue;
+            bin[k] = min(__umulhi(hitTri[k], sortScale), kSortBins - 1u);
+            rank[k] = atomicAdd(&sHist[bin[k]], 1u);
+        }
+        __syncthreads();
+        {
+            const uint32_t n = sHist[threadIdx.x], lane = __lane_id(), wave = threadIdx.x >> 6;
+            uint32_t       incl = n;
+            for (int off = 1; off < 64; off <<= 1)
+            {
+                const uint32_t up = __shfl_up(incl, off);
+                if (static_cast<int>(lane) >= off) incl += up;
+            }
+            if (lane == 63) sScratch[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += sScratch[w];
+            sStart[threadIdx.x] = before + incl - n;
+            if (threadIdx.x == 0)
+            {
+                const uint32_t total = sScratch[0] + sScratch[1] + sScratch[2] + sScratch[3];
+                sScratch[5] = total;
+                sScratch[4] = total ? atomicAdd(hitCount, total) : 0u; // the tile's run in the next queue
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+            if (isHit[k]) sPerm[sStart[bin[k]] + rank[k]] = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
+        __syncthreads();
+        // the thread's work from here on: entries k * 256 + tid of the SORTED order
+        const uint32_t tileHits = sScratch[5], base = sScratch[4];
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+        {
+            const uint32_t p = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
+            isHit[k] = p < tileHits;
+            outPos[k] = base + p;
+            if (!isHit[k]) continue;
+            const uint32_t local = sPerm[p];
+            hitTri[k] = local; // (reused: which entry of the tile)
+            slots[k] = queue[(tile * kItems + local / kBlock) * kBlock + (local % kBlock)];
+            hitQueue[outPos[k]] = slots[k];
+        }
+        __syncthreads(); // LDS is reused by the miss append and the next tile
+    }
+    else
+        blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch, &outPos);
     blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
 
     // Pass 2: shade the hits
@@ -429,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
     for (int k = 0; k < kItems; ++k)
     {
         if (!isHit[k]) continue;
-        const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
+        const uint32_t i = SORTED ? (tile * kItems + hitTri[k] / kBlock) * kBlock + (hitTri[k] % kBlock) : (tile * kItems + k) * kBlock + threadIdx.x;
         const uint32_t slot = slots[k];
         const float4   h = ps.hit[i];
         const uint32_t tri = __float_as_uint(h.x);
@@ -1875,6 +1944,7 @@ struct Renderer::Impl
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
+    uint32_t optShadeSortFromBounce = 3, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
     uint32_t optRefillMinDeep = 22, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at 22 idle lanes
     // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
@@ -2197,8 +2267,12 @@ struct Renderer::Impl
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
             launchTimed(2, [&] {
-                hipLaunchKernelGGL(kShade, dim3(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount,
-                                   (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u));
+                const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u);
+                const dim3     shadeGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
+                if (optShadeSortFromBounce != 0u && bounce >= optShadeSortFromBounce)
+                    hipLaunchKernelGGL(kShade<true>, shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, sortScale);
+                else
+                    hipLaunchKernelGGL(kShade<false>, shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, 0u);
                 // the paths that left the scene at this bounce, while its direction / throughput arrays and queue are intact
                 hipLaunchKernelGGL(kSky, dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, qIn, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
             });
@@ -2271,6 +2345,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         throw std::runtime_error("position and vertex attribute counts differ");
     // child links, leaf ranges and texture indices are followed blindly on the device: check them once here
     validateScene(sceneView.bvhNodes, sceneView.positionAttributes.size(), sceneView.vertexAttributes, sceneView.baseColorTextures.size());
+    m.sortScale = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(kSortBins) << 32) / std::max<uint64_t>(sceneView.positionAttributes.size(), 1), 0xFFFFFFFFull));
 
     // 48-B reference nodes -> 32-B device nodes
     {
@@ -2678,6 +2753,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "chunk") mImpl->optChunk = mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20)); // (both, as refill_min)
     else if (name == "chunk_early") mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20));
+    else if (name == "shade_sort_from_bounce") mImpl->optShadeSortFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "chunk_early_bounces") mImpl->optChunkEarlyBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "sample_sort") mImpl->optSampleSort = value != 0;
     else if (name == "accumulate_runs") mImpl->optAccumulateRuns = value != 0;

@@ -657,6 +657,8 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
     if seed % 3 == 1:                                           # every launch on the compact-capable records (default: the deeper bounces only)
         r.set_option("compact_from_bounce", 1)
         r.set_option("compact_shadow_from_bounce", 1)
+    if seed % 4 == 3:                                           # kShade appends each tile's hits in triangle order
+        r.set_option("shade_sort_from_bounce", seed % 3)
     if seed % 3 == 2:                                           # ... on the 32-byte records
         r.set_option("hot_from_bounce", 1)
         r.set_option("hot_shadow_from_bounce", 1)
@@ -907,7 +909,8 @@ def test_slot_order_batching_and_accumulation_variants_give_identical_images(duc
                 dict(accumulate_runs=0), dict(shade_blocks=7), dict(slot_group_shift=10, accumulate_runs=0),
                 dict(compact_from_bounce=0, compact_shadow_from_bounce=0), dict(compact_from_bounce=1, compact_shadow_from_bounce=1),
                 dict(compact_from_bounce=1, compact_shadow_from_bounce=1, uniform_fetch=0),
-                dict(hot_from_bounce=1, hot_shadow_from_bounce=1), dict(hot_from_bounce=2, hot_shadow_from_bounce=1, uniform_fetch=0)]
+                dict(hot_from_bounce=1, hot_shadow_from_bounce=1), dict(hot_from_bounce=2, hot_shadow_from_bounce=1, uniform_fetch=0),
+                dict(shade_sort_from_bounce=1), dict(shade_sort_from_bounce=2, shade_blocks=5), dict(shade_sort_from_bounce=0)]
     for opts in variants:
         for max_paths in (0, 5 * 15 * 1024):                  # default batch (all 23 samples at once) / 5 samples per batch -> 5, 5, 5, 4, 4
             r, _ = _renderer(duck_pt, W, H, spp, bounces, cam=cam, max_paths_in_flight=max_paths)

@@ -11,7 +11,7 @@ spp = int(sys.argv[1]); variants = sys.argv[2:] or ["-"]
 defaults = dict(kv.split("=") for kv in os.environ.get("RF_OPT_DEFAULTS", "").split(",") if kv)
 rounds = 3
 pt, info = scenes.atrium()
-W, H, b = 1920, 1080, 8
+W, H, b = int(os.environ.get("RF_W", 1920)), int(os.environ.get("RF_H", 1080)), int(os.environ.get("RF_B", 8))
 cam = rf.fly_camera(W, H)
 r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, b, rf.make_sky(), 0.25), pt.scene())
 r.render(spp); r.synchronize()
