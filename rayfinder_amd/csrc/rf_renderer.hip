@@ -77,9 +77,10 @@ struct PathStreams
     float4* rad;     // [slot] radiance.rgb
     float4* hit;     // [queue position] {triangle bits, u, v, t}
     P3*     pending; // [queue position] (throughput * solar radiance) * reflectance, waiting for visibility
-    float4* noise;   // [slot] {u.x, cos(2 pi u.y), sin(2 pi u.y), -}: the path's one blue-noise pair
+    P3*     noise;   // [queue position] {u.x, cos(2 pi u.y), sin(2 pi u.y)}: the path's one blue-noise pair, this bounce's copy
     P3*     rayDOut; // [position in the NEXT queue] written by kShade
     P3*     thrOut;  // [position in the NEXT queue]
+    P3*     noiseOut; // [position in the NEXT queue]: kShade copies the triple along; the shadow launch of the bounce reads it here
 };
 
 // 12-byte load of the xyz part of a float4 stream element (global_load_dwordx3): the L1 -> VGPR return path
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
         // first-bounce flag), which saves 32 of the 80 bytes a path costs here and the reads back
         store3(ps.rayO + pos[k], origin);
         store3(ps.rayD + pos[k], dir);
-        ps.noise[slots[k]] = make_float4(nx, cosPhi, sinPhi, 0.0f);
+        store3(ps.noise + pos[k], vec3(nx, cosPhi, sinPhi));
     }
     // primary rays are counted on the host (samples x valid pixels of the shard): one atomic per wave on a single counter
     // was what bound this kernel -- 261 k waves at ~90 same-address atomics/us = 2.9 of its 3.2 ms (MI355X_MICROARCH.md "dequeue")
@@ -499,7 +500,6 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
     {
         if (!isHit[k]) continue;
         const uint32_t i = SORTED ? (tile * kItems + hitTri[k] / kBlock) * kBlock + (hitTri[k] % kBlock) : (tile * kItems + k) * kBlock + threadIdx.x;
-        const uint32_t slot = slots[k];
         const float4   h = ps.hit[i];
         const uint32_t tri = __float_as_uint(h.x);
         // everything this stage needs of the triangle sits in ONE 128-byte record (positions + packed attributes): one L2 line
@@ -514,8 +514,9 @@ __global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu 
             store3(ps.rayO + outPos[k], hp); // (this bounce's origins have been consumed by the closest-hit launch)
         }
         const Vec3  throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i); // wgsl:184
-        const Vec3  nz = load3(ps.noise + slot);
+        const Vec3  nz = load3(ps.noise + i);
         const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
+        store3(ps.noiseOut + outPos[k], nz); // travels with the path: dense for this bounce's shadow launch and for the next kShade
         // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
         const float4* va = rec + 3;
         const float4  a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkySta
     {
         const uint32_t slot = queue[i];
         const Vec3     o = load3(ps.rayO + i);
-        const float4   nz = ps.noise[slot];
+        const Vec3     nz = load3(ps.noiseOut + i);
         const Vec3     l = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
         ClosestHit     h;
         const bool     occluded = traverse<true, COUNT>(scene, o, l, kTMax, &sStack[threadIdx.x], h, tc);
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
                 {
-                    const Vec3 nz = load3s(ps.noise + slot);
+                    const Vec3 nz = load3s(ps.noiseOut + resultIndex);
                     dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
                 else dir = load3s(ps.rayD + resultIndex);
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTracePacket(DeviceScene scene, Wid
             o = load3s(ps.rayO + idx);
             if (ANY_HIT && !shadowDirFromStream)
             {
-                const Vec3 nz = load3s(ps.noise + slot);
+                const Vec3 nz = load3s(ps.noiseOut + idx);
                 dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
             }
             else dir = load3s(ps.rayD + idx);
@@ -1925,8 +1926,8 @@ struct Renderer::Impl
     uint64_t                validPixels = 0;     // pixels of this rank's tiles that lie inside the frame
     unsigned long long      primaryRaysHost = 0; // samples traced x validPixels since the last resetStats()
     uint64_t                maxPaths = 0;
-    DeviceBuffer<P3>        sRayO, sRayD, sRayD2, sThr, sThr2, sPending; // queue-position arrays, packed xyz; rayD / thr: double-buffered (PathStreams)
-    DeviceBuffer<float4>    sRad, sHit, sNoise;
+    DeviceBuffer<P3>        sRayO, sRayD, sRayD2, sThr, sThr2, sPending, sNoise, sNoise2; // queue-position arrays, packed xyz; rayD / thr / noise: double-buffered (PathStreams)
+    DeviceBuffer<float4>    sRad, sHit;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
     DeviceBuffer<unsigned long long> bounceTotals; // 2 x kMaxBounceStats
@@ -2011,6 +2012,7 @@ struct Renderer::Impl
         sHit.alloc(paths);
         sPending.alloc(paths);
         sNoise.alloc(paths);
+        sNoise2.alloc(paths);
         queueA.alloc(paths);
         queueB.alloc(paths);
         missQueue.alloc(paths);
@@ -2126,7 +2128,7 @@ struct Renderer::Impl
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
         const uint32_t count = static_cast<uint32_t>(n);
         RF_HIP(hipMemcpyAsync(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice, stream));
-        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr};
+        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
         const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
         if (shadow)
         {
@@ -2204,7 +2206,7 @@ struct Renderer::Impl
         const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
         primaryRaysHost += static_cast<unsigned long long>(numSamples) * validPixels;
         // bounce b reads direction / throughput from buffer (b - 1) & 1 and kShade writes the next bounce's into the other one
-        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr};
+        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
         const uint32_t numBounces = fp.numBounces;
 
         BatchTiming bt{getEvent(), getEvent(), numSamples};
@@ -2313,6 +2315,7 @@ struct Renderer::Impl
             std::swap(qIn, qOut);
             std::swap(ps.rayD, ps.rayDOut);
             std::swap(ps.thr, ps.thrOut);
+            std::swap(ps.noise, ps.noiseOut);
         }
         hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr);
         launchTimed(4, [&] {
