@@ -51,14 +51,38 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def load_scene(path):
+REAL_ASSET_CANDIDATES = ("assets/Sponza.pt", "assets/Sponza.glb", "assets/Sponza.gltf", "assets/Sponza/Sponza.gltf", "assets/Sponza/glTF/Sponza.gltf")
+
+
+def find_real_asset():
+    """The asset the metric names, if a user put it next to the repo (the reference keeps it at assets/Sponza.glb and its
+    pt-format-tool writes Sponza.pt beside it: src/pt-format-tool/main.cpp:31-34).  It is absent from the reference mount
+    (.MISSING_LARGE_BLOBS), so normally nothing is found and the synthetic stand-in is used."""
+    for rel in REAL_ASSET_CANDIDATES:
+        for base in (ROOT, os.getcwd()):
+            p = os.path.join(base, rel)
+            if os.path.isfile(p):
+                return p
+    return ""
+
+
+def load_scene(path, scale=1, gpu_builder_device=None):
+    """-> (PtFormat, info).  path: a .pt / .glb / .gltf (data = "real"); else the synthetic atrium, tessellated `scale` x finer."""
     import rayfinder_amd as rf
     from rayfinder_amd import scenes
     if path:
+        if not path.endswith(".pt") and gpu_builder_device is not None:
+            rf.set_bake_bvh_builder(gpu_builder_device)
         pt = rf.PtFormat.load(path) if path.endswith(".pt") else rf.PtFormat.from_gltf(path)
+        rf.set_bake_bvh_builder(None)
         v = pt.view()
-        return pt, dict(name=os.path.basename(path), triangles=int(v.num_triangle_position_attributes), textures=int(v.num_textures))
-    return scenes.atrium()
+        return pt, dict(name=os.path.basename(path), triangles=int(v.num_triangle_position_attributes), textures=int(v.num_textures), real=True)
+    if scale > 1 and gpu_builder_device is not None:
+        rf.set_bake_bvh_builder(gpu_builder_device)      # same node bytes as the host builder (bvh_build below), 40x faster at this size
+    try:
+        return scenes.atrium(scale)
+    finally:
+        rf.set_bake_bvh_builder(None)
 
 
 def oracle_scene(pt):
@@ -149,6 +173,148 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     return base, parity
 
 
+def find_pmc_profile(workload):
+    """The committed per-ray counter figures for this workload: profiles/pmc_per_ray*.json whose "workload" matches
+    (scene name, frame, bounces -- per ray, so they hold for any --steps / N)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_per_ray*.json"))):
+        try:
+            pmc = json.load(open(path))
+        except Exception as e:  # a malformed file must not take the bench line down
+            log(f"[bench] {path} ignored: {e}")
+            continue
+        if pmc.get("workload") == workload:
+            return pmc, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def build_roofline(s, cs, per_bounce, workload):
+    """The roofline block of the JSON line.
+
+    Top level (the driver's contract): the closest-hit traversal kernel against HBM in MEASURED fabric-side bytes --
+    traffic = bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate --pmc passes of this command, calibrated),
+    achieved = traffic / the launch duration measured live with HIP events, frac = achieved / 8 TB/s.
+    `bound` names the ceiling that actually BINDS this kernel on this workload (the one with the largest fraction among
+    HBM bytes, L1->L2 requests, vector-L1 tag accesses and VALU issue), `ceilings` holds all four, `per_bounce` the same per
+    launch of the timed batch (live times x profiled per-ray counters), `other_kernels` the shadow traversal and kShade."""
+    launches = max(s["launches_closest"], 1)
+    avg_ms = s["ms_closest"] / launches
+    rays_per_launch = s["closest_rays"] / launches
+    roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=None, kernel="kTraceWide<closest>",
+                    avg_launch_ms=round(avg_ms, 4), launches=launches, rays_per_launch=int(rays_per_launch),
+                    compulsory_hbm_bytes_per_ray=40)   # 12 B origin + 12 B direction in (packed, at the ray's queue position: no queue read), 16 B hit record out
+    pmc, pmc_file = find_pmc_profile(workload)
+    if pmc is not None and avg_ms > 0:
+        sec = avg_ms * 1e-3
+        per_ray = float(pmc["hbm_side_bytes_per_ray"])
+        traffic = per_ray * rays_per_launch
+        achieved = traffic / sec / 1e9
+        roofline.update(traffic=int(traffic), achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBPS, 4),
+                        traffic_source=dict(file=pmc_file, profile=pmc.get("profile"), hbm_side_bytes_per_ray=per_ray,
+                                            fetch_size_bytes_per_ray=pmc.get("fetch_size_bytes_per_ray"), fetch_calibration=pmc.get("fetch_calibration"),
+                                            write_size_bytes_per_ray=pmc.get("write_size_bytes_per_ray"), write_calibration=pmc.get("write_calibration"),
+                                            l2_hit_rate=pmc.get("l2_hit_rate")))
+        ceil = pmc.get("ceilings", {})
+        ceilings = {"hbm": dict(bytes_per_ray=per_ray, GBps=round(achieved, 1), peak_GBps=HBM_PEAK_GBPS, frac=round(achieved / HBM_PEAK_GBPS, 4),
+                                random_64B_gather_GBps_measured=ceil.get("hbm_random_64B_gather_GBps"),
+                                frac_of_random_gather_rate=round(achieved / ceil["hbm_random_64B_gather_GBps"], 4) if ceil.get("hbm_random_64B_gather_GBps") else None)}
+        if pmc.get("l1_to_l2_read_requests_per_ray") and ceil.get("l1_to_l2_requests_G_per_s"):
+            g = float(pmc["l1_to_l2_read_requests_per_ray"]) * rays_per_launch / sec / 1e9
+            ceilings["l1_l2_requests"] = dict(requests_per_ray=pmc["l1_to_l2_read_requests_per_ray"], G_per_s=round(g, 1), peak_G_per_s=ceil["l1_to_l2_requests_G_per_s"],
+                                              frac=round(g / ceil["l1_to_l2_requests_G_per_s"], 4), counter="TCP_TCC_READ_REQ_sum",
+                                              peak_source="calibration.json: random 64-byte record gather, cache-resident table (tools/microbench/fetch_calib.hip)")
+        if pmc.get("l1_accesses_per_ray"):
+            gacc = float(pmc["l1_accesses_per_ray"]) * rays_per_launch / sec / 1e9
+            ceilings["l1_tag"] = dict(accesses_per_ray=pmc["l1_accesses_per_ray"], G_per_s=round(gacc, 1), peak_G_per_s=L1_PEAK_GACC, frac=round(gacc / L1_PEAK_GACC, 4),
+                                      counter="TCP_TOTAL_CACHE_ACCESSES_sum", peak_source="256 CUs x 1 tag access/clk x 2.4 GHz")
+            roofline["l1"] = dict(accesses_per_ray=pmc["l1_accesses_per_ray"], G_accesses_per_s=round(gacc, 1), peak_G_accesses_per_s=L1_PEAK_GACC,
+                                  frac=round(gacc / L1_PEAK_GACC, 4), counter="TCP_TOTAL_CACHE_ACCESSES_sum")
+        # per launch of the timed batch: live HIP-event time of THIS run x the profiled per-ray counters of that bounce
+        rows = []
+        prof = {(r["kernel"], r["bounce"]): r for r in pmc.get("per_bounce", [])}
+        for b in per_bounce:
+            for kind in ("closest", "shadow"):
+                r = prof.get((kind, b["bounce"]))
+                ms, rays = b[f"ms_{kind}"], b[f"{kind}_rays"]
+                if r is None or ms <= 0 or not rays:
+                    continue
+                row = dict(kernel=kind, bounce=b["bounce"], rays=rays, ms=ms, G_rays_per_s=round(rays / ms * 1e-6, 2))
+                fr = {}
+                if "l1_to_l2_requests_per_ray" in r and ceil.get("l1_to_l2_requests_G_per_s"):
+                    g = r["l1_to_l2_requests_per_ray"] * rays / ms * 1e-6
+                    row.update(l1_to_l2_requests_per_ray=r["l1_to_l2_requests_per_ray"], G_requests_per_s=round(g, 1))
+                    fr["l1_l2_requests"] = g / ceil["l1_to_l2_requests_G_per_s"]
+                if "l1_accesses_per_ray" in r:
+                    g = r["l1_accesses_per_ray"] * rays / ms * 1e-6
+                    row.update(l1_accesses_per_ray=r["l1_accesses_per_ray"])
+                    fr["l1_tag"] = g / L1_PEAK_GACC
+                if "valu_issue_share" in r:
+                    # instructions per ray are a property of the rays; the share scales with this run's time against the profiled run's
+                    share = r["valu_issue_share"] * (r["ms"] / ms) * (rays / max(r["rays"], 1)) if r.get("ms") else r["valu_issue_share"]
+                    fr["valu"] = share
+                if "l2_hit_rate" in r:
+                    row["l2_hit_rate"] = r["l2_hit_rate"]
+                row["fractions"] = {k: round(v, 3) for k, v in fr.items()}
+                if fr:
+                    row["binds"] = max(fr, key=fr.get)
+                rows.append(row)
+        if rows:
+            roofline["per_bounce"] = rows
+            # VALU issue share of the whole kernel: ray-weighted over its launches
+            cl = [r for r in rows if r["kernel"] == "closest" and "valu" in r["fractions"]]
+            if cl:
+                share = sum(r["fractions"]["valu"] * r["ms"] for r in cl) / sum(r["ms"] for r in cl)
+                ceilings["valu"] = dict(issue_share=round(share, 4), peak=1.0, frac=round(share, 4), counter="SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x cycles)")
+        roofline["ceilings"] = ceilings
+        binding = max(ceilings, key=lambda k: ceilings[k]["frac"])
+        roofline["bound"] = binding
+        deep = [r for r in rows if r["kernel"] == "closest" and r["bounce"] >= 3 and "binds" in r]
+        first = [r for r in rows if r["kernel"] == "closest" and r["bounce"] == 1 and "binds" in r]
+        roofline["bound_by_phase"] = dict(bounce_1=first[0]["binds"] if first else None,
+                                          bounces_3_up=max(set(r["binds"] for r in deep), key=[r["binds"] for r in deep].count) if deep else None)
+        roofline["bound_note"] = ("`bound` = the ceiling with the largest fraction for this kernel on this workload; achieved / peak / frac / traffic above stay the "
+                                  "HBM-side figures (measured fabric bytes) whatever binds")
+        # one-line entries for the two other kernels the frame spends its time in
+        other = {}
+        if pmc.get("shadow") and s["ms_shadow"] > 0:
+            k = pmc["shadow"]
+            t = k["hbm_side_bytes_per_unit"] * s["shadow_rays"]
+            gb = t / (s["ms_shadow"] * 1e-3) / 1e9
+            other["kTraceWide<shadow>"] = dict(bound="l1_l2_requests" if roofline["bound"] != "hbm" else "hbm", unit="GB/s", peak=HBM_PEAK_GBPS, achieved=round(gb, 1), frac=round(gb / HBM_PEAK_GBPS, 4),
+                                               traffic=int(t / max(s["launches_shadow"], 1)), hbm_side_bytes_per_ray=k["hbm_side_bytes_per_unit"],
+                                               l1_to_l2_requests_per_ray=k.get("l1_to_l2_read_requests_per_unit"),
+                                               G_requests_per_s=round(k.get("l1_to_l2_read_requests_per_unit", 0.0) * s["shadow_rays"] / (s["ms_shadow"] * 1e-3) / 1e9, 1),
+                                               avg_launch_ms=round(s["ms_shadow"] / max(s["launches_shadow"], 1), 4))
+        if pmc.get("shade") and s["ms_shade"] > 0:
+            k = pmc["shade"]
+            lo, hi = (k[f"hbm_side_bytes_per_unit_{x}"] * s["closest_rays"] / (s["ms_shade"] * 1e-3) / 1e9 for x in ("low", "high"))
+            other["kShade+kSky"] = dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBPS, achieved=round(lo, 1), frac=round(lo / HBM_PEAK_GBPS, 4),
+                                        achieved_if_all_reads_were_streams=round(hi, 1), frac_if_all_reads_were_streams=round(hi / HBM_PEAK_GBPS, 4),
+                                        traffic=int(k["hbm_side_bytes_per_unit_low"] * s["closest_rays"] / max(s["launches_shade"], 1)),
+                                        hbm_side_bytes_per_queue_entry=[k["hbm_side_bytes_per_unit_low"], k["hbm_side_bytes_per_unit_high"]],
+                                        avg_launch_ms=round(s["ms_shade"] / max(s["launches_shade"], 1), 4),
+                                        note="the timed span holds kShade and the bounce's kSky launch; FETCH_SIZE counts random gathers at ~1.07 x and coalesced streams at 0.5 x "
+                                             "their bytes, kShade mixes both: `achieved` applies the gather factor to every read (lower bracket), the other figure the stream factor")
+        if other:
+            roofline["other_kernels"] = other
+    if cs is not None:
+        bytes_closest = 28 * cs["closest_rays"] + 16 * cs["closest_rays"] + 48 * (cs["closest_node_visits"] + cs["closest_triangle_tests"])
+        bytes_shadow = 28 * cs["shadow_rays"] + 4 * cs["shadow_rays"] + 48 * (cs["shadow_node_visits"] + cs["shadow_triangle_tests"])
+        roofline["algorithmic"] = dict(
+            bytes_per_launch=int(bytes_closest / launches), bytes_per_ray=round(bytes_closest / max(cs["closest_rays"], 1), 1),
+            GBps=round(bytes_closest / launches / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+            node_visits_per_ray=round(cs["closest_node_visits"] / max(cs["closest_rays"], 1), 2),
+            triangle_tests_per_ray=round(cs["closest_triangle_tests"] / max(cs["closest_rays"], 1), 2),
+            shadow_kernel_GBps=round(bytes_shadow / max(s["ms_shadow"], 1e-9) / 1e6, 1),
+            # what the kernel itself requests: 56 of the 64 B of a wide record (one record = both children of a reference node,
+            # leaves are never fetched) + 36 B per triangle + ray I/O (24 B in, 16 B out)
+            requested_GBps=round((40 * cs["closest_rays"] + 56 * cs["closest_record_fetches"] + 36 * cs["closest_triangle_tests"]) / max(s["ms_closest"], 1e-9) / 1e6, 1),
+            record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2),
+            note="SURVEY.md 8(d): 28 B ray in + 16 B hit out + 48 B per reference node visit + 48 B per triangle test; a cache rate when the BVH is "
+                 "resident in L2 / Infinity Cache, reported for reference and not divided by the HBM peak")
+    return roofline
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,7 +323,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--scene", default=os.environ.get("RF_SCENE", ""), help="Sponza.pt / Sponza.glb; default: synthetic atrium")
+    ap.add_argument("--scene", default=os.environ.get("RF_SCENE", ""), help="Sponza.pt / Sponza.glb; default: assets/Sponza.{pt,glb} if present, else the synthetic atrium")
+    ap.add_argument("--scene-scale", type=int, default=1, help="synthetic atrium tessellated N x finer in both grid directions (N^2 x the triangles): "
+                    "8 = 17 M triangles, 2.2 GB of BVH records + triangles -- the out-of-cache regime for the HBM roofline")
+    ap.add_argument("--spp-per-step", type=int, default=SPP_PER_STEP, help="samples per pixel in one step (default 16; profiling runs of the big scene use fewer)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (and with them the parity crop)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-counting", action="store_true", help="skip the untimed counting pass (profiling runs): the algorithmic figures are null then")
@@ -176,6 +345,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     comm = None
+    rccl_ranks = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -184,7 +354,12 @@ def main():
         # exchange goes through the product's own RCCL communicator, whose id travels over the rendezvous store
         ids = [rf.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        comm = rf.TileComm(ids[0], rank, world, local_rank)
+        try:
+            comm = rf.TileComm(ids[0], rank, world, local_rank)      # times out with an error (RF_COMM_TIMEOUT_S) instead of hanging
+            rccl_ranks = comm.info()["rccl_ranks"]                   # what RCCL itself says the communicator spans (ncclCommCount)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] rank {rank}: RCCL communicator creation FAILED: {e}")
+            comm = None
     exchange = "none" if world == 1 else "C++ RCCL exchange (rf_renderer_gather_frame: grouped ncclSend/ncclRecv + device un-tile)"
 
     def all_ranks_ok(ok):
@@ -193,9 +368,11 @@ def main():
         return bool(t.item() > 0.5)
 
     W, H, K, WU, B = args.width, args.height, max(args.steps, 1), max(args.warmup, 0), args.bounces
-    spp, warm_spp = SPP_PER_STEP * K, SPP_PER_STEP * WU
+    SPS = max(args.spp_per_step, 1)
+    spp, warm_spp = SPS * K, SPS * WU
     t0 = time.time()
-    pt, info = load_scene(args.scene)
+    scene_path = args.scene or find_real_asset()
+    pt, info = load_scene(scene_path, max(args.scene_scale, 1), local_rank)
     log(f"[bench] rank {rank}: scene {info} ready in {time.time() - t0:.1f} s")
 
     cam = rf.fly_camera(W, H)
@@ -203,22 +380,25 @@ def main():
     r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25), pt.scene(), device_ordinal=local_rank)
     r.set_tile_shard(rank, world)
     accum = None
-    if comm is not None:
+    if world > 1:
         # self-test of the exchange before anything is timed.  The C++ path has only ever run at world size 1 on the
         # builder's single-GPU boxes; should it throw here on any rank, every rank falls back -- loudly, and named in the JSON
         # line -- to the round-1 plumbing (torch.distributed.gather of the compact buffers + host un-tile) so that a
         # scaling curve still exists.  (A hang cannot be caught; the layout arithmetic both sides share is tested under gloo.)
-        err = ""
+        err = "" if comm is not None else "no communicator"
         try:
-            r.gather_frame(comm, 0)
-            r.synchronize()
+            if comm is not None:
+                r.gather_frame(comm, 0)      # the first exchange is watched: an error after RF_COMM_TIMEOUT_S instead of a hang
+                r.synchronize()
         except Exception as e:  # noqa: BLE001
             err = str(e)
         if not all_ranks_ok(err == ""):
             log(f"[bench] rank {rank}: C++ RCCL exchange FAILED ({err or 'on another rank'}); falling back to torch.distributed.gather")
             exchange = f"FALLBACK torch.distributed.gather + host un-tile (the C++ RCCL exchange failed: {err or 'on another rank'})"
-            comm.close()
+            if comm is not None:
+                comm.close()
             comm = None
+            rccl_ranks = 0
             from rayfinder_amd.sharding import shard_layout
             _, max_tiles = shard_layout(W, H, rank, world)
             accum = torch.zeros((max_tiles * 1024, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -309,50 +489,8 @@ def main():
         r.set_counting(False)
         assert cs["closest_rays"] == s["closest_rays"] and cs["shadow_rays"] == s["shadow_rays"], "counting pass traced different rays"
 
-    # ---- roofline of the dominant kernel (closest-hit traversal)
-    launches = max(s["launches_closest"], 1)
-    avg_ms = s["ms_closest"] / launches
-    rays_per_launch = s["closest_rays"] / launches
-    roofline = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBPS, unit="GB/s", frac=None, traffic=None, kernel="kTraceWide<closest>",
-                    avg_launch_ms=round(avg_ms, 4), launches=launches, rays_per_launch=int(rays_per_launch),
-                    compulsory_hbm_bytes_per_ray=40)   # 12 B origin + 12 B direction in (packed, at the ray's queue position: no queue read), 16 B hit record out
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_per_ray.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-            # fabric-side bytes per ray of this kernel from the committed rocprofv3 PMC passes of this command on this
-            # workload (same scene, frame, bounces; the figure is per ray, so it does not depend on --steps or on N)
-            if pmc.get("workload") == f"{info['name']} {W}x{H}x{B}":
-                per_ray = float(pmc["hbm_side_bytes_per_ray"])
-                traffic = per_ray * rays_per_launch
-                achieved = traffic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-                roofline.update(traffic=int(traffic), achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBPS, 4),
-                                traffic_source=dict(file="profiles/pmc_per_ray.json", profile=pmc.get("profile"), hbm_side_bytes_per_ray=per_ray,
-                                                    fetch_size_bytes_per_ray=pmc.get("fetch_size_bytes_per_ray"), fetch_calibration=pmc.get("fetch_calibration"),
-                                                    write_size_bytes_per_ray=pmc.get("write_size_bytes_per_ray"), write_calibration=pmc.get("write_calibration"),
-                                                    l2_hit_rate=pmc.get("l2_hit_rate")))
-                if pmc.get("l1_accesses_per_ray"):
-                    gacc = float(pmc["l1_accesses_per_ray"]) * rays_per_launch / (avg_ms * 1e-3) / 1e9
-                    roofline["l1"] = dict(accesses_per_ray=pmc["l1_accesses_per_ray"], G_accesses_per_s=round(gacc, 1), peak_G_accesses_per_s=L1_PEAK_GACC,
-                                          frac=round(gacc / L1_PEAK_GACC, 4), counter="TCP_TOTAL_CACHE_ACCESSES_sum")
-        except Exception as e:  # a malformed file must not take the bench line down
-            log(f"[bench] profiles/pmc_per_ray.json ignored: {e}")
-    if cs is not None:
-        bytes_closest = 28 * cs["closest_rays"] + 16 * cs["closest_rays"] + 48 * (cs["closest_node_visits"] + cs["closest_triangle_tests"])
-        bytes_shadow = 28 * cs["shadow_rays"] + 4 * cs["shadow_rays"] + 48 * (cs["shadow_node_visits"] + cs["shadow_triangle_tests"])
-        roofline["algorithmic"] = dict(
-            bytes_per_launch=int(bytes_closest / launches), bytes_per_ray=round(bytes_closest / max(cs["closest_rays"], 1), 1),
-            GBps=round(bytes_closest / launches / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
-            node_visits_per_ray=round(cs["closest_node_visits"] / max(cs["closest_rays"], 1), 2),
-            triangle_tests_per_ray=round(cs["closest_triangle_tests"] / max(cs["closest_rays"], 1), 2),
-            shadow_kernel_GBps=round(bytes_shadow / max(s["ms_shadow"], 1e-9) / 1e6, 1),
-            # what the kernel itself requests: 56 of the 64 B of a wide record (one record = both children of a reference node,
-            # leaves are never fetched) + 36 B per triangle + ray I/O (24 B in, 16 B out)
-            requested_GBps=round((40 * cs["closest_rays"] + 56 * cs["closest_record_fetches"] + 36 * cs["closest_triangle_tests"]) / max(s["ms_closest"], 1e-9) / 1e6, 1),
-            record_fetches_per_ray=round(cs["closest_record_fetches"] / max(cs["closest_rays"], 1), 2),
-            note="SURVEY.md 8(d): 28 B ray in + 16 B hit out + 48 B per reference node visit + 48 B per triangle test; a cache rate (the BVH is "
-                 "resident in L2 / Infinity Cache), reported for reference and not divided by the HBM peak")
-    roofline["limiter"] = "vector-L1 (TCP) tag-access rate and VALU issue; HBM-side traffic is a small fraction of the peak because the scene is cache resident"
+    # ---- roofline of the dominant kernel (closest-hit traversal) + one-line entries for the shadow traversal and kShade
+    roofline = build_roofline(s, cs, per_bounce, f"{info['name']} {W}x{H}x{B}")
 
     cfg_label = {(1920, 1080, 8): "BASELINE.json config 3" if world == 1 else "BASELINE.json config 4", (3840, 2160, 16): "BASELINE.json config 5",
                  (800, 600, 4): "BASELINE.json config 2"}.get((W, H, B), "custom configuration")
@@ -370,16 +508,19 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{info['name']}{'' if args.scene else ' -- the real Sponza.glb is not in the reference mount'}, {W}x{H}, {B} bounces, "
-                                   f"{SPP_PER_STEP} spp per step x {K} steps = {spp} spp, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
-                       "spp_per_step": SPP_PER_STEP, "spp": spp,
+            "data": "real" if info.get("real") else "synthetic",
+            "config": {"workload": f"{info['name']}{'' if scene_path else ' -- the real Sponza.glb is not in the reference mount'}, {W}x{H}, {B} bounces, "
+                                   f"{SPS} spp per step x {K} steps = {spp} spp, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
+                       "spp_per_step": SPS, "spp": spp,
                        "scene_triangles": info.get("triangles"), "scene_textures": info.get("textures"), "scene_digest": info.get("digest"),
                        "sharding": f"32x32 tiles along a Z-order curve dealt round-robin (rotated per block) over {world} rank(s), one exchange at frame end: {exchange}" if world > 1 else "none"},
             "timed_region_s": round(elapsed, 4),
             "paths_per_s": round(paths_total / elapsed, 1),
             "rays": {"closest": int(closest_total), "shadow": int(shadow_total), "abandoned": int(abandoned_total)},
             "kernel_ms_rank0": {k: round(s[k], 3) for k in ("ms_raygen", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")},
+            "exchange": exchange,
+            "rccl_ranks": rccl_ranks,      # ncclCommCount of the product's communicator (0: no RCCL exchange in this run -- one GPU, or the fallback)
+            "device_memory": r.memory_info(),
             "nan_pixels": nan_pixels,
             "per_bounce_rank0": per_bounce,
             "roofline": roofline,

@@ -100,7 +100,7 @@ typedef struct rf_renderer_descriptor
     rf_render_parameters render_params;
     uint32_t             max_width, max_height; /* maxFramebufferSize; 0 = render_params size */
     int32_t              device_ordinal;
-    uint64_t             max_paths_in_flight;   /* 0 = default (1 Gi paths per batch; path state is allocated on demand: samples x pixels x 124 B) */
+    uint64_t             max_paths_in_flight;   /* 0 = default (1 Gi paths per batch, less when less device memory is free; path state is allocated on demand: samples x pixels x 140 B) */
 } rf_renderer_descriptor;
 
 typedef struct rf_stats
@@ -225,7 +225,22 @@ RF_API int  rf_renderer_tonemap_device_image(rf_renderer* r, const void* image_d
 RF_API int  rf_comm_read_frame(rf_comm* c, rf_renderer* r, float* dst);
 /* Max over ranks of *value (timing plumbing for hosts without another collective layer; also a barrier). */
 RF_API int  rf_comm_all_reduce_max(rf_comm* c, rf_renderer* r /* NULL: default stream */, double* value);
+/* What RCCL reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice); any pointer may be NULL.
+ * A scaling line that says N GPUs carries rccl_ranks == N from here. */
+RF_API int  rf_comm_info(const rf_comm* c, uint32_t* rccl_ranks, uint32_t* rccl_rank, int32_t* device_ordinal);
+/* Device memory held by a handle: path state + queues (140 B per path slot, allocated on demand for the largest batch traced),
+ * the batch depth in use (lowered automatically when the device has less free memory than the default wants: same image,
+ * more batches) and the resident scene.  Any pointer may be NULL. */
+RF_API int  rf_renderer_memory_info(const rf_renderer* r, uint64_t* path_state_bytes, uint64_t* paths_allocated, uint64_t* max_paths_per_batch, uint64_t* scene_bytes);
 /* Host helpers (no GPU needed). */
+/* The point-to-point operations rank `rank` posts (one RCCL group) for a gather to `root`: exactly the list
+ * rf_renderer_gather_frame executes.  Offsets / counts in tiles (1024 float4): a receive lands at offset_tiles of the root's
+ * staging area (rf_gather_layout), a send starts at offset_tiles of the rank's own compact buffer.  ops == NULL: count query. */
+typedef struct rf_gather_op
+{
+    uint32_t is_send, peer, offset_tiles, count_tiles;
+} rf_gather_op;
+RF_API int rf_gather_plan(uint32_t width, uint32_t height, uint32_t world_size, uint32_t rank, uint32_t root, uint32_t flags, rf_gather_op* ops, uint32_t* num_ops);
 /* The staging layout the gather uses: shards rank after rank, each rank's tiles in ascending tile id.
  * rank_first_tile[world_size + 1], tile_slot[tiles] (staging position of a tile, in tiles), tile_owner[tiles]. */
 RF_API int rf_gather_layout(uint32_t width, uint32_t height, uint32_t world_size, uint32_t* rank_first_tile, uint32_t* tile_slot, uint32_t* tile_owner);

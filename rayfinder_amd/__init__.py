@@ -288,6 +288,17 @@ def gather_layout(width, height, world_size):
     return first, slot, owner
 
 
+def gather_plan(width, height, world_size, rank, root=0, loopback=False):
+    """The point-to-point operations `rank` posts for a frame-end gather to `root` (what rf_renderer_gather_frame executes):
+    (n, 4) u32 rows {is_send, peer, offset_tiles, count_tiles}.  Host arithmetic, no GPU."""
+    n = C.c_uint32(0)
+    flags = RF_GATHER_LOOPBACK if loopback else 0
+    check(lib.rf_gather_plan(width, height, world_size, rank, root, flags, None, C.byref(n)))
+    ops = np.zeros((n.value, 4), np.uint32)
+    check(lib.rf_gather_plan(width, height, world_size, rank, root, flags, _ptr(ops), C.byref(n)))
+    return ops
+
+
 def comm_unique_id():
     """ncclGetUniqueId: 128 bytes that rank 0 hands to the other ranks before TileComm(...)."""
     buf = np.zeros(128, np.uint8)
@@ -312,6 +323,12 @@ class TileComm:
 
     def __del__(self):
         self.close()
+
+    def info(self):
+        """What RCCL reports for this communicator: dict(rccl_ranks, rccl_rank, device)."""
+        n, r, d = C.c_uint32(0), C.c_uint32(0), C.c_int32(0)
+        check(lib.rf_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
+        return dict(rccl_ranks=n.value, rccl_rank=r.value, device=d.value)
 
     def read_frame(self, renderer, width, height):
         """Root: the gathered row-major (H, W, 4) float image."""
@@ -406,6 +423,12 @@ class ReferencePathTracer:
         s = _ffi.Stats()
         check(lib.rf_renderer_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    def memory_info(self):
+        """Device memory held by the handle: dict(path_state_bytes, paths_allocated, max_paths_per_batch, scene_bytes)."""
+        v = [C.c_uint64(0) for _ in range(4)]
+        check(lib.rf_renderer_memory_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("path_state_bytes", "paths_allocated", "max_paths_per_batch", "scene_bytes"), (x.value for x in v)))
 
     def bounce_stats(self):
         """Per-bounce queue occupancy (rays traced) and traversal kernel ms since the last reset."""

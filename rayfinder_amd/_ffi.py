@@ -10,6 +10,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RAYFINDER_AMD_LIB: an experiment build of the same library (make EXP=... LIBNAME=...), for A/B measurements
 LIB_PATH = os.environ.get("RAYFINDER_AMD_LIB") or os.path.join(_HERE, "librayfinder_amd.so")
+if os.environ.get("RAYFINDER_AMD_LIB"):
+    import sys
+    print(f"[rayfinder_amd] RAYFINDER_AMD_LIB overrides the packaged library: loading {LIB_PATH}", file=sys.stderr, flush=True)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -130,6 +133,9 @@ SIGNATURES = {
     "rf_renderer_tonemap_device_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "rf_comm_read_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_comm_all_reduce_max": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "rf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "rf_renderer_memory_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4),
+    "rf_gather_plan": (C.c_int, [C.c_uint32] * 6 + [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_gather_layout": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_tiles_for_rank": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_untile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),

@@ -395,6 +395,9 @@ int rf_renderer_gather_frame(rf_renderer* r, rf_comm* c, uint32_t root, uint32_t
         require(root < c->impl->worldSize(), "gather root out of range");
         require(r->impl->shardRank() == c->impl->rank() && r->impl->shardWorldSize() == c->impl->worldSize(),
                 "the renderer's tile shard differs from the communicator's rank / world size (call rf_renderer_set_tile_shard first)");
+        // the exchange is enqueued on the renderer's stream with the communicator's device current: they must be one device
+        require(r->impl->deviceOrdinal() == c->impl->deviceOrdinal(), "the renderer and the communicator are on different devices");
+        r->impl->clearAccumulationIfStale(); // nothing rendered since the last reset: send zeros, not the previous frame
         const void* image = c->impl->gatherFrame(r->impl->accumulationDevicePointer(), r->impl->width(), r->impl->height(), root, r->impl->streamHandle(),
                                                  (flags & RF_GATHER_LOOPBACK) != 0);
         if (image_device_out) *image_device_out = const_cast<void*>(image);
@@ -426,6 +429,53 @@ int rf_comm_all_reduce_max(rf_comm* c, rf_renderer* r, double* value)
     return guarded([&] {
         require(c && value, "null argument");
         *value = c->impl->allReduceMax(*value, r ? r->impl->streamHandle() : nullptr);
+        return RF_OK;
+    });
+}
+
+int rf_comm_info(const rf_comm* c, uint32_t* rccl_ranks, uint32_t* rccl_rank, int32_t* device_ordinal)
+{
+    return guarded([&] {
+        require(c, "null argument");
+        uint32_t count = 0, user = 0;
+        int      dev = 0;
+        c->impl->rcclInfo(count, user, dev);
+        if (rccl_ranks) *rccl_ranks = count;
+        if (rccl_rank) *rccl_rank = user;
+        if (device_ordinal) *device_ordinal = dev;
+        return RF_OK;
+    });
+}
+
+int rf_gather_plan(uint32_t width, uint32_t height, uint32_t world_size, uint32_t rank, uint32_t root, uint32_t flags, rf_gather_op* ops, uint32_t* num_ops)
+{
+    return guarded([&] {
+        require(width > 0 && height > 0 && world_size > 0, "empty frame or world");
+        require(rank < world_size && root < world_size, "rank / root out of range");
+        require(num_ops, "null argument");
+        static_assert(sizeof(rf_gather_op) == sizeof(rf::GatherOp));
+        const rf::GatherLayout          g = rf::gatherLayout(width, height, world_size);
+        const std::vector<rf::GatherOp> plan = rf::gatherPlan(g, world_size, rank, root, (flags & RF_GATHER_LOOPBACK) != 0);
+        if (ops)
+        {
+            require(*num_ops >= plan.size(), "ops array too small");
+            std::memcpy(ops, plan.data(), plan.size() * sizeof(rf::GatherOp));
+        }
+        *num_ops = static_cast<uint32_t>(plan.size());
+        return RF_OK;
+    });
+}
+
+int rf_renderer_memory_info(const rf_renderer* r, uint64_t* path_state_bytes, uint64_t* paths_allocated, uint64_t* max_paths_per_batch, uint64_t* scene_bytes)
+{
+    return guarded([&] {
+        require(r, "null argument");
+        uint64_t a = 0, b = 0, c = 0, d = 0;
+        r->impl->memoryInfo(a, b, c, d);
+        if (path_state_bytes) *path_state_bytes = a;
+        if (paths_allocated) *paths_allocated = b;
+        if (max_paths_per_batch) *max_paths_per_batch = c;
+        if (scene_bytes) *scene_bytes = d;
         return RF_OK;
     });
 }

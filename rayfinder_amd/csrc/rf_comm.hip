@@ -6,9 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <future>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 namespace rf
 {
@@ -97,6 +101,32 @@ GatherLayout gatherLayout(uint32_t width, uint32_t height, uint32_t worldSize)
     return g;
 }
 
+std::vector<GatherOp> gatherPlan(const GatherLayout& g, uint32_t worldSize, uint32_t rank, uint32_t root, bool loopback)
+{
+    std::vector<GatherOp> ops;
+    const auto            tilesOf = [&](uint32_t r) { return g.rankFirstTile[r + 1] - g.rankFirstTile[r]; };
+    // the root posts every receive at once (one group), so all of its xGMI ingress links carry data concurrently
+    if (rank == root)
+        for (uint32_t p = 0; p < worldSize; ++p)
+        {
+            if (tilesOf(p) == 0 || (p == root && !loopback)) continue;
+            ops.push_back(GatherOp{0u, p, g.rankFirstTile[p], tilesOf(p)});
+        }
+    if (tilesOf(rank) > 0 && (rank != root || loopback)) ops.push_back(GatherOp{1u, root, 0u, tilesOf(rank)});
+    return ops;
+}
+
+namespace
+{
+// seconds a rank waits for its peers in ncclCommInitRank and in its FIRST gather before it gives up with an error
+// instead of hanging (a missing rank, a wrong id, a dead xGMI link); RF_COMM_TIMEOUT_S overrides, 0 = wait forever
+double commTimeoutSeconds()
+{
+    if (const char* v = std::getenv("RF_COMM_TIMEOUT_S")) return std::atof(v);
+    return 180.0;
+}
+} // namespace
+
 struct TileComm::Impl
 {
     ncclComm_t comm = nullptr;
@@ -109,15 +139,20 @@ struct TileComm::Impl
     DevBuf<float4>   staging, image;
     DevBuf<double>   scalar;
     uint32_t         imageW = 0, imageH = 0;
+    bool             firstGatherDone = false;
 
-    void ensureLayout(uint32_t w, uint32_t h)
+    // A new frame size: the previous gather's kUntile (on the caller's non-blocking stream) may still be reading the tables and
+    // the staging / image buffers that are about to be replaced -- wait for it, then upload on that same stream.
+    void ensureLayout(uint32_t w, uint32_t h, hipStream_t stream)
     {
         if (w == layoutW && h == layoutH) return;
+        RF_HIP(hipStreamSynchronize(stream));
         layout = gatherLayout(w, h, world);
         dTileSlot.ensure(layout.tileSlot.size());
         dTileOwner.ensure(layout.tileOwner.size());
-        RF_HIP(hipMemcpy(dTileSlot.p, layout.tileSlot.data(), layout.tileSlot.size() * 4, hipMemcpyHostToDevice));
-        RF_HIP(hipMemcpy(dTileOwner.p, layout.tileOwner.data(), layout.tileOwner.size() * 4, hipMemcpyHostToDevice));
+        RF_HIP(hipMemcpyAsync(dTileSlot.p, layout.tileSlot.data(), layout.tileSlot.size() * 4, hipMemcpyHostToDevice, stream));
+        RF_HIP(hipMemcpyAsync(dTileOwner.p, layout.tileOwner.data(), layout.tileOwner.size() * 4, hipMemcpyHostToDevice, stream));
+        RF_HIP(hipStreamSynchronize(stream)); // (`layout` outlives the copy anyway; this keeps pageable-copy semantics out of the picture)
         layoutW = w;
         layoutH = h;
     }
@@ -143,7 +178,26 @@ TileComm::TileComm(const uint8_t idBytes[kCommIdBytes], uint32_t rank, uint32_t 
     RF_HIP(hipSetDevice(deviceOrdinal));
     ncclUniqueId id;
     std::memcpy(&id, idBytes, kCommIdBytes);
-    RF_NCCL(ncclCommInitRank(&mImpl->comm, static_cast<int>(worldSize), id, static_cast<int>(rank)));
+    // ncclCommInitRank blocks until every rank of the world has called it.  It runs on a helper thread so that a rank whose
+    // peers never arrive reports that after RF_COMM_TIMEOUT_S instead of hanging the job (the helper is abandoned then: the
+    // caller is expected to exit).
+    const double timeout = commTimeoutSeconds();
+    auto         task = std::make_shared<std::packaged_task<ncclResult_t()>>([deviceOrdinal, worldSize, rank, id, comm = &mImpl->comm]() -> ncclResult_t {
+        if (hipSetDevice(deviceOrdinal) != hipSuccess) return ncclUnhandledCudaError;
+        return ncclCommInitRank(comm, static_cast<int>(worldSize), id, static_cast<int>(rank));
+    });
+    std::future<ncclResult_t> done = task->get_future();
+    std::thread([task] { (*task)(); }).detach();
+    if (timeout > 0.0 && done.wait_for(std::chrono::duration<double>(timeout)) != std::future_status::ready)
+    {
+        mImpl.release(); // the helper still writes into it: leaked on purpose
+        throw std::runtime_error("RCCL: ncclCommInitRank did not complete within " + std::to_string(static_cast<int>(timeout)) + " s on rank " + std::to_string(rank) + " of " +
+                                 std::to_string(worldSize) + " (a rank is missing, or the ranks do not share one unique id); RF_COMM_TIMEOUT_S changes the limit");
+    }
+    RF_NCCL(done.get());
+    int count = 0;
+    RF_NCCL(ncclCommCount(mImpl->comm, &count));
+    if (static_cast<uint32_t>(count) != worldSize) throw std::runtime_error("RCCL communicator spans " + std::to_string(count) + " ranks, expected " + std::to_string(worldSize));
 }
 
 TileComm::~TileComm()
@@ -157,15 +211,26 @@ TileComm::~TileComm()
 
 uint32_t TileComm::rank() const { return mImpl->rank; }
 uint32_t TileComm::worldSize() const { return mImpl->world; }
+int      TileComm::deviceOrdinal() const { return mImpl->device; }
+
+void TileComm::rcclInfo(uint32_t& count, uint32_t& userRank, int& device) const
+{
+    int c = 0, r = 0, d = 0;
+    RF_NCCL(ncclCommCount(mImpl->comm, &c));
+    RF_NCCL(ncclCommUserRank(mImpl->comm, &r));
+    RF_NCCL(ncclCommCuDevice(mImpl->comm, &d));
+    count = static_cast<uint32_t>(c), userRank = static_cast<uint32_t>(r), device = d;
+}
 
 const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uint32_t height, uint32_t root, void* streamHandle, bool loopback)
 {
     Impl& m = *mImpl;
+    if (m.comm == nullptr) throw std::runtime_error("the RCCL communicator was aborted");
     if (root >= m.world) throw std::invalid_argument("gather root out of range");
     if (width == 0 || height == 0) throw std::invalid_argument("empty frame");
     hipStream_t stream = static_cast<hipStream_t>(streamHandle);
     RF_HIP(hipSetDevice(m.device));
-    m.ensureLayout(width, height);
+    m.ensureLayout(width, height, stream);
     const GatherLayout& g = m.layout;
     const auto          tilesOf = [&](uint32_t r) { return g.rankFirstTile[r + 1] - g.rankFirstTile[r]; };
     const size_t        floatsPerTile = static_cast<size_t>(kTilePixels) * 4;
@@ -173,26 +238,26 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
     if (tilesOf(m.rank) > 0 && compactDevice == nullptr) throw std::invalid_argument("null tile buffer");
     if (isRoot)
     {
-        m.staging.ensure(static_cast<size_t>(g.rankFirstTile[m.world]) * kTilePixels);
-        m.image.ensure(static_cast<size_t>(width) * height);
+        const size_t stagingWant = static_cast<size_t>(g.rankFirstTile[m.world]) * kTilePixels, imageWant = static_cast<size_t>(width) * height;
+        if (stagingWant > m.staging.n || imageWant > m.image.n) RF_HIP(hipStreamSynchronize(stream)); // a consumer of the old buffers may still run
+        m.staging.ensure(stagingWant);
+        m.image.ensure(imageWant);
         m.imageW = width;
         m.imageH = height;
     }
 
-    // one group: the root posts every receive at once, so all of its xGMI links carry data concurrently
+    // one group: exactly the operations of gatherPlan() (the list the CPU tests check for every rank of a world)
+    const std::vector<GatherOp> plan = gatherPlan(g, m.world, m.rank, root, loopback);
     RF_NCCL(ncclGroupStart());
     try
     {
-        if (isRoot)
+        for (const GatherOp& op : plan)
         {
-            for (uint32_t p = 0; p < m.world; ++p)
-            {
-                if (tilesOf(p) == 0 || (p == root && !loopback)) continue;
-                RF_NCCL(ncclRecv(m.staging.p + static_cast<size_t>(g.rankFirstTile[p]) * kTilePixels, tilesOf(p) * floatsPerTile, ncclFloat, static_cast<int>(p), m.comm, stream));
-            }
+            if (op.isSend)
+                RF_NCCL(ncclSend(static_cast<const float*>(compactDevice) + op.offsetTiles * floatsPerTile, op.countTiles * floatsPerTile, ncclFloat, static_cast<int>(op.peer), m.comm, stream));
+            else
+                RF_NCCL(ncclRecv(m.staging.p + static_cast<size_t>(op.offsetTiles) * kTilePixels, op.countTiles * floatsPerTile, ncclFloat, static_cast<int>(op.peer), m.comm, stream));
         }
-        if (tilesOf(m.rank) > 0 && (!isRoot || loopback))
-            RF_NCCL(ncclSend(compactDevice, tilesOf(m.rank) * floatsPerTile, ncclFloat, static_cast<int>(root), m.comm, stream));
     }
     catch (...)
     {
@@ -200,6 +265,34 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
         throw;
     }
     RF_NCCL(ncclGroupEnd());
+    if (!m.firstGatherDone)
+    {
+        // The first exchange of a communicator also sets up its peer connections; a peer that never posts its side (it died, it
+        // disagrees about the frame size or the root) would leave this stream stuck forever.  Watch this one exchange: past the
+        // time limit the communicator is aborted and the caller gets an error instead of a hang.  Later gathers are not watched
+        // (they stay fully asynchronous).  NOTE: an exception thrown on one rank leaves its peers waiting in their own gather
+        // until THEIR limit expires.
+        const double timeout = commTimeoutSeconds();
+        const auto   t0 = std::chrono::steady_clock::now();
+        for (;;)
+        {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) RF_HIP(q);
+            ncclResult_t async = ncclSuccess;
+            RF_NCCL(ncclCommGetAsyncError(m.comm, &async));
+            if (async != ncclSuccess && async != ncclInProgress) throw std::runtime_error(std::string("RCCL error during the first frame exchange: ") + ncclGetErrorString(async));
+            if (timeout > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout)
+            {
+                (void)ncclCommAbort(m.comm);
+                m.comm = nullptr;
+                throw std::runtime_error("RCCL: the first frame exchange did not complete within " + std::to_string(static_cast<int>(timeout)) + " s on rank " +
+                                         std::to_string(m.rank) + " (a peer is missing or disagrees about frame size / root); communicator aborted");
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        m.firstGatherDone = true;
+    }
     if (!isRoot) return nullptr;
 
     const uint32_t numTiles = g.tilesX * g.tilesY;

@@ -27,6 +27,20 @@ struct GatherLayout
 };
 GatherLayout gatherLayout(uint32_t width, uint32_t height, uint32_t worldSize);
 
+// The point-to-point operations ONE rank posts (inside one RCCL group) for a frame-end gather to `root`: what
+// TileComm::gatherFrame() executes, as data.  Offsets and counts are in tiles (1024 float4 each): a receive lands
+// at `offsetTiles` of the root's staging area, a send starts at `offsetTiles` (always 0) of the rank's own compact
+// buffer.  Pure host arithmetic: the plan of every rank of a world can be checked without a GPU
+// (tests/test_distributed_cpu.py: every send has its receive, the receives tile the staging area exactly).
+struct GatherOp
+{
+    uint32_t isSend;      // 1: ncclSend to `peer`, 0: ncclRecv from `peer`
+    uint32_t peer;
+    uint32_t offsetTiles;
+    uint32_t countTiles;
+};
+std::vector<GatherOp> gatherPlan(const GatherLayout& layout, uint32_t worldSize, uint32_t rank, uint32_t root, bool loopback);
+
 class TileComm
 {
 public:
@@ -40,6 +54,10 @@ public:
 
     uint32_t rank() const;
     uint32_t worldSize() const;
+    int      deviceOrdinal() const;
+    // What RCCL itself reports for this communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): proof of how
+    // many ranks the exchange really spans.
+    void rcclInfo(uint32_t& count, uint32_t& userRank, int& device) const;
 
     // Frame-end exchange, enqueued on `stream` (a hipStream_t: the renderer's, so the exchange is ordered behind
     // the frame's kernels).  compactDevice: this rank's tile-major buffer (tilesForRank(...).size() * 1024 float4).

@@ -1720,7 +1720,10 @@ __global__ __launch_bounds__(kBlock) void kDeferredLighting(DeviceScene scene, S
     const uint32_t blocksX = (width + 7u) / 8u;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = (wave % blocksX) * 8u + (lane & 7u), y = (wave / blocksX) * 8u + (lane >> 3);
-    if (x >= width || y >= height) return;
+    // lanes outside the frame (sizes that are not multiples of 8) stay alive for the wave reduction at the end and contribute 0
+    unsigned long long closest = 0, shadow = 0;
+    if (x < width && y < height)
+    {
     const float W = static_cast<float>(width), H = static_cast<float>(height);
     // pixel centre displaced by the frame's projection jitter (deferred_renderer.cpp:309-315: (r2 - 0.5) / size in NDC)
     const float su = (static_cast<float>(x) + 0.5f) / W - (jitterX - 0.5f) / (2.0f * W);
@@ -1728,7 +1731,7 @@ __global__ __launch_bounds__(kBlock) void kDeferredLighting(DeviceScene scene, S
     const Vec3  rd = normalize(cam.lowerLeftCorner + cam.horizontal * su + cam.vertical * tv - cam.origin);
     TraversalCounters  tc;
     ClosestHit         h;
-    unsigned long long closest = 1, shadow = 0;
+    closest = 1;
     Vec3               color;
     const Vec3         lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
     if (!traverse<false, false>(scene, cam.origin, rd, kTMax, &sStack[threadIdx.x], h, tc)) color = skyWithSun(sky, rd); // :106-117
@@ -1801,6 +1804,7 @@ __global__ __launch_bounds__(kBlock) void kDeferredLighting(DeviceScene scene, S
     }
     bgraOut[idx] = q[2] | (q[1] << 8) | (q[0] << 16) | (255u << 24);
     if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
+    }
     const unsigned long long cr = waveSum(closest), sr = waveSum(shadow);
     if (__lane_id() == 0)
     {
@@ -1995,27 +1999,60 @@ struct Renderer::Impl
     }
 
     uint64_t allocatedPaths = 0;
+    bool     maxPathsIsDefault = true; // no caller-chosen batch depth: clamp it by the memory that is free (render())
+
+    // bytes of path state + queues per path slot (eight packed xyz streams, two float4 streams, three u32 queues)
+    static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 3 * sizeof(uint32_t);
+
+    void releasePathState()
+    {
+        sRayO.release(), sRayD.release(), sRayD2.release(), sThr.release(), sThr2.release(), sRad.release(), sHit.release();
+        sPending.release(), sNoise.release(), sNoise2.release(), queueA.release(), queueB.release(), missQueue.release();
+        allocatedPaths = 0;
+    }
 
     // Path streams and queues are allocated on demand for the largest batch actually traced
     // (at most maxPaths): small renders stay small, big ones use the HBM that is there.
-    void ensurePathState(uint64_t paths)
+    // Returns false when the device is out of memory: nothing stays allocated then (allocatedPaths = 0), and the
+    // caller retries with a smaller batch.  allocatedPaths is only raised once every buffer exists.
+    bool ensurePathState(uint64_t paths)
     {
-        if (paths <= allocatedPaths) return;
+        if (paths <= allocatedPaths) return true;
         RF_HIP(hipStreamSynchronize(stream));
+        releasePathState();
+        const auto tryAlloc = [](auto& buf, uint64_t n) -> bool {
+            void* p = nullptr;
+            const hipError_t e = hipMalloc(&p, n * sizeof(*buf.ptr));
+            if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation)
+            {
+                (void)hipGetLastError(); // clear the sticky error
+                return false;
+            }
+            RF_HIP(e);
+            buf.ptr = static_cast<decltype(buf.ptr)>(p);
+            buf.count = n;
+            return true;
+        };
+        const bool ok = tryAlloc(sRayO, paths) && tryAlloc(sRayD, paths) && tryAlloc(sRayD2, paths) && tryAlloc(sThr, paths) && tryAlloc(sThr2, paths) &&
+                        tryAlloc(sRad, paths) && tryAlloc(sHit, paths) && tryAlloc(sPending, paths) && tryAlloc(sNoise, paths) && tryAlloc(sNoise2, paths) &&
+                        tryAlloc(queueA, paths) && tryAlloc(queueB, paths) && tryAlloc(missQueue, paths);
+        if (!ok)
+        {
+            releasePathState();
+            return false;
+        }
         allocatedPaths = paths;
-        sRayO.alloc(paths);
-        sRayD.alloc(paths);
-        sRayD2.alloc(paths);
-        sThr.alloc(paths);
-        sThr2.alloc(paths);
-        sRad.alloc(paths);
-        sHit.alloc(paths);
-        sPending.alloc(paths);
-        sNoise.alloc(paths);
-        sNoise2.alloc(paths);
-        queueA.alloc(paths);
-        queueB.alloc(paths);
-        missQueue.alloc(paths);
+        return true;
+    }
+
+    // Largest batch (in paths) the device can hold right now: what is free plus what the path state already holds, with a
+    // tenth kept back for the allocator's granularity and for whoever else uses the device.
+    uint64_t pathsThatFit()
+    {
+        size_t freeBytes = 0, totalBytes = 0;
+        RF_HIP(hipMemGetInfo(&freeBytes, &totalBytes));
+        const uint64_t budget = static_cast<uint64_t>(freeBytes) + allocatedPaths * kBytesPerPath;
+        return budget / 10 * 9 / kBytesPerPath;
     }
 
     void configureShard()
@@ -2109,7 +2146,7 @@ struct Renderer::Impl
     void queryWide(const float* rays6, uint64_t n, float tMax, bool shadow, std::vector<float4>& out0, std::vector<float4>& out1)
     {
         if (n > 0xFFFFFFFFull) throw std::runtime_error("too many rays");
-        ensurePathState(n);
+        if (!ensurePathState(n)) throw std::runtime_error("out of device memory for the ray batch");
         std::vector<P3>       o(n), d(n);
         std::vector<uint32_t> ids(n);
         for (uint64_t i = 0; i < n; ++i)
@@ -2493,6 +2530,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     // wave (FrameParams::samplePerm).  Measured on the atrium, 1080p, Mrays/s: 64 Mi 5125, 128 Mi 5171, 256 Mi 5224 (before
     // the sample sort); 256 Mi 5692, 512 Mi 5826 / 5796, 1 Gi 5983 (with it).
     const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (1024ull << 20);
+    m.maxPathsIsDefault = desc.maxPathsInFlight == 0;
     // path slots and queue indices are 32-bit: at most 2^31 paths per batch, and one sample of the whole
     // (padded) frame must fit in a batch
     constexpr uint64_t kMaxPathsPerBatch = 1ull << 31;
@@ -2576,13 +2614,30 @@ void Renderer::render(uint32_t numFrames)
             RF_HIP(hipMemsetAsync(m.image, 0, pixelsPadded * sizeof(float4), m.stream)); // wgsl:47-49
             m.imageDirty = false;
         }
-        const uint32_t perBatch = static_cast<uint32_t>(std::max<uint64_t>(1, m.maxPaths / pixelsPadded));
         // equal batches (320 samples with room for 256 per batch -> 160 + 160, not 256 + 64): a small trailing batch has
         // short launches and, with few samples per pixel, less coherent waves
         const uint32_t todo = std::min(remaining, spp - m.accumulated);
-        const uint32_t numBatches = (todo + perBatch - 1) / perBatch;
-        const uint32_t n = (todo + numBatches - 1) / numBatches;
-        m.ensurePathState(static_cast<uint64_t>(n) * pixelsPadded);
+        uint32_t       n = 0;
+        for (;;)
+        {
+            const uint32_t perBatch = static_cast<uint32_t>(std::max<uint64_t>(1, m.maxPaths / pixelsPadded));
+            const uint32_t numBatches = (todo + perBatch - 1) / perBatch;
+            n = (todo + numBatches - 1) / numBatches;
+            const uint64_t need = static_cast<uint64_t>(n) * pixelsPadded;
+            if (need <= m.allocatedPaths) break;
+            // The batch depth is a speed knob, never a requirement: a device with less free memory than the
+            // batch wants (a smaller or shared GPU, a second handle on this one) traces the same samples in more, smaller
+            // batches -- same image.  First by what hipMemGetInfo reports, then by halving if hipMalloc still refuses.
+            const uint64_t fit = m.pathsThatFit();
+            if (need > fit && n > 1)
+            {
+                m.maxPaths = std::max<uint64_t>(pixelsPadded, std::min(m.maxPaths / 2, fit));
+                continue;
+            }
+            if (m.ensurePathState(need)) break;
+            if (n == 1) throw std::runtime_error("out of device memory: one sample of the frame (" + std::to_string(need * Impl::kBytesPerPath >> 20) + " MiB of path state) does not fit");
+            m.maxPaths = std::max<uint64_t>(pixelsPadded, m.maxPaths / 2);
+        }
         m.traceBatch(m.frameCount, n);
         m.frameCount += n;
         m.accumulated += n;
@@ -2634,6 +2689,25 @@ void Renderer::readAccumulation(float* dst)
 }
 
 void*    Renderer::accumulationDevicePointer() const { return mImpl->image; }
+
+void Renderer::clearAccumulationIfStale()
+{
+    Impl& m = *mImpl;
+    if (!m.imageDirty || m.image == nullptr) return;
+    RF_HIP(hipSetDevice(m.device));
+    RF_HIP(hipMemsetAsync(m.image, 0, static_cast<size_t>(m.tiles.size()) * 1024 * sizeof(float4), m.stream)); // wgsl:47-49
+    m.imageDirty = false;
+}
+
+void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, uint64_t& maxPathsPerBatch, uint64_t& sceneBytes) const
+{
+    const Impl& m = *mImpl;
+    pathsAllocated = m.allocatedPaths;
+    pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
+    maxPathsPerBatch = m.maxPaths;
+    sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
+                 m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2);
+}
 uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }
 
 void Renderer::bindAccumulationBuffer(void* devicePtr, uint64_t bytes)
@@ -2776,7 +2850,12 @@ void Renderer::setOption(const std::string& name, int64_t value)
         Impl&          m = *mImpl;
         const uint64_t pixelsPadded = static_cast<uint64_t>(m.tiles.size()) * 1024;
         RF_HIP(hipSetDevice(m.device));
-        if (pixelsPadded) m.ensurePathState(std::min<uint64_t>(std::max<uint64_t>(static_cast<uint64_t>(value), 1) * pixelsPadded, std::max(m.maxPaths / pixelsPadded, uint64_t{1}) * pixelsPadded));
+        if (pixelsPadded)
+        {
+            uint64_t samples = std::min<uint64_t>(std::max<uint64_t>(static_cast<uint64_t>(value), 1), std::max(m.maxPaths / pixelsPadded, uint64_t{1}));
+            samples = std::max<uint64_t>(std::min(samples, m.pathsThatFit() / pixelsPadded), 1);
+            (void)m.ensurePathState(samples * pixelsPadded); // best effort: render() falls back to smaller batches
+        }
     }
     else if (name == "query_variant") mImpl->queryVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
     else if (name == "persistent_blocks") mImpl->wideBlocks = static_cast<uint32_t>(value);

@@ -125,6 +125,12 @@ public:
     // Device pointer of the compact tile-major accumulation buffer (numTiles*1024 float4) and a
     // way to render into caller-owned device memory (e.g. a torch tensor used for the RCCL gather).
     void*    accumulationDevicePointer() const;
+    // Zero the accumulation buffer (on the handle's stream) if nothing has been rendered into it since the last reset, so that a
+    // reader on the device (the frame exchange) never sees the previous frame's sums.
+    void     clearAccumulationIfStale();
+    // Device memory held: path state + queues (allocated on demand, kBytesPerPath per path slot), the batch depth in use, and
+    // the resident scene (BVH layouts, triangles, shading records, textures).
+    void     memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, uint64_t& maxPathsPerBatch, uint64_t& sceneBytes) const;
     uint64_t accumulationBytes() const;
     void     bindAccumulationBuffer(void* devicePtr, uint64_t bytes);
     // BGRA8 swap-chain image (wgsl:59-63), row-major.

@@ -117,6 +117,12 @@ def _texture_sizes():
 
 
 # ----------------------------------------------------------------------------- mesh helpers
+# Tessellation factor of every surface grid (atrium(scale)): scale s multiplies both grid directions, i.e. s^2 times the
+# triangles (265 k at 1; 17 M at 8 -- 2.2 GB of BVH records + triangles, an order of magnitude past the 256 MiB Infinity Cache:
+# the out-of-cache regime of bench.py --scene-scale).  Same shapes, textures and camera; the surfaces' small bumps are re-sampled.
+_SCALE = 1
+
+
 class _Mesh:
     def __init__(self):
         self.P, self.N, self.UV, self.T = [], [], [], []
@@ -150,6 +156,7 @@ def _bump(u, v, seed, amp):
 
 
 def _plane(mesh, origin, eu, ev, nu, nv, tex, uv_scale, bump_seed=0, bump=0.0):
+    nu, nv = nu * _SCALE, nv * _SCALE
     origin, eu, ev = (np.asarray(a, np.float64) for a in (origin, eu, ev))
     s, t = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1), indexing="ij")
     n = _normalize(np.cross(eu, ev))
@@ -163,6 +170,7 @@ def _plane(mesh, origin, eu, ev, nu, nv, tex, uv_scale, bump_seed=0, bump=0.0):
 
 
 def _column(mesh, cx, cz, y0, y1, radius, sides, segs, tex, flutes=12):
+    sides, segs = sides * _SCALE, segs * _SCALE
     ang = np.arange(sides + 1, dtype=np.float64) * (6.283185307179586 / sides)
     sn, cs = _sincos(ang)
     fl, _ = _sincos(ang * flutes)
@@ -177,8 +185,8 @@ def _column(mesh, cx, cz, y0, y1, radius, sides, segs, tex, flutes=12):
     mesh.add_grid(pos, nrm, uv, tex)
     # capital and base as short wide drums
     for (ya, yb, r) in ((y0, y0 + 0.12, radius * 1.35), (y1 - 0.15, y1, radius * 1.45)):
-        tt = np.linspace(0.0, 1.0, 3)
-        xx = cx + r * cs[None, :] * np.ones((3, 1)); zz = cz + r * sn[None, :] * np.ones((3, 1))
+        tt = np.linspace(0.0, 1.0, 2 * _SCALE + 1)
+        xx = cx + r * cs[None, :] * np.ones((tt.size, 1)); zz = cz + r * sn[None, :] * np.ones((tt.size, 1))
         yy = np.broadcast_to((ya + (yb - ya) * tt)[:, None], xx.shape)
         p2 = np.stack([xx, yy, zz], axis=-1)
         n2 = _normalize(np.stack([np.broadcast_to(cs[None, :], xx.shape), np.zeros_like(xx), np.broadcast_to(sn[None, :], xx.shape)], axis=-1))
@@ -189,11 +197,12 @@ def _column(mesh, cx, cz, y0, y1, radius, sides, segs, tex, flutes=12):
 def _arch(mesh, p0, p1, y_spring, rise, thickness, depth_axis, depth, steps, tex):
     """Semi-elliptical arch band between two column tops, extruded along depth_axis."""
     p0, p1 = np.asarray(p0, np.float64), np.asarray(p1, np.float64)
+    steps = steps * _SCALE
     a = np.linspace(0.0, 3.141592653589793, steps + 1)
     sn, cs = _sincos(a)
     mid = 0.5 * (p0 + p1); half = 0.5 * (p1 - p0)
     d = np.zeros(3); d[depth_axis] = depth
-    w = np.linspace(-0.5, 0.5, 5)
+    w = np.linspace(-0.5, 0.5, 4 * _SCALE + 1)
     for r_scale, flip in ((1.0, 1.0), (1.0 + thickness, -1.0)):
         base = mid[None, :] - cs[:, None] * half[None, :] * r_scale
         base = base + np.array([0.0, 1.0, 0.0])[None, :] * (y_spring + rise * r_scale * sn)[:, None]
@@ -206,6 +215,7 @@ def _arch(mesh, p0, p1, y_spring, rise, thickness, depth_axis, depth, steps, tex
 
 
 def _curtain(mesh, p0, p1, y_top, y_bot, waves, nu, nv, tex, amp, seed):
+    nu, nv = nu * _SCALE, nv * _SCALE
     p0, p1 = np.asarray(p0, np.float64), np.asarray(p1, np.float64)
     s, t = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1), indexing="ij")
     along = p1 - p0
@@ -222,8 +232,17 @@ def _curtain(mesh, p0, p1, y_top, y_bot, waves, nu, nv, tex, amp, seed):
     mesh.add_grid(pos, nrm, uv, tex)
 
 
-def atrium_triangles():
+def atrium_triangles(scale=1):
     """-> positions (N,9), normals (N,9), uvs (N,6), texture index (N,) in source order."""
+    global _SCALE
+    _SCALE = int(scale)
+    try:
+        return _atrium_triangles()
+    finally:
+        _SCALE = 1
+
+
+def _atrium_triangles():
     m = _Mesh()
     X0, X1, Z0, Z1 = -15.0, 15.0, -7.0, 7.0   # outer walls
     CX0, CX1, CZ0, CZ1 = -11.5, 11.5, -3.4, 3.4  # open court
@@ -295,10 +314,12 @@ def atrium_textures():
 _CACHE = {}
 
 
-def atrium():
-    """-> (PtFormat, info dict).  The BVH is built by the product's host builder."""
-    if "atrium" not in _CACHE:
-        P, N, UV, T = atrium_triangles()
+def atrium(scale=1):
+    """-> (PtFormat, info dict).  The BVH is built by the product's builder (host by default: rf.set_bake_bvh_builder).
+    scale > 1: every surface grid tessellated scale x finer in both directions (scale^2 x the triangles)."""
+    key = "atrium" if scale == 1 else f"atrium{scale}"
+    if key not in _CACHE:
+        P, N, UV, T = atrium_triangles(scale)
         tex = atrium_textures()
         pt = PtFormat.from_triangles(P, N, UV, T, tex)
         h = hashlib.sha256()
@@ -306,10 +327,11 @@ def atrium():
             h.update(np.ascontiguousarray(a).tobytes())
         for px, w, hh in tex:
             h.update(px.tobytes())
-        info = dict(name="synthetic atrium (Sponza stand-in)", triangles=int(P.shape[0]), textures=len(tex),
+        name = "synthetic atrium (Sponza stand-in)" if scale == 1 else f"synthetic atrium x{scale} tessellation (out-of-cache variant of the Sponza stand-in)"
+        info = dict(name=name, triangles=int(P.shape[0]), textures=len(tex),
                     texture_mib=sum(px.size for px, _, _ in tex) * 4 / 2 ** 20, digest=h.hexdigest()[:16])
-        _CACHE["atrium"] = (pt, info)
-    return _CACHE["atrium"]
+        _CACHE[key] = (pt, info)
+    return _CACHE[key]
 
 
 def quad_scene(albedo_rgb=(255, 255, 255), size=2.0, y=0.0):

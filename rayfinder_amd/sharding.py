@@ -8,7 +8,7 @@ and the only exchange is the gather of the compact per-rank accumulation buffers
 """
 import numpy as np
 
-from . import gather_layout, tiles_for_rank, untile
+from . import gather_layout, gather_plan, tiles_for_rank, untile
 
 
 def shard_layout(width, height, rank, world_size):
@@ -68,3 +68,54 @@ def assemble_with_layout(parts, width, height, world_size):
         ok = (x < width) & (y < height)
         image[y[ok], x[ok]] = staging[int(slot[tile]) * 1024 + w[ok]]
     return image
+
+
+def exchange_with_plan(compact, width, height, rank, world_size, root=0, group=None):
+    """The frame-end exchange exactly as the C++ posts it (rf_gather_plan = the list TileComm::gatherFrame executes:
+    one receive per peer into the root's staging area, one send per non-root rank), driven through torch.distributed
+    point-to-point calls so that it runs on CPU under gloo.  Root: the row-major (H, W, 4) image; others: None."""
+    import torch
+    import torch.distributed as dist
+
+    first, slot, owner = gather_layout(width, height, world_size)
+    plan = gather_plan(width, height, world_size, rank, root)
+    staging = torch.zeros((int(first[-1]) * 1024, 4), dtype=torch.float32) if rank == root else None
+    reqs = []
+    for is_send, peer, off, cnt in plan.tolist():
+        if is_send:
+            reqs.append(dist.isend(compact[off * 1024:(off + cnt) * 1024].contiguous(), dst=peer, group=group))
+        else:
+            reqs.append(dist.irecv(staging[off * 1024:(off + cnt) * 1024], src=peer, group=group))
+    for r in reqs:
+        r.wait()
+    if rank != root:
+        return None
+    # the root's own shard is read in place (no loopback)
+    n_own = int(first[root + 1] - first[root])
+    staging[int(first[root]) * 1024:int(first[root + 1]) * 1024] = compact[: n_own * 1024]
+    tiles_x = (width + 31) // 32
+    image = np.zeros((height, width, 4), np.float32)
+    st = staging.numpy()
+    w = np.arange(1024)
+    block, lane = w >> 6, w & 63
+    dx, dy = (block & 3) * 8 + (lane & 7), (block >> 2) * 8 + (lane >> 3)
+    for tile in range(len(slot)):
+        x, y = (tile % tiles_x) * 32 + dx, (tile // tiles_x) * 32 + dy
+        ok = (x < width) & (y < height)
+        image[y[ok], x[ok]] = st[int(slot[tile]) * 1024 + w[ok]]
+    return image
+
+
+def tile_major(image, tiles, width, height, max_tiles=None):
+    """Row-major (H, W, 4) image -> the compact tile-major buffer a rank's renderer holds for `tiles`
+    (32x32 tiles of 8x8-pixel blocks; pixels outside the frame are zero)."""
+    out = np.zeros(((max_tiles or len(tiles)) * 1024, 4), np.float32)
+    tiles_x = (width + 31) // 32
+    w = np.arange(1024)
+    block, lane = w >> 6, w & 63
+    dx, dy = (block & 3) * 8 + (lane & 7), (block >> 2) * 8 + (lane >> 3)
+    for t, tid in enumerate(tiles):
+        x, y = (int(tid) % tiles_x) * 32 + dx, (int(tid) // tiles_x) * 32 + dy
+        ok = (x < width) & (y < height)
+        out[t * 1024 + w[ok]] = image[y[ok], x[ok]]
+    return out

@@ -130,6 +130,52 @@ per_ray = dict(
     source="rocprofv3 --pmc passes of `bench.py --no-cpu-baseline --no-counting` (tools/roofline_pmc.sh), one counter group per run, averaged over every launch of "
            "the kernel and divided by the rays one launch traces; FETCH_SIZE / WRITE_SIZE (KB) x 1024 x the calibration factors of calibration.json; fabric-side "
            "requests of the 8 L2s (Infinity-Cache hits included)")
+def kernel_block(prefix, rays_timed, label):
+    """Fabric-side bytes and L1 / L2 figures per unit of work for every instantiation of a kernel whose name starts with `prefix`."""
+    names = [n for n in pm if n.startswith(prefix)]
+    if not names or not rays_timed:
+        return None
+    kk = {"_dispatches": sum(pm[n]["_dispatches"] for n in names)}
+    for n in names:
+        for c, v in pm[n].items():
+            if c != "_dispatches":
+                kk[c] = kk.get(c, 0.0) + v * pm[n]["_dispatches"] / kk["_dispatches"]
+    units = rays_timed * (bench["steps"] + bench["warmup"]) / bench["steps"] / kk["_dispatches"]
+    f, w = kk.get("FETCH_SIZE", 0.0) * 1024.0 / units, kk.get("WRITE_SIZE", 0.0) * 1024.0 / units
+    return dict(kernel=label, instantiations={n: pm[n]["_dispatches"] for n in names}, units_per_average_dispatch=round(units),
+                fetch_size_bytes_per_unit=round(f, 2), write_size_bytes_per_unit=round(w, 2),
+                l1_accesses_per_unit=round(kk.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / units, 2),
+                l1_to_l2_read_requests_per_unit=round(kk.get("TCP_TCC_READ_REQ_sum", 0.0) / units, 2),
+                l2_hit_rate=round(kk["TCC_HIT_sum"] / max(kk["TCC_HIT_sum"] + kk["TCC_MISS_sum"], 1.0), 4) if "TCC_HIT_sum" in kk else None)
+
+
+# the other two kernels the bench line prices: the shadow traversal (per shadow ray; random record gathers like the closest-hit
+# kernel: same read calibration) and kShade (per queue entry = per closest-hit ray; its reads are a mix of coalesced streams --
+# counted at 0.5 -- and 128-byte record gathers -- counted at ~1 --, so its bytes are reported with BOTH factors as a bracket)
+sh = kernel_block("kTraceWide<true", bench["rays"]["shadow"], "kTraceWide<shadow>")
+if sh:
+    sh["hbm_side_bytes_per_unit"] = round(fc * sh["fetch_size_bytes_per_unit"] + wc * sh["write_size_bytes_per_unit"], 2)
+    per_ray["shadow"] = sh
+kd = kernel_block("kShade<", bench["rays"]["closest"], "kShade")
+if kd:
+    stream = factors.get("streaming_read_ratio") or 0.5
+    kd["hbm_side_bytes_per_unit_low"] = round(fc * kd["fetch_size_bytes_per_unit"] + wc * kd["write_size_bytes_per_unit"], 2)
+    kd["hbm_side_bytes_per_unit_high"] = round(kd["fetch_size_bytes_per_unit"] / stream + wc * kd["write_size_bytes_per_unit"], 2)
+    kd["note"] = "low: every read counted as a random gather (FETCH_SIZE x %.3f); high: every read counted as a coalesced stream (FETCH_SIZE / %.3f)" % (fc, stream)
+    per_ray["shade"] = kd
+# ceilings measured by the calibration microbenchmark on this chip (tools/microbench/fetch_calib.hip): L1 -> L2 request rate of a
+# random 64-byte record stream served by L2 / Infinity Cache (32 MiB table) and by HBM (8 GiB table), and the streaming rates
+req_rates = {k2: v["rate"] * v["l1_to_l2_read_requests_per_record"] for k2, v in calibration.items()
+             if k2.startswith("gather") and k2.endswith("<25>") and "l1_to_l2_read_requests_per_record" in v and not k2.startswith("gather12")}
+hbm_gather = {k2: v["rate"] * 64.0 for k2, v in calibration.items() if k2.startswith("gather") and k2.endswith("<33>") and not k2.startswith("gather12")}
+per_ray["ceilings"] = dict(
+    l1_to_l2_requests_G_per_s=round(max(req_rates.values()), 1) if req_rates else None,
+    l1_to_l2_requests_source={k2: round(v, 1) for k2, v in req_rates.items()},
+    hbm_random_64B_gather_GBps=round(max(hbm_gather.values()), 1) if hbm_gather else None,
+    hbm_random_64B_gather_source={k2: round(v, 1) for k2, v in hbm_gather.items()},
+    hbm_stream_read_GBps=calibration.get("stream16<33>", {}).get("rate"), hbm_stream_write_GBps=calibration.get("fill16<33>", {}).get("rate"),
+    note="measured on this chip by tools/microbench/fetch_calib.hip: G L1->L2 read requests/s of a random 64-byte record gather over a 32 MiB table "
+         "(cache resident) = records/s x requests per record; bytes/s of the same gather over an 8 GiB table (every record from HBM)")
 json.dump(per_ray, open(os.path.join(out, "pmc_per_ray.json"), "w"), indent=1)
 print(json.dumps(per_ray, indent=1))
 
@@ -180,6 +226,8 @@ for kind in ("closest", "shadow"):
                 e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 3)
         table.append(e)
 if table:
+    per_ray["per_bounce"] = table
+    json.dump(per_ray, open(os.path.join(out, "pmc_per_ray.json"), "w"), indent=1)
     json.dump(dict(profile=os.path.basename(os.path.abspath(out)), spp_of_the_batch=bench["config"]["spp"],
                    note="one row per launch of the timed batch; l1_accesses_per_clk_per_cu is against the ceiling of 1 (one vector-L1 tag access per clock "
                         "per CU); valu_issue_share = wave instructions x 4 cycles / SIMD-cycles available", rows=table),
