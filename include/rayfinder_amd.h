@@ -265,6 +265,43 @@ RF_API int rf_renderer_intersect_rays(rf_renderer* r, const float* rays6, uint64
 RF_API int rf_renderer_occluded_rays(rf_renderer* r, const float* rays6, uint64_t num_rays, float t_max, float* visibility);
 
 /* ---------------------------------------------------------------------------------------------
+ * BVH queries on the HOST (no GPU needed; re-entrant pure functions)
+ * ------------------------------------------------------------------------------------------ */
+/* nlrs::Intersection {p, t} (src/common/ray_intersection.hpp:15-19) plus the triangle hit and its barycentrics. */
+typedef struct rf_intersection
+{
+    float    p[3];     /* offset hit point (offsetRay, ray_intersection.cpp:17-35) */
+    float    t;
+    uint32_t triangle; /* index into the triangle array (BVH leaf order); 0xFFFFFFFF on a miss */
+    float    u, v;
+} rf_intersection;
+/* nlrs::BvhStats (ray_intersection.hpp:38-41) plus triangle tests and the high-water mark of the pending-node list. */
+typedef struct rf_bvh_stats
+{
+    uint32_t nodes_visited, triangle_tests, stack_high_water;
+} rf_bvh_stats;
+/* bool rayIntersectBvh(const Ray&, span<const BvhNode>, span<const Positions>, float tMax, Intersection&, BvhStats* = nullptr)
+ * (src/common/ray_intersection.hpp:43-49, .cpp:138-213): the reference's CPU query -- focus picking (src/pt/main.cpp:214-225),
+ * bvh-visualizer (src/bvh-visualizer/main.cpp:60-78) -- on the host, bit-identical hit / t / p / nodesVisited.
+ * positions: num_triangles records of position_stride_bytes = 36 (Positions, the .pt file's bvhPositionAttributes) or
+ * 48 (PositionAttribute).  *hit_out = 1 / 0 replaces the bool; stats may be NULL.  Pending far children are kept in a list
+ * that grows on demand (the reference's 32-entry array is overrun past depth 32).  Malformed links -> RF_ERROR_RUNTIME. */
+RF_API int rf_intersect_bvh(const float ray6[6], const void* nodes48, uint64_t num_nodes, const void* positions, uint32_t position_stride_bytes,
+                            uint64_t num_triangles, float t_max, rf_intersection* out, rf_bvh_stats* stats /* NULL ok */, int* hit_out);
+/* The same for num_rays rays on num_threads host threads (0 = all hardware threads; static blocks of rays).
+ * hit[i] = 1 / 0; any output array may be NULL. */
+RF_API int rf_intersect_bvh_batch(const float* rays6, uint64_t num_rays, const void* nodes48, uint64_t num_nodes, const void* positions,
+                                  uint32_t position_stride_bytes, uint64_t num_triangles, float t_max, uint32_t num_threads, uint8_t* hit,
+                                  rf_intersection* out, rf_bvh_stats* stats);
+/* The bvh-visualizer pixel loop on the host (src/bvh-visualizer/main.cpp:60-78; the CPU twin of
+ * rf_renderer_trace_primary_stats): rows [row_begin, row_end) of a width x height grid, u = j/W, v = 1-(i+1)/H, tMax = FLT_MAX,
+ * static blocks of scanlines over num_threads threads (0 = all; 1 = what the reference does).  Outputs are indexed
+ * i*width + j over the whole grid; any of them may be NULL. */
+RF_API int rf_bvh_visualizer_pass(const rf_camera* camera, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, const void* nodes48,
+                                  uint64_t num_nodes, const void* positions, uint32_t position_stride_bytes, uint64_t num_triangles, uint32_t num_threads,
+                                  uint32_t* nodes_visited, uint8_t* hit, float* t, uint32_t* triangle_tests);
+
+/* ---------------------------------------------------------------------------------------------
  * CPU-side scene preparation (host code, runs without a GPU)
  * ------------------------------------------------------------------------------------------ */
 /* Bvh buildBvh(std::span<const Positions>) (src/common/bvh.hpp:33, bvh.cpp:263-291).

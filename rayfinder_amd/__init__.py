@@ -101,6 +101,58 @@ def build_bvh(positions36):
     return nodes[:cnt.value].copy(), idx, depth.value
 
 
+# ------------------------------------------------------------------------------------- BVH queries on the host
+INTERSECTION_DTYPE = np.dtype([("p", "<f4", 3), ("t", "<f4"), ("triangle", "<u4"), ("u", "<f4"), ("v", "<f4")])
+BVH_STATS_DTYPE = np.dtype([("nodes_visited", "<u4"), ("triangle_tests", "<u4"), ("stack_high_water", "<u4")])
+
+
+def _positions(tris):
+    """(N, 9) f32 Positions (36 B) or (N, 12) PositionAttribute (48 B) -> (array, stride)"""
+    tris = _f32(tris)
+    tris = tris.reshape(-1, 12 if tris.ndim == 2 and tris.shape[1] == 12 else 9)
+    return tris, tris.shape[1] * 4
+
+
+def intersect_bvh(ray6, nodes, positions, t_max):
+    """rayIntersectBvh (src/common/ray_intersection.hpp:43-49) on the host -> (hit: bool, intersection record, stats record)."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    tris, stride = _positions(positions)
+    out = np.zeros(1, INTERSECTION_DTYPE); st = np.zeros(1, BVH_STATS_DTYPE)
+    hit = C.c_int(0)
+    check(lib.rf_intersect_bvh(_ptr(_f32(ray6)), _ptr(nodes), nodes.shape[0], _ptr(tris), stride, tris.shape[0], np.float32(t_max), _ptr(out), _ptr(st), C.byref(hit)))
+    return bool(hit.value), out[0], st[0]
+
+
+def intersect_bvh_batch(rays6, nodes, positions, t_max, threads=0):
+    """-> dict(hit u8, tri, t, uv, p, nodesVisited, triTests, stackHigh), one entry per ray; host threads, no GPU."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    tris, stride = _positions(positions)
+    rays = _f32(rays6).reshape(-1, 6)
+    n = rays.shape[0]
+    hit = np.zeros(n, np.uint8); out = np.zeros(n, INTERSECTION_DTYPE); st = np.zeros(n, BVH_STATS_DTYPE)
+    check(lib.rf_intersect_bvh_batch(_ptr(rays), n, _ptr(nodes), nodes.shape[0], _ptr(tris), stride, tris.shape[0], np.float32(t_max), threads, _ptr(hit), _ptr(out), _ptr(st)))
+    return dict(hit=hit, tri=out["triangle"].copy(), t=out["t"].copy(), uv=np.stack([out["u"], out["v"]], axis=1), p=out["p"].copy(),
+                nodesVisited=st["nodes_visited"].copy(), triTests=st["triangle_tests"].copy(), stackHigh=st["stack_high_water"].copy())
+
+
+def bvh_visualizer_pass(camera, width, height, nodes, positions, threads=0, row_begin=0, row_end=None):
+    """The bvh-visualizer pixel loop (src/bvh-visualizer/main.cpp:60-78) on the host; the CPU twin of
+    ReferencePathTracer.trace_primary_stats -> dict(nodesVisited, hit, t, triTests), each width*height."""
+    nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+    tris, stride = _positions(positions)
+    n = width * height
+    nv = np.zeros(n, np.uint32); hit = np.zeros(n, np.uint8); t = np.zeros(n, np.float32); tt = np.zeros(n, np.uint32)
+    check(lib.rf_bvh_visualizer_pass(C.byref(camera), width, height, row_begin, height if row_end is None else row_end, _ptr(nodes), nodes.shape[0], _ptr(tris), stride,
+                                     tris.shape[0], threads, _ptr(nv), _ptr(hit), _ptr(t), _ptr(tt)))
+    return dict(nodesVisited=nv, hit=hit, t=t, triTests=tt)
+
+
+def bvh_visualizer_grey(nodes_visited):
+    """src/bvh-visualizer/main.cpp:73-76: grey level u32(min(0.01f * nodesVisited, 1) * 255) per pixel (f32 arithmetic)."""
+    x = np.float32(0.01) * np.asarray(nodes_visited).astype(np.float32)
+    return (np.minimum(x, np.float32(1.0)) * np.float32(255.0)).astype(np.uint32).astype(np.uint8)
+
+
 def check_wide_layouts(nodes):
     """rf_check_wide_layouts: the render path's record layouts of a flattened tree decode to the same child planes (host only).
     -> {"regular": bool, "compact": bool, "hot": bool}; raises on a mismatch."""

@@ -143,6 +143,10 @@ SIGNATURES = {
     "rf_renderer_get_bounce_stats": (C.c_int, [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5),
     "rf_renderer_intersect_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float] + [C.c_void_p] * 6),
     "rf_renderer_occluded_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]),
+    "rf_intersect_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "rf_intersect_bvh_batch": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rf_bvh_visualizer_pass": (C.c_int, [C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_build_bvh": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_int32)]),
     "rf_check_wide_layouts": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
     "rf_build_bvh_gpu": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -8,6 +8,7 @@
 #include "rf_comm.hpp"
 #include "rf_gltf.hpp"
 #include "rf_pt_format.hpp"
+#include "rf_query.hpp"
 #include "rf_renderer.hpp"
 #include "rf_sky.hpp"
 
@@ -429,6 +430,65 @@ int rf_comm_all_reduce_max(rf_comm* c, rf_renderer* r, double* value)
     return guarded([&] {
         require(c && value, "null argument");
         *value = c->impl->allReduceMax(*value, r ? r->impl->streamHandle() : nullptr);
+        return RF_OK;
+    });
+}
+
+namespace
+{
+rf::TriangleSpan triangleSpan(const void* positions, uint32_t stride, uint64_t count)
+{
+    require(stride == 36 || stride == 48, "position_stride_bytes must be 36 (Positions) or 48 (PositionAttribute)");
+    require(positions != nullptr || count == 0, "null triangle array");
+    return rf::TriangleSpan{static_cast<const uint8_t*>(positions), count, stride};
+}
+} // namespace
+
+int rf_intersect_bvh(const float ray6[6], const void* nodes48, uint64_t num_nodes, const void* positions, uint32_t position_stride_bytes, uint64_t num_triangles,
+                     float t_max, rf_intersection* out, rf_bvh_stats* stats, int* hit_out)
+{
+    return guarded([&] {
+        require(ray6 && nodes48 && out && hit_out, "null argument");
+        require(num_nodes > 0, "scene has no BVH nodes");
+        static_assert(sizeof(rf_intersection) == sizeof(rf::HostIntersection) && sizeof(rf_bvh_stats) == sizeof(rf::HostBvhStats));
+        rf::HostIntersection h{};
+        rf::HostBvhStats     st{};
+        const bool           hit = rf::intersectBvh(rf::vec3(ray6[0], ray6[1], ray6[2]), rf::vec3(ray6[3], ray6[4], ray6[5]),
+                                                    std::span<const rf::BvhNode>(static_cast<const rf::BvhNode*>(nodes48), num_nodes),
+                                                    triangleSpan(positions, position_stride_bytes, num_triangles), t_max, h, &st);
+        std::memcpy(out, &h, sizeof h);
+        if (stats) std::memcpy(stats, &st, sizeof st);
+        *hit_out = hit ? 1 : 0;
+        return RF_OK;
+    });
+}
+
+int rf_intersect_bvh_batch(const float* rays6, uint64_t num_rays, const void* nodes48, uint64_t num_nodes, const void* positions, uint32_t position_stride_bytes,
+                           uint64_t num_triangles, float t_max, uint32_t num_threads, uint8_t* hit, rf_intersection* out, rf_bvh_stats* stats)
+{
+    return guarded([&] {
+        require((rays6 || num_rays == 0) && nodes48, "null argument");
+        require(num_nodes > 0, "scene has no BVH nodes");
+        rf::intersectBvhBatch(rays6, num_rays, std::span<const rf::BvhNode>(static_cast<const rf::BvhNode*>(nodes48), num_nodes),
+                              triangleSpan(positions, position_stride_bytes, num_triangles), t_max, num_threads, hit, reinterpret_cast<rf::HostIntersection*>(out),
+                              reinterpret_cast<rf::HostBvhStats*>(stats));
+        return RF_OK;
+    });
+}
+
+int rf_bvh_visualizer_pass(const rf_camera* camera, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end, const void* nodes48, uint64_t num_nodes,
+                           const void* positions, uint32_t position_stride_bytes, uint64_t num_triangles, uint32_t num_threads, uint32_t* nodes_visited, uint8_t* hit,
+                           float* t, uint32_t* triangle_tests)
+{
+    return guarded([&] {
+        require(camera && nodes48, "null argument");
+        require(num_nodes > 0, "scene has no BVH nodes");
+        require(width > 0 && height > 0, "empty image");
+        rf::Camera cam;
+        static_assert(sizeof(rf::Camera) == sizeof(rf_camera));
+        std::memcpy(&cam, camera, sizeof cam);
+        rf::bvhVisualizerPass(cam, width, height, row_begin, row_end, std::span<const rf::BvhNode>(static_cast<const rf::BvhNode*>(nodes48), num_nodes),
+                              triangleSpan(positions, position_stride_bytes, num_triangles), num_threads, nodes_visited, hit, t, triangle_tests);
         return RF_OK;
     });
 }

@@ -986,3 +986,36 @@ def test_rf_render_cli_writes_the_tonemapped_image(duck_pt, tmp_path):
     r.close()
     want = np.stack([(bgra >> 16) & 255, (bgra >> 8) & 255, bgra & 255, bgra >> 24], -1).astype(np.uint8)
     assert np.array_equal(rgba, want)
+
+
+# ---------------------------------------------------------------- bvh-visualizer: the file the tool writes (VERDICT r2 missing 2)
+def test_bvh_visualizer_tool_png_is_the_grey_map_of_the_node_visit_pass(duck_pt, tmp_path):
+    """rf-bvh-visualizer (GPU mode) writes grey = u32(min(0.01 * nodesVisited, 1) * 255), alpha 255
+    (src/bvh-visualizer/main.cpp:73-84) of trace_primary_stats' node-visit map; --cpu writes the SAME bytes from the host pass;
+    GPU pass == host pass (rf_bvh_visualizer_pass) on every output."""
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "rayfinder_amd", "bin", "rf-bvh-visualizer")
+    a = duck_pt.arrays()
+    pt_path = tmp_path / "Duck.pt"
+    duck_pt.save(pt_path)
+    r0, _ = _renderer(duck_pt, 64, 64, 1, 1)
+    for (w, h, args) in ((1280, 720, []), (256, 256, ["256", "256"]), (333, 77, ["333", "77"])):
+        cam = rf.bvh_visualizer_camera(a["bvhNodes"], np.float32(np.float32(w) / np.float32(h)))
+        gpu = r0.trace_primary_stats(cam, w, h)
+        host = rf.bvh_visualizer_pass(cam, w, h, a["bvhNodes"], a["bvhPositionAttributes"])
+        for k in ("nodesVisited", "hit", "triTests"):
+            assert np.array_equal(gpu[k], host[k]), k
+        assert np.array_equal(bits(gpu["t"]), bits(host["t"]))
+        files = []
+        for mode in ([], ["--cpu"]):
+            out = tmp_path / f"viz_{w}_{len(mode)}.png"
+            p = subprocess.run([exe] + mode + ["--out", str(out), str(pt_path)] + args, capture_output=True, text=True, cwd=tmp_path)
+            assert p.returncode == 0, p.stderr
+            files.append(out.read_bytes())
+            img = np.array(Image.open(out))
+            assert img.shape == (h, w, 4) and (img[..., 3] == 255).all()
+            grey = rf.bvh_visualizer_grey(gpu["nodesVisited"]).reshape(h, w)
+            assert np.array_equal(img[..., 0], grey) and np.array_equal(img[..., 1], grey) and np.array_equal(img[..., 2], grey)
+        assert files[0] == files[1]

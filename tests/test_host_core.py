@@ -548,3 +548,157 @@ def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(du
     nodes[0]["secondChildOffset"] = 7
     with pytest.raises(Exception):
         rf.check_wide_layouts(nodes)
+
+
+# ---------------------------------------------------------------- the product's CPU query (rf_query.cpp): config 1 without a GPU
+def test_host_query_node_visits_equal_the_golden_map_and_the_oracle(duck_pt, duck_oracle):
+    """BASELINE.json config 1 through the PRODUCT on a GPU-less box: Duck.glb -> .pt arrays (product ingest + builder) -> the
+    bvh-visualizer pass of rf_bvh_visualizer_pass == the committed golden node-visit map == the oracle, bit for bit."""
+    from oracle import orc
+    g = np.load(os.path.join(GOLDEN, "duck_golden.npz"))
+    a = duck_pt.arrays()
+    cam = rf.bvh_visualizer_camera(a["bvhNodes"], 1.0)
+    out = rf.bvh_visualizer_pass(cam, 256, 256, a["bvhNodes"], a["bvhPositionAttributes"], threads=3)
+    assert np.array_equal(out["nodesVisited"], g["viz256_nodes_visited"].astype(np.uint32))
+    assert np.array_equal(np.packbits(out["hit"]), g["viz256_hit"])
+    assert int(out["nodesVisited"].sum()) == 1209382 and int(out["hit"].sum()) == 19462 and int(out["triTests"].sum()) == 69097
+    # 36-byte Positions and 48-byte PositionAttribute records traverse alike; one thread == many threads
+    out48 = rf.bvh_visualizer_pass(cam, 256, 256, a["bvhNodes"], a["trianglePositionAttributes"], threads=1)
+    for k in ("nodesVisited", "hit", "triTests"):
+        assert np.array_equal(out[k], out48[k])
+    assert np.array_equal(bits(out["t"]), bits(out48["t"]))
+    # the reference tool's own size, against the oracle (t included) and the golden row sums
+    aspect = np.float32(np.float32(1280) / np.float32(720))
+    cam = rf.bvh_visualizer_camera(a["bvhNodes"], aspect)
+    big = rf.bvh_visualizer_pass(cam, 1280, 720, a["bvhNodes"], a["bvhPositionAttributes"])
+    cpu = orc.bvh_visualize(duck_oracle.nodes, duck_oracle.tris36, rf.camera_to_array(cam), 1280, 720)
+    assert np.array_equal(big["nodesVisited"], cpu["nodesVisited"]) and np.array_equal(big["hit"], cpu["hit"])
+    assert np.array_equal(bits(big["t"]), bits(cpu["t"])) and np.array_equal(big["triTests"], cpu["triTests"])
+    assert int(big["nodesVisited"].sum()) == 9979946 and int(big["nodesVisited"].max()) == 159
+    assert np.array_equal(big["nodesVisited"].reshape(720, 1280).sum(axis=1), g["viz720_row_sums"])
+    # a row range leaves the other rows untouched
+    part = rf.bvh_visualizer_pass(cam, 1280, 720, a["bvhNodes"], a["bvhPositionAttributes"], row_begin=100, row_end=104)
+    assert np.array_equal(part["nodesVisited"].reshape(720, 1280)[100:104], big["nodesVisited"].reshape(720, 1280)[100:104])
+    assert part["nodesVisited"].reshape(720, 1280)[:100].sum() == 0 and part["nodesVisited"].reshape(720, 1280)[104:].sum() == 0
+
+
+def test_host_query_reference_bvh_test_grid(duck_pt, duck_oracle):
+    """src/tests/bvh.cpp:76-101: the 64 x 64 ray grid, tMax = 1000 -- hit, t, triangle == golden (== brute force), p / u / v /
+    nodesVisited / stack high-water == oracle; single-ray entry point == batch."""
+    from oracle import orc
+    g = np.load(os.path.join(GOLDEN, "duck_golden.npz"))
+    a = duck_pt.arrays()
+    out = rf.intersect_bvh_batch(g["grid_rays"], a["bvhNodes"], a["bvhPositionAttributes"], 1000.0, threads=4)
+    assert np.array_equal(out["hit"], g["grid_hit"]) and int(out["hit"].sum()) == 1216
+    h = out["hit"] == 1
+    assert np.array_equal(bits(out["t"][h]), bits(g["grid_t"][h])) and np.array_equal(out["tri"][h], g["grid_tri"][h])
+    assert (out["tri"][~h] == 0xFFFFFFFF).all()
+    ref = orc.intersect_bvh_batch(duck_oracle.nodes, duck_oracle.tris36, g["grid_rays"], 1000.0)
+    assert np.array_equal(out["nodesVisited"], ref["nodesVisited"]) and np.array_equal(out["triTests"], ref["triTests"])
+    assert np.array_equal(out["stackHigh"], ref["stackHigh"])
+    assert np.array_equal(bits(out["p"][h]), bits(ref["p"][h])) and np.array_equal(bits(out["uv"][h]), bits(ref["uv"][h]))
+    for i in (0, 777, 2048, 4095, int(np.flatnonzero(h)[0]), int(np.flatnonzero(h)[-1])):
+        hit, rec, st = rf.intersect_bvh(g["grid_rays"][i], a["bvhNodes"], a["bvhPositionAttributes"], 1000.0)
+        assert hit == bool(out["hit"][i]) and st["nodes_visited"] == out["nodesVisited"][i]
+        if hit:
+            assert rec["t"].view(np.uint32) == out["t"][i].view(np.uint32) and rec["triangle"] == out["tri"][i]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_host_query_on_random_soups_and_hostile_rays(seed):
+    """Random triangle soups (degenerate and duplicate triangles included) with axis-parallel, +-0, denormal, NaN and 1e30 rays:
+    host query == oracle on every output bit."""
+    from oracle import orc
+    rng = np.random.default_rng(seed)
+    n = 700
+    P = (rng.standard_normal((n, 3, 3)) * 0.15 + rng.uniform(-2, 2, (n, 1, 3))).astype(np.float32)
+    P[::50, 1] = P[::50, 0]                       # degenerate
+    P[1::60] = P[0:1]                             # duplicates
+    P[::7] = np.round(P[::7] * 4) / 4             # vertices on a lattice: rays through box planes
+    nodes, idx, _ = rf.build_bvh(P.reshape(n, 9))
+    tris = orc.reorder(P.reshape(n, 9), idx)
+    m = 3000
+    rays = np.concatenate([rng.uniform(-3, 3, (m, 3)), rng.standard_normal((m, 3))], axis=1).astype(np.float32)
+    rays[::9, 3] = 0.0; rays[1::9, 4] = -0.0; rays[2::9, 3:5] = 0.0
+    rays[3::97, 5] = 1e-42                        # denormal component
+    rays[4::101, 0] = np.nan; rays[5::103, 3] = np.nan; rays[6::107, 1] = 1e30
+    rays[7::11, :3] = np.round(rays[7::11, :3] * 4) / 4
+    for tmax in (np.float32(1000.0), np.finfo(np.float32).max):
+        out = rf.intersect_bvh_batch(rays, nodes, tris, tmax, threads=2)
+        ref = orc.intersect_bvh_batch(nodes, tris, rays, tmax)
+        assert np.array_equal(out["hit"], ref["hit"]) and np.array_equal(out["nodesVisited"], ref["nodesVisited"])
+        assert np.array_equal(out["triTests"], ref["triTests"]) and np.array_equal(out["stackHigh"], ref["stackHigh"])
+        h = out["hit"] == 1
+        assert h.sum() > 100
+        assert np.array_equal(out["tri"][h], ref["tri"][h]) and np.array_equal(bits(out["t"][h]), bits(ref["t"][h]))
+        assert np.array_equal(bits(out["p"][h]), bits(ref["p"][h])) and np.array_equal(bits(out["uv"][h]), bits(ref["uv"][h]))
+
+
+def test_host_query_rejects_malformed_trees_and_bad_strides(duck_pt):
+    a = duck_pt.arrays()
+    nodes = a["bvhNodes"].copy()
+    ray = np.array([0.1, 0.8, 5.0, 0.0, 0.0, -1.0], np.float32)
+    bad = nodes.copy(); bad[0]["secondChildOffset"] = len(nodes) + 5
+    with pytest.raises(rf.RayfinderError):
+        rf.intersect_bvh(ray, bad, a["bvhPositionAttributes"], 1000.0)
+    bad = nodes.copy(); bad["trianglesOffset"][nodes["triangleCount"] > 0] = len(a["bvhPositionAttributes"])   # every leaf points past the array
+    with pytest.raises(rf.RayfinderError):
+        rf.bvh_visualizer_pass(rf.bvh_visualizer_camera(nodes, 1.0), 64, 64, bad, a["bvhPositionAttributes"])
+    out = np.zeros(1, rf.INTERSECTION_DTYPE); hit = rf._ffi.C.c_int(0)
+    rc = rf.lib.rf_intersect_bvh(ray.ctypes.data, nodes.ctypes.data, len(nodes), a["bvhPositionAttributes"].ctypes.data, 40, len(a["bvhPositionAttributes"]),
+                                 np.float32(1.0), out.ctypes.data, None, rf._ffi.C.byref(hit))
+    assert rc == rf._ffi.RF_ERROR_INVALID_ARGUMENT
+
+
+def test_host_query_deep_chain_needs_no_fixed_stack():
+    """A 200-deep degenerate chain (every far child pending): the reference's 32-entry array would be overrun; the host query's
+    pending list grows (stack high-water 200) and still finds the hit at the bottom."""
+    depth = 200
+    P = np.zeros((depth + 1, 9), np.float32)
+    for i in range(depth + 1):
+        z = np.float32(-1.0 - i)
+        P[i] = [-1, -1, z, 1, -1, z, 0, 1, z]
+    # layout: interiors at 0..depth-1 (node k's first child is k+1), then leaf of the bottom, then the pending leaves
+    nodes = np.zeros(2 * depth + 1, rf.NODE_DTYPE)
+    for k in range(depth):
+        nodes[k]["min"] = [-1, -1, -1.0 - depth]; nodes[k]["max"] = [1, 1, -1.0 - k]
+        nodes[k]["splitAxis"] = 0
+        nodes[k]["secondChildOffset"] = 2 * depth - k
+    def leaf(at, tri):
+        nodes[at]["min"] = [-1, -1, P[tri][2]]; nodes[at]["max"] = [1, 1, P[tri][2]]
+        nodes[at]["trianglesOffset"] = tri; nodes[at]["triangleCount"] = 1; nodes[at]["splitAxis"] = 0xFFFFFFFF
+    leaf(depth, depth)                                         # first child of the last interior node: the farthest triangle
+    for k in range(depth):
+        leaf(2 * depth - k, k)                                 # second child of interior k: the triangle at z = -1-k
+    ray = np.array([0.0, 0.0, 5.0, 1e-3, 1e-3, -1.0], np.float32)   # +x: first child first, every second child pending
+    hit, rec, st = rf.intersect_bvh(ray, nodes, P, np.finfo(np.float32).max)
+    assert hit and st["stack_high_water"] == depth and st["nodes_visited"] == 2 * depth + 1
+    assert rec["triangle"] == 0 and abs(rec["t"] - 6.0) < 1e-2      # the nearest triangle wins in the end
+
+
+def test_cli_bvh_visualizer_cpu_writes_the_reference_grey_map(duck_pt, tmp_path):
+    """rf-bvh-visualizer --cpu (no GPU): the PNG it writes decodes to grey = u32(min(0.01 * nodesVisited, 1) * 255), alpha 255
+    (src/bvh-visualizer/main.cpp:73-84) of the host pass's node-visit map -- at the tool's default 1280 x 720 and at 256 x 256
+    (BASELINE.json config 1), from the .glb and from the .pt file."""
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(ROOT, "rayfinder_amd", "bin", "rf-bvh-visualizer")
+    a = duck_pt.arrays()
+    pt_path = tmp_path / "Duck.pt"
+    duck_pt.save(pt_path)
+    for (w, h, src, args) in ((256, 256, DUCK, ["256", "256"]), (1280, 720, str(pt_path), [])):
+        out = tmp_path / f"viz_{w}.png"
+        r = subprocess.run([exe, "--cpu", "--threads", "2", "--out", str(out), src] + args, capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stderr
+        img = np.array(Image.open(out))
+        assert img.shape == (h, w, 4) and (img[..., 3] == 255).all()
+        cam = rf.bvh_visualizer_camera(a["bvhNodes"], np.float32(np.float32(w) / np.float32(h)))
+        nv = rf.bvh_visualizer_pass(cam, w, h, a["bvhNodes"], a["bvhPositionAttributes"])["nodesVisited"]
+        grey = rf.bvh_visualizer_grey(nv).reshape(h, w)
+        for c in range(3):
+            assert np.array_equal(img[..., c], grey)
+        assert f"{int(nv.sum())} node visits" in r.stdout
+    # the grey formula itself, against the oracle's restatement of main.cpp:73-76
+    from oracle import orc
+    for n in (0, 1, 49, 50, 99, 100, 101, 157, 5000):
+        assert int(rf.bvh_visualizer_grey(np.array([n]))[0]) == orc.lib().orc_bvh_visualizer_pixel(n) & 0xFF

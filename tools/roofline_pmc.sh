@@ -12,7 +12,9 @@ case $OUT in /*) ;; *) OUT=$PWD/$OUT ;; esac     # the passes run from /tmp
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-4}; WARMUP=${WARMUP:-2}
-BENCH="python $REPO/bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-counting"
+# BENCH_ARGS: extra bench.py arguments (e.g. "--scene-scale 8 --spp-per-step 8"); CALIB_FROM: a committed profile directory whose
+# calibration files are reused instead of re-running the microbenchmark (same chip, same rocprofv3)
+BENCH="python $REPO/bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-counting ${BENCH_ARGS:-}"
 CALIB=$REPO/tools/microbench/fetch_calib
 [ -x $CALIB ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $CALIB $REPO/tools/microbench/fetch_calib.hip
 
@@ -38,11 +40,16 @@ pmc() {   # tag, command, counters
 }
 
 # ---- 1. calibration microbenchmark
+if [ -n "${CALIB_FROM:-}" ]; then
+  cp $REPO/$CALIB_FROM/calib_plain.jsonl $REPO/$CALIB_FROM/calib_pmc*_summary.txt $OUT/
+  echo "$CALIB_FROM" > $OUT/calibration_reused_from.txt
+else
 $CALIB > $OUT/calib_plain.jsonl 2> $OUT/calib_plain.err
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1)); pmc calib_pmc$i "$CALIB" "$ctrs"
 done
+fi
 
 # ---- 2. the bench command
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
