@@ -254,6 +254,10 @@ def build_roofline(s, cs, per_bounce, workload):
                     fr["valu"] = share
                 if "l2_hit_rate" in r:
                     row["l2_hit_rate"] = r["l2_hit_rate"]
+                if "hbm_side_bytes_per_ray" in r:
+                    gb = r["hbm_side_bytes_per_ray"] * rays / ms * 1e-6
+                    row.update(hbm_side_bytes_per_ray=r["hbm_side_bytes_per_ray"], hbm_side_GBps=round(gb, 1))
+                    fr["hbm"] = gb / HBM_PEAK_GBPS
                 row["fractions"] = {k: round(v, 3) for k, v in fr.items()}
                 if fr:
                     row["binds"] = max(fr, key=fr.get)

@@ -88,6 +88,8 @@ PY
 perdispatch per_bounce_pmc1 "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE"
 perdispatch per_bounce_pmc2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU"
 perdispatch per_bounce_pmc3 "TCC_HIT_sum TCC_MISS_sum"
+perdispatch per_bounce_pmc4 "FETCH_SIZE"
+perdispatch per_bounce_pmc5 "WRITE_SIZE"
 
 # ---- 3. post-process
 python3 $REPO/tools/roofline_post.py $OUT

@@ -196,7 +196,7 @@ def per_dispatch(path):
 
 
 pb = {}
-for i in (1, 2, 3):
+for i in (1, 2, 3, 4, 5):
     for kind, rows in per_dispatch(os.path.join(out, f"per_bounce_pmc{i}.csv")).items():
         for j, row in enumerate(rows):
             pb.setdefault(kind, {}).setdefault(j, {}).update(row)
@@ -224,6 +224,11 @@ for kind in ("closest", "shadow"):
                 e["salu_instructions_per_ray"] = round(c.get("SQ_INSTS_SALU", 0.0) / rays, 1)
             if "TCC_HIT_sum" in c:
                 e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 3)
+            if "FETCH_SIZE" in c:
+                # fabric-side bytes of THIS launch (random record gathers: the gather calibration), and the rate they moved at
+                e["hbm_side_bytes_per_ray"] = round((fc * c["FETCH_SIZE"] + wc * c.get("WRITE_SIZE", 0.0)) * 1024.0 / rays, 1)
+                if b[f"ms_{kind}"] > 0:
+                    e["hbm_side_GBps"] = round(e["hbm_side_bytes_per_ray"] * rays / (b[f"ms_{kind}"] * 1e-3) / 1e9, 1)
         table.append(e)
 if table:
     per_ray["per_bounce"] = table
