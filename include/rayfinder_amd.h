@@ -169,6 +169,9 @@ RF_API int rf_renderer_set_counting(rf_renderer* r, int enabled);
 RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
 /* Tuning knobs for A/B measurements; none of them changes a result (every combination is covered by the -m gpu parity tests).
  *   traversal_variant 0 | 2            one-ray-per-thread kernels over the 32-byte nodes | persistent kernels over the 64-byte records (default)
+ *   quad_from_bounce, quad_shadow_from_bounce         first bounce whose closest-hit / shadow launch reads the 128-byte quad records (two
+ *                                      levels of the tree per dependent fetch; defaults 1 / 1; 0 = never; takes precedence over the layouts below)
+ *   quad_except_mask, quad_shadow_except_mask         ... except at bounce b when bit b-1 is set (default 0)
  *   compact_from_bounce, compact_shadow_from_bounce   first bounce whose closest-hit / shadow launch reads the compact-capable records
  *                                      (three loads per descending step; defaults 3 / 2; 0 = never)
  *   hot_from_bounce, hot_shadow_from_bounce           the same for the 32-byte records (two loads per step; default 0 = never)
@@ -176,13 +179,13 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *   leaf_vote                          descending lanes below which a wave processes its parked leaves (20)
  *   chunk, chunk_early, chunk_early_bounces   queue entries per cursor claim (128; 256 at bounces 1-2)
  *   shade_sort_from_bounce             first bounce whose shading stage appends each 1024-entry tile's surviving paths in the order of
- *                                      the triangles they hit (default 3; 0 = never: input order)
+ *                                      the triangles they hit (default 2; 0 = never: input order)
  *   uniform_fetch 0 | 1 | 2 | -1       scalar-cache fetch of wave-uniform records (1), and leaf triangles (2, default); -1: bounces 1-2 only
  *   shadow_nearest_first 0 | 1         any-hit child order: the reference's split-axis order | nearer slab entry first (default)
  *   packet_bounces n                   bounces 1..n traced by lockstep wave packets (default 0)
  *   slot_group_shift, sample_sort, accumulate_runs, shade_blocks, reserve_samples, persistent_blocks, extra_lds
  *                                      path-slot order, accumulation kernel, grid sizes, occupancy experiments
- *   query_variant 0 | 2, query_compact 0 | 1 | 2      kernels / record layout behind rf_renderer_intersect_rays / _occluded_rays (tests) */
+ *   query_variant 0 | 2, query_compact 0 | 1 | 2 | 3  kernels / record layout behind rf_renderer_intersect_rays / _occluded_rays (tests) */
 RF_API int rf_renderer_set_option(rf_renderer* r, const char* name, int64_t value);
 RF_API int rf_renderer_reset_stats(rf_renderer* r);
 RF_API int rf_renderer_get_stats(rf_renderer* r, rf_stats* out);

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 {
     constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
     constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
-    static_assert(!(COMPACT != 0 && COUNT), "the compact-record variants have no counting build");
+    static_assert(!(COMPACT != 0 && COUNT), "the compact-record and quad-record variants have no counting build");
     __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
@@ -840,6 +840,102 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             if (static_cast<int32_t>(node) >= 0)
             {
                 if (COUNT) ++recordFetches;
+                if constexpr (COMPACT == 3)
+                {
+                    // ---- quad records (rf_wide.hpp): the boxes of the node's (up to) four grandchildren in ONE 128-byte record --
+                    // two levels of the reference's tree per dependent fetch.  Entries 0,1 belong to the first child, 2,3 to the
+                    // second; an entry passes iff P(entry) && tmin(entry) < rayTMax, which implies the same for the skipped child.
+                    float    tq0, tq1, tq2, tq3;
+                    bool     okq0, okq1, okq2, okq3, hasNaN = false;
+                    uint32_t w0, w1, w2, w3;
+                    const auto quadStep = [&](float4 a0, float4 a1, float4 a2, float4 a3, float4 a4, float4 a5) {
+                        float f0, f1, f2, f3;
+                        slabPairBounds(pr, a0, a1, a2, tq0, f0, tq1, f1);
+                        slabPairBounds(pr, a3, a4, a5, tq2, f2, tq3, f3);
+                        asm volatile("" : "+v"(tq0), "+v"(f0), "+v"(tq1), "+v"(f1), "+v"(tq2), "+v"(f2), "+v"(tq3), "+v"(f3)); // (min/max chains stay with their products: see slabStep)
+                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2) || slabPairHasNaN(pr, a3, a4, a5);
+                        okq0 = tq0 <= f0 && f0 > 0.0f;
+                        okq1 = tq1 <= f1 && f1 > 0.0f;
+                        okq2 = tq2 <= f2 && f2 > 0.0f;
+                        okq3 = tq3 <= f3 && f3 > 0.0f;
+                    };
+                    const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
+                    if (uniformFetch && __ballot(node != uNode) == 0ull)
+                    {
+                        typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                        const float4* un = wide.quad + 8 * static_cast<size_t>(uNode);
+                        u16v          a;
+                        u8v           b;
+                        u4v           c;
+                        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&s"(a), "=&s"(b), "=&s"(c)
+                                     : "s"(un)
+                                     : "memory");
+                        const auto f4 = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w)); };
+                        quadStep(f4(a.s0, a.s1, a.s2, a.s3), f4(a.s4, a.s5, a.s6, a.s7), f4(a.s8, a.s9, a.sa, a.sb), f4(a.sc, a.sd, a.se, a.sf), f4(b.s0, b.s1, b.s2, b.s3),
+                                 f4(b.s4, b.s5, b.s6, b.s7));
+                        w0 = c.x, w1 = c.y, w2 = c.z, w3 = c.w;
+                    }
+                    else
+                    {
+                        const float4* n = wide.quad + 8 * static_cast<size_t>(node);
+                        const float4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3], v4 = n[4], v5 = n[5], v6 = n[6];
+                        w0 = __float_as_uint(v6.x), w1 = __float_as_uint(v6.y), w2 = __float_as_uint(v6.z), w3 = __float_as_uint(v6.w);
+                        quadStep(v0, v1, v2, v3, v4, v5);
+                    }
+                    if (__builtin_expect(hasNaN, 0))
+                    {
+                        // class B ray: a 0 * inf product means the packed test is not the reference's here
+                        needScalar = true;
+                        okq0 = okq1 = okq2 = okq3 = false;
+                        stackSize = 0; // -> popNext() ends the ray; it is redone below
+                    }
+                    const uint32_t axN = (w0 >> kWideAxisShift) & 3u, axA = (w1 >> kWideAxisShift) & 3u, axB = (w3 >> kWideAxisShift) & 3u;
+                    const bool     h0 = okq0 && tq0 < rayTMax, h1 = okq1 && tq1 < rayTMax && w1 != kQuadEmpty, h2 = okq2 && tq2 < rayTMax,
+                                   h3 = okq3 && tq3 < rayTMax && w3 != kQuadEmpty;
+                    constexpr uint32_t kAxisMask = ~(3u << kWideAxisShift);
+                    // an entry that cannot be hit any more carries kQuadEmpty from here on
+                    const uint32_t e0 = h0 ? (w0 & kAxisMask) : kQuadEmpty, e1 = h1 ? (w1 & kAxisMask) : kQuadEmpty, e2 = h2 ? w2 : kQuadEmpty, e3 = h3 ? (w3 & kAxisMask) : kQuadEmpty;
+                    // visit order.  Closest hit: the reference's -- inside each child by dirNeg[the child's split axis], the two children by
+                    // dirNeg[the node's] (wgsl:409-417 applied at both levels).  Any hit: nearer slab entry first at both levels (the
+                    // visibility bit does not depend on the order: see NEAREST_FIRST above).
+                    bool swapA, swapB, swapN;
+                    if (NEAREST_FIRST)
+                    {
+                        const float inf = __uint_as_float(0x7F800000u);
+                        const float k0 = h0 ? tq0 : inf, k1 = h1 ? tq1 : inf, k2 = h2 ? tq2 : inf, k3 = h3 ? tq3 : inf;
+                        swapA = k1 < k0, swapB = k3 < k2;
+                        swapN = __builtin_fminf(k2, k3) < __builtin_fminf(k0, k1);
+                    }
+                    else
+                    {
+                        swapA = ((negMask >> axA) & 1u) != 0u, swapB = ((negMask >> axB) & 1u) != 0u, swapN = ((negMask >> axN) & 1u) != 0u;
+                    }
+                    const uint32_t a0w = swapA ? e1 : e0, a1w = swapA ? e0 : e1, b0w = swapB ? e3 : e2, b1w = swapB ? e2 : e3;
+                    const float    a0t = swapA ? tq1 : tq0, a1t = swapA ? tq0 : tq1, b0t = swapB ? tq3 : tq2, b1t = swapB ? tq2 : tq3;
+                    const uint32_t s0w = swapN ? b0w : a0w, s1w = swapN ? b1w : a1w, s2w = swapN ? a0w : b0w, s3w = swapN ? a1w : b1w;
+                    const float    s1t = swapN ? b1t : a1t, s2t = swapN ? a0t : b0t, s3t = swapN ? a1t : b1t;
+                    const bool     x0 = s0w != kQuadEmpty, x1 = s1w != kQuadEmpty, x2 = s2w != kQuadEmpty, x3 = s3w != kQuadEmpty;
+                    if (x0 || x1 || x2 || x3)
+                    {
+                        // enter the first entry that can be hit; the later ones wait on the stack with their tmin, last first
+                        bool pushed = true;
+                        if (x3 && (x0 || x1 || x2)) pushed = push(s3w, s3t);
+                        if (x2 && (x0 || x1)) pushed = push(s2w, s2t) && pushed;
+                        if (x1 && x0) pushed = push(s1w, s1t) && pushed;
+                        node = x0 ? s0w : (x1 ? s1w : (x2 ? s2w : s3w));
+                        if (!pushed)
+                        {
+                            needScalar = true;
+                            node = kNodeDone;
+                        }
+                    }
+                    else popNext();
+                }
+                else
+                {
                 uint2 words;
                 float t0, t1;
                 bool  ok0, ok1, hasNaN = false;
@@ -1091,6 +1187,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                         }
                     }
                     else popNext();
+                }
                 }
             }
         } while (__popcll(__ballot(static_cast<int32_t>(node) >= 0)) >= leafVote);
@@ -1900,7 +1997,7 @@ struct Renderer::Impl
     int         device = 0;
     hipStream_t stream = nullptr;
 
-    DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact, wideHot, wideOwn;
+    DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact, wideHot, wideOwn, wideQuad;
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
     DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
@@ -1949,7 +2046,7 @@ struct Renderer::Impl
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
-    uint32_t optShadeSortFromBounce = 3, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
+    uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
     uint32_t optRefillMinDeep = 22, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at 22 idle lanes
     // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
@@ -1959,6 +2056,8 @@ struct Renderer::Impl
     bool                   optSampleSort = true, optAccumulateRuns = true;
     uint32_t               optCompactFromBounce = 3;       // closest-hit launches of bounce >= this use the compact-capable records (0: never)
     uint32_t               optCompactShadowFromBounce = 2; // ... and the shadow launches of bounce >= this
+    uint32_t               optQuadFromBounce = 1, optQuadShadowFromBounce = 1; // the 128-byte quad records (two levels per fetch) from this bounce on (0: never); takes precedence over the others
+    uint32_t               optQuadExceptMask = 0, optQuadShadowExceptMask = 0; // ... except at the bounces whose bit (bounce - 1) is set here
     uint32_t               optHotFromBounce = 0, optHotShadowFromBounce = 0; // the 32-byte records (all six planes carried) from this bounce on (0: never); takes precedence
     int                    optQueryCompact = 0;            // the ray-query entry points use the compact-capable (1) / 32-byte (2) records too (tests)
     uint32_t               optExtraLds = 0;      // experiment: dynamic LDS bytes added to the kTraceWide launches (lowers the occupancy)
@@ -2174,7 +2273,13 @@ struct Renderer::Impl
             RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
             RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
-            if (shadowNearestFirst && optQueryCompact == 2 && wide.hot != nullptr)
+            if (shadowNearestFirst && optQueryCompact == 3 && wide.quad != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (optQueryCompact == 3 && wide.quad != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, false, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (shadowNearestFirst && optQueryCompact == 2 && wide.hot != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
             else if (shadowNearestFirst && optQueryCompact == 1 && wide.compact != nullptr)
@@ -2189,7 +2294,10 @@ struct Renderer::Impl
         }
         else
         {
-            if (optQueryCompact == 2 && wide.hot != nullptr)
+            if (optQueryCompact == 3 && wide.quad != nullptr)
+                hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+            else if (optQueryCompact == 2 && wide.hot != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
             else if (optQueryCompact == 1 && wide.compact != nullptr)
@@ -2294,6 +2402,9 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (bounce <= optPacketBounces)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
+                else if (wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
+                    hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (wide.hot != nullptr && optHotFromBounce != 0u && bounce >= optHotFromBounce)
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
@@ -2331,6 +2442,9 @@ struct Renderer::Impl
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+                    else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce)
                         hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
@@ -2419,6 +2533,12 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             m.wideOwn.upload(wb.own.data(), wb.own.size());
             m.wide.hot = m.wideHot.ptr;
             m.wide.own = m.wideOwn.ptr;
+        }
+        m.wide.quad = nullptr;
+        if (wb.quadUsable && !wb.quad.empty())
+        {
+            m.wideQuad.upload(wb.quad.data(), wb.quad.size());
+            m.wide.quad = m.wideQuad.ptr;
         }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
@@ -2838,6 +2958,10 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "compact_from_bounce") mImpl->optCompactFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "compact_shadow_from_bounce") mImpl->optCompactShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "query_compact") mImpl->optQueryCompact = static_cast<int>(value);
+    else if (name == "quad_from_bounce") mImpl->optQuadFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "quad_shadow_from_bounce") mImpl->optQuadShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "quad_except_mask") mImpl->optQuadExceptMask = static_cast<uint32_t>(value);
+    else if (name == "quad_shadow_except_mask") mImpl->optQuadShadowExceptMask = static_cast<uint32_t>(value);
     else if (name == "hot_from_bounce") mImpl->optHotFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "hot_shadow_from_bounce") mImpl->optHotShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "packet_bounces") mImpl->optPacketBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
@@ -3025,9 +3149,75 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes)
 {
     if (nodes.empty()) throw std::runtime_error("checkWideLayouts: no nodes");
     const WideBuild wb = buildWide(nodes.data(), nodes.size());
-    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u);
+    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u) | (!wb.quad.empty() ? 8u : 0u);
     const size_t    records = wb.nodes.size() / 4;
     const auto      fail = [](size_t r, const char* what) { throw std::runtime_error("wide layout mismatch at record " + std::to_string(r) + ": " + what); };
+    if (!wb.quad.empty())
+    {
+        // Walk the quad records from the root next to the 64-byte records: the entries of a quad record must be the children of
+        // the children the plain record of the same node names (a leaf child filling one slot), with the same leaf words, the
+        // split axes of both levels, and the skipped child's box must be the union of its entries (what makes the skip exact).
+        struct Pair
+        {
+            uint32_t plain, quad;
+        };
+        std::vector<Pair> todo{{0u, 0u}};
+        size_t            visited = 0;
+        while (!todo.empty())
+        {
+            const Pair at = todo.back();
+            todo.pop_back();
+            ++visited;
+            if (at.plain >= records || 8 * static_cast<size_t>(at.quad) + 8 > wb.quad.size()) fail(at.plain, "quad record index out of range");
+            const float4*  w = &wb.nodes[4 * static_cast<size_t>(at.plain)];
+            const float4*  q = &wb.quad[8 * static_cast<size_t>(at.quad)];
+            const uint32_t qw[4] = {floatBits(q[6].x), floatBits(q[6].y), floatBits(q[6].z), floatBits(q[6].w)};
+            const uint32_t pw[2] = {floatBits(w[3].x) & ~(3u << kWideAxisShift), floatBits(w[3].y)};
+            if (((qw[0] >> kWideAxisShift) & 3u) != ((floatBits(w[3].x) >> kWideAxisShift) & 3u)) fail(at.plain, "quad record: split axis of the node differs");
+            const float cbox[2][6] = {{w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y}, {w[2].x, w[2].y, w[2].z, w[2].w, w[1].z, w[1].w}};
+            for (int k = 0; k < 2; ++k)
+            {
+                const float4*  e = q + 3 * k;
+                const float    b0[6] = {e[0].x, e[0].y, e[0].z, e[0].w, e[1].x, e[1].y}, b1[6] = {e[2].x, e[2].y, e[2].z, e[2].w, e[1].z, e[1].w};
+                const uint32_t wa = qw[2 * k], wb2 = qw[2 * k + 1];
+                if (pw[k] & kWideLeafBit)
+                {
+                    // a leaf child fills slot 2k with itself
+                    if ((wa & ~(3u << kWideAxisShift)) != pw[k] || wb2 != kQuadEmpty) fail(at.plain, "quad record: leaf child not passed through");
+                    for (int j = 0; j < 6; ++j)
+                        if (!(b0[j] == cbox[k][j])) fail(at.plain, "quad record: leaf child's box differs");
+                    continue;
+                }
+                const float4*  cw = &wb.nodes[4 * static_cast<size_t>(pw[k])]; // the child's own plain record = its children
+                const float    g0[6] = {cw[0].x, cw[0].y, cw[0].z, cw[0].w, cw[1].x, cw[1].y}, g1[6] = {cw[2].x, cw[2].y, cw[2].z, cw[2].w, cw[1].z, cw[1].w};
+                const uint32_t gw[2] = {floatBits(cw[3].x) & ~(3u << kWideAxisShift), floatBits(cw[3].y)};
+                const uint32_t childAxis = (floatBits(cw[3].x) >> kWideAxisShift) & 3u;
+                for (int j = 0; j < 6; ++j)
+                {
+                    if (!(b0[j] == g0[j]) || !(b1[j] == g1[j])) fail(at.plain, "quad record: grandchild box differs");
+                    const float u = (j == 0 || j == 1 || j == 4) ? std::min(g0[j], g1[j]) : std::max(g0[j], g1[j]);
+                    if (!(u == cbox[k][j])) fail(at.plain, "quad record: skipped child's box is not the union of its children's");
+                }
+                const uint32_t tagged = k == 0 ? wb2 : wb2; // slot 2k+1 carries the child's split axis
+                if (((tagged >> kWideAxisShift) & 3u) != childAxis) fail(at.plain, "quad record: split axis of a child differs");
+                const uint32_t ea = k == 0 ? (wa & ~(3u << kWideAxisShift)) : wa, eb = wb2 & ~(3u << kWideAxisShift);
+                const uint32_t ent[2] = {ea, eb};
+                for (int j = 0; j < 2; ++j)
+                {
+                    if (gw[j] & kWideLeafBit)
+                    {
+                        if (ent[j] != gw[j]) fail(at.plain, "quad record: grandchild leaf word differs");
+                    }
+                    else
+                    {
+                        if (ent[j] & kWideLeafBit) fail(at.plain, "quad record: interior grandchild encoded as a leaf");
+                        todo.push_back(Pair{gw[j], ent[j]});
+                    }
+                }
+            }
+        }
+        if (visited != wb.quad.size() / 8) fail(0, "quad records: not every record is reachable from the root exactly once");
+    }
     for (size_t r = 0; r < records; ++r)
     {
         const float4* w = &wb.nodes[4 * r];

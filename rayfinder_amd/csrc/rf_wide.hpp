@@ -41,6 +41,7 @@ constexpr uint32_t kWideLeafBit = 0x80000000u;
 constexpr uint32_t kWideIndexBits = 26;  // record / first-triangle / big-leaf index
 constexpr uint32_t kWideAxisShift = 29;  // bits 30..29 of the FIRST child word carry the node's split axis
 constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is interior
+constexpr uint32_t kQuadEmpty = 0xFFFFFFFFu; // quad records: an entry slot that holds no node (its child is a leaf and fills one slot only)
 #if defined(RF_EXP_WAVES)
 constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment builds: resident workgroups per CU of kTraceWide
 constexpr int      kWideLdsStack = 160 * 1024 / RF_EXP_WAVES / 2048; // as deep as the LDS allows at that occupancy (7: 11, 8: 10)
@@ -56,6 +57,7 @@ struct WideScene
     const float4* compact;   // the same records in the compact-capable layout (see buildWide), or nullptr
     const float4* hot;       // 2 float4 per interior node: the 32-byte records of the all-planes-carried layout (see buildWide), or nullptr
     const float4* own;       // 2 float4 per interior node: the node's own box {lo.x lo.y hi.x hi.y} {lo.z hi.z - -} (read after a pop only)
+    const float4* quad;      // 8 float4 per quad record: TWO levels in one 128-byte record (see buildWide), or nullptr
     const uint2*  bigLeaves; // {first triangle, count}
     float4        rootLo;    // root box (w unused)
     float4        rootHi;
@@ -70,6 +72,25 @@ struct WideBuild
     bool                compactUsable = true; // every node's x planes are attained by one of its children (true for boxes built as unions)
     std::vector<float4> hot, own;      // the 32-byte layout (all six planes carried) and the nodes' own boxes; empty when !hotUsable
     bool                hotUsable = true; // every plane of every node is attained by a child AND every index fits 24 bits
+    // Quad records (kTraceWide<..., COMPACT = 3>): one 128-byte record per interior node at an EVEN level below the root holds the
+    // boxes of the node's (up to four) GRANDCHILDREN -- a child that is a leaf fills one slot with itself -- i.e. two levels of
+    // the reference's tree per dependent fetch:
+    //     {E0.lo.xy E0.hi.xy | E0.lo.z E0.hi.z E1.lo.z E1.hi.z | E1.lo.xy E1.hi.xy |     entries of the FIRST child  (node + 1)
+    //      E2.lo.xy E2.hi.xy | E2.lo.z E2.hi.z E3.lo.z E3.hi.z | E3.lo.xy E3.hi.xy |     entries of the SECOND child (secondChildOffset)
+    //      word0 word1 word2 word3 | - - - -}
+    // word k: child word of entry k (leaf descriptor as in the 64-byte records, or the index of the entry's own quad record);
+    // kQuadEmpty in slots 1 / 3 when the child is a leaf.  Bits 30..29 carry split axes: word0 the node's, word1 the first
+    // child's, word3 the second child's.
+    // Decision-identical to the reference for the render path.  The reference visits a child c iff P(c) && tmin(c) < rayTMax
+    // and then its children g under the same test; boxes are unions, so every plane of c is a plane of one of its children,
+    // t = (plane - o) * inv is monotone in the plane under rounding, hence per axis the slab interval of g lies inside that of
+    // c:  P(g) => P(c)  and  tmin(c) <= tmin(g).  So "g passes" already implies "c passes" (with the same rayTMax: no triangle
+    // is tested between c's visit and its children's tests), a child none of whose children pass contributes no triangle test,
+    // and the entries in the order [near child's near, far | far child's near, far] (each level by dirNeg[its own split axis])
+    // with the later ones pushed together with their tmin and re-tested against rayTMax when popped are exactly the leaves /
+    // subtrees the reference enters, in its order.  Not for the counting build (nodesVisited counts the skipped level).
+    std::vector<float4> quad;
+    bool                quadUsable = true; // every plane of every interior node is attained by one of its children (unions), indices fit
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
@@ -85,13 +106,19 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
     for (size_t i = 0; i < count; ++i)
         if (nodes[i].triangleCount == 0) wideIndex[i] = numInterior++;
     if (numInterior >= (1u << kWideIndexBits)) out.boxesRegular = false; // index field too narrow: not usable
-    auto childWord = [&](size_t idx) -> uint32_t {
+    std::vector<uint32_t> bigLeafOf; // per node: index into bigLeaves + 1 (0: none yet), so that every layout names the same table entry
+    auto leafWord = [&](size_t idx) -> uint32_t {
         const BvhNode& n = nodes[idx];
-        if (n.triangleCount == 0) return wideIndex[idx];
         if (n.triangleCount <= 7 && n.trianglesOffset < (1u << kWideIndexBits)) return kWideLeafBit | ((n.triangleCount - 1) << kWideIndexBits) | n.trianglesOffset;
-        out.bigLeaves.push_back(make_uint2(n.trianglesOffset, n.triangleCount));
-        return kWideLeafBit | (7u << kWideIndexBits) | static_cast<uint32_t>(out.bigLeaves.size() - 1);
+        if (bigLeafOf.empty()) bigLeafOf.assign(count, 0u);
+        if (bigLeafOf[idx] == 0u)
+        {
+            out.bigLeaves.push_back(make_uint2(n.trianglesOffset, n.triangleCount));
+            bigLeafOf[idx] = static_cast<uint32_t>(out.bigLeaves.size());
+        }
+        return kWideLeafBit | (7u << kWideIndexBits) | (bigLeafOf[idx] - 1u);
     };
+    auto childWord = [&](size_t idx) -> uint32_t { return nodes[idx].triangleCount == 0 ? wideIndex[idx] : leafWord(idx); };
     out.rootLo = make_float4(nodes[0].aabb.min.x, nodes[0].aabb.min.y, nodes[0].aabb.min.z, 0.0f);
     out.rootHi = make_float4(nodes[0].aabb.max.x, nodes[0].aabb.max.y, nodes[0].aabb.max.z, 0.0f);
     if (nodes[0].triangleCount > 0) out.rootLeaf = childWord(0);
@@ -176,7 +203,83 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         for (int k = 0; k < 6; ++k)
             if (!(std::fabs(lo[k]) < 1e30f && std::fabs(hi[k]) < 1e30f && lo[k] <= hi[k])) out.boxesRegular = false;
     }
+    // ---- quad records: the interior nodes reachable from the root in steps of two levels, numbered in node (= depth-first) order
+    if (numInterior > 0 && out.boxesRegular)
+    {
+        std::vector<uint32_t> quadIndex(count, kQuadEmpty);
+        {
+            std::vector<uint8_t>  member(count, 0);
+            std::vector<uint32_t> todo{0u};
+            while (!todo.empty())
+            {
+                const uint32_t i = todo.back();
+                todo.pop_back();
+                member[i] = 1;
+                for (const size_t c : {static_cast<size_t>(i) + 1, static_cast<size_t>(nodes[i].secondChildOffset)})
+                    if (nodes[c].triangleCount == 0)
+                        for (const size_t g : {c + 1, static_cast<size_t>(nodes[c].secondChildOffset)})
+                            if (nodes[g].triangleCount == 0) todo.push_back(static_cast<uint32_t>(g));
+            }
+            uint32_t numQuad = 0;
+            for (size_t i = 0; i < count; ++i)
+                if (member[i]) quadIndex[i] = numQuad++;
+            out.quad.assign(8 * static_cast<size_t>(numQuad), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        }
+        struct Entry
+        {
+            Aabb     box;
+            uint32_t word;
+        };
+        const auto attained = [&](const BvhNode& n) { // every plane of an interior node's box is a plane of one of its children
+            const BvhNode &a = nodes[(&n - nodes) + 1], &b = nodes[n.secondChildOffset];
+            return (a.aabb.min.x == n.aabb.min.x || b.aabb.min.x == n.aabb.min.x) && (a.aabb.min.y == n.aabb.min.y || b.aabb.min.y == n.aabb.min.y) &&
+                   (a.aabb.min.z == n.aabb.min.z || b.aabb.min.z == n.aabb.min.z) && (a.aabb.max.x == n.aabb.max.x || b.aabb.max.x == n.aabb.max.x) &&
+                   (a.aabb.max.y == n.aabb.max.y || b.aabb.max.y == n.aabb.max.y) && (a.aabb.max.z == n.aabb.max.z || b.aabb.max.z == n.aabb.max.z);
+        };
+        for (size_t i = 0; i < count; ++i)
+        {
+            if (quadIndex[i] == kQuadEmpty) continue;
+            const BvhNode& n = nodes[i];
+            Entry          e[4];
+            uint32_t       axes[2] = {0u, 0u};
+            const size_t   kids[2] = {i + 1, n.secondChildOffset};
+            for (int k = 0; k < 2; ++k)
+            {
+                const BvhNode& c = nodes[kids[k]];
+                if (c.triangleCount > 0)
+                {
+                    e[2 * k] = Entry{c.aabb, leafWord(kids[k])};
+                    e[2 * k + 1] = Entry{Aabb{vec3(0.0f, 0.0f, 0.0f), 0.0f, vec3(0.0f, 0.0f, 0.0f), 0.0f}, kQuadEmpty};
+                }
+                else
+                {
+                    if (!attained(c)) out.quadUsable = false; // the skipped level must be implied by its children's tests
+                    axes[k] = c.splitAxis & 3u;
+                    const size_t g[2] = {kids[k] + 1, c.secondChildOffset};
+                    for (int j = 0; j < 2; ++j)
+                    {
+                        const BvhNode& gn = nodes[g[j]];
+                        const uint32_t w = gn.triangleCount > 0 ? leafWord(g[j]) : quadIndex[g[j]];
+                        if (gn.triangleCount == 0 && w >= (1u << kWideIndexBits)) out.quadUsable = false;
+                        e[2 * k + j] = Entry{gn.aabb, w};
+                    }
+                }
+            }
+            float4* q = &out.quad[8 * static_cast<size_t>(quadIndex[i])];
+            for (int k = 0; k < 2; ++k)
+            {
+                const Aabb &a = e[2 * k].box, &b = e[2 * k + 1].box;
+                q[3 * k] = make_float4(a.min.x, a.min.y, a.max.x, a.max.y);
+                q[3 * k + 1] = make_float4(a.min.z, a.max.z, b.min.z, b.max.z);
+                q[3 * k + 2] = make_float4(b.min.x, b.min.y, b.max.x, b.max.y);
+            }
+            const auto tag = [](uint32_t word, uint32_t axis) { return word == kQuadEmpty ? word : (word | (axis << kWideAxisShift)); };
+            q[6] = make_float4(bitsFloat(tag(e[0].word, n.splitAxis & 3u)), bitsFloat(tag(e[1].word, axes[0])), bitsFloat(e[2].word), bitsFloat(tag(e[3].word, axes[1])));
+        }
+    }
     if (out.bigLeaves.empty()) out.bigLeaves.push_back(make_uint2(0, 0));
+    if (!out.boxesRegular || numInterior == 0) out.quadUsable = false;
+    if (!out.quadUsable) out.quad.clear();
     if (!out.boxesRegular) out.compactUsable = false;
     if (!out.compactUsable || numInterior == 0) out.compact.clear();
     if (!out.boxesRegular) out.hotUsable = false;

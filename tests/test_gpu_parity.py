@@ -157,7 +157,7 @@ def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tm
     # step; 2: 32-byte records, two loads, all six planes carried): the same planes and products, so the same bits on the same
     # hostile rays
     r.set_option("shadow_nearest_first", 1)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):                                # (3: the 128-byte quad records, two levels of the tree per fetch)
         r.set_option("query_compact", mode)
         gpu_c = r.intersect_rays(rays, tmax)
         assert np.array_equal(gpu_c["hit"], cpu["hit"]) and np.array_equal(gpu_c["tri"], cpu["tri"]), mode
@@ -654,7 +654,10 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
     sky = rf.make_sky(turbidity=float(rng.uniform(1, 10)), albedo=tuple(rng.uniform(0, 1, 3)), sun_zenith_degrees=float(rng.uniform(0, 89)),
                       sun_azimuth_degrees=float(rng.uniform(0, 360)))
     r, params = _renderer(pt, W, H, spp, bounces, cam=cam, sky=sky, exposure=0.5)
-    if seed % 3 == 1:                                           # every launch on the compact-capable records (default: the deeper bounces only)
+    if seed % 4 != 2:                                           # (default since round 3: the quad records at every bounce)
+        r.set_option("quad_from_bounce", 0 if seed % 4 != 1 else 3)
+        r.set_option("quad_shadow_from_bounce", 0 if seed % 4 != 3 else 2)
+    if seed % 3 == 1:                                           # every launch on the compact-capable records (without quad records: the deeper bounces only)
         r.set_option("compact_from_bounce", 1)
         r.set_option("compact_shadow_from_bounce", 1)
     if seed % 4 == 3:                                           # kShade appends each tile's hits in triangle order
@@ -905,11 +908,13 @@ def test_slot_order_batching_and_accumulation_variants_give_identical_images(duc
     cam = rf.fly_camera(W, H)
     rp = orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.25, rf.aligned_sky_state(rf.make_sky()))
     ref, _ = orc.render(duck_oracle.scene, rp, 0, spp)
+    NQ = dict(quad_from_bounce=0, quad_shadow_from_bounce=0)      # without the quad records (the default since round 3) the other layouts run
     variants = [dict(), dict(slot_group_shift=-1), dict(slot_group_shift=2), dict(slot_group_shift=6, sample_sort=0), dict(sample_sort=0),
                 dict(accumulate_runs=0), dict(shade_blocks=7), dict(slot_group_shift=10, accumulate_runs=0),
-                dict(compact_from_bounce=0, compact_shadow_from_bounce=0), dict(compact_from_bounce=1, compact_shadow_from_bounce=1),
-                dict(compact_from_bounce=1, compact_shadow_from_bounce=1, uniform_fetch=0),
-                dict(hot_from_bounce=1, hot_shadow_from_bounce=1), dict(hot_from_bounce=2, hot_shadow_from_bounce=1, uniform_fetch=0),
+                dict(NQ, compact_from_bounce=0, compact_shadow_from_bounce=0), dict(NQ, compact_from_bounce=1, compact_shadow_from_bounce=1),
+                dict(NQ, compact_from_bounce=1, compact_shadow_from_bounce=1, uniform_fetch=0), dict(NQ),
+                dict(NQ, hot_from_bounce=1, hot_shadow_from_bounce=1), dict(NQ, hot_from_bounce=2, hot_shadow_from_bounce=1, uniform_fetch=0),
+                dict(quad_from_bounce=2, quad_shadow_from_bounce=1, uniform_fetch=0), dict(quad_from_bounce=1, quad_shadow_from_bounce=3, quad_except_mask=2, quad_shadow_except_mask=8),
                 dict(shade_sort_from_bounce=1), dict(shade_sort_from_bounce=2, shade_blocks=5), dict(shade_sort_from_bounce=0)]
     for opts in variants:
         for max_paths in (0, 5 * 15 * 1024):                  # default batch (all 23 samples at once) / 5 samples per batch -> 5, 5, 5, 4, 4

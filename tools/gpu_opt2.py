@@ -10,7 +10,8 @@ from rayfinder_amd import scenes
 spp = int(sys.argv[1]); variants = sys.argv[2:] or ["-"]
 defaults = dict(kv.split("=") for kv in os.environ.get("RF_OPT_DEFAULTS", "").split(",") if kv)
 rounds = 3
-pt, info = scenes.atrium()
+if int(os.environ.get("RF_SCENE_SCALE", 1)) > 1: rf.set_bake_bvh_builder(0)      # GPU builder: same node bytes, 40x faster at that size
+pt, info = scenes.atrium(scale=int(os.environ.get("RF_SCENE_SCALE", 1)))
 W, H, b = int(os.environ.get("RF_W", 1920)), int(os.environ.get("RF_H", 1080)), int(os.environ.get("RF_B", 8))
 cam = rf.fly_camera(W, H)
 r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, b, rf.make_sky(), 0.25), pt.scene())
