@@ -401,10 +401,13 @@ ORC_API int orc_ray_intersect_triangle(const float* ro, const float* rd, const f
 }
 
 /* The reference's stack is 32 entries with no overflow handling (ray_intersection.cpp:148,194 has
- * only a debug assert; wgsl:327,375 has none).  Documented choice: the oracle keeps a 64-entry
- * stack so deeper trees stay well defined, and reports the high-water mark so tests can assert
- * it stays < 32 on the scenes used (where the behaviours coincide). */
-#define ORC_STACK 64
+ * only a debug assert; wgsl:327,375 has none).  Documented choice, the same as the product's
+ * (rf_device.hpp: kLdsStack + kSpillStack = 96): a 96-entry stack so deeper trees stay well
+ * defined; a ray that would need a 97th pending node is ABANDONED with what it has found so far
+ * (closest hit: the nearest hit up to there; any hit: unoccluded) and reports stackHigh =
+ * ORC_STACK + 1.  The high-water mark is reported so tests can assert it stays < 32 on the scenes
+ * used (where all behaviours coincide). */
+#define ORC_STACK 96
 
 typedef struct {
     uint32_t nodesVisited, triTests, stackHigh;
@@ -444,6 +447,7 @@ static int ray_intersect_bvh(v3 ro, v3 rd, const OrcBvhNode* nodes, const float*
                 if (toVisitOffset == 0) break;
                 currentNodeIdx = nodesToVisit[--toVisitOffset];
             } else {
+                if (toVisitOffset == ORC_STACK) { stackHigh = ORC_STACK + 1; break; } /* abandoned (see ORC_STACK) */
                 if (it.dirNeg[node->splitAxis]) {
                     nodesToVisit[toVisitOffset++] = currentNodeIdx + 1;
                     currentNodeIdx = node->secondChildOffset;
@@ -452,7 +456,6 @@ static int ray_intersect_bvh(v3 ro, v3 rd, const OrcBvhNode* nodes, const float*
                     currentNodeIdx = currentNodeIdx + 1;
                 }
                 if (toVisitOffset > stackHigh) stackHigh = (uint32_t)toVisitOffset;
-                if (toVisitOffset >= ORC_STACK) abort();
             }
         } else {
             if (toVisitOffset == 0) break;
@@ -487,6 +490,7 @@ static float shadow_ray(v3 ro, v3 rd, const OrcBvhNode* nodes, const float* tris
                 if (toVisitOffset == 0) break;
                 currentNodeIdx = nodesToVisit[--toVisitOffset];
             } else {
+                if (toVisitOffset == ORC_STACK) break; /* abandoned (see ORC_STACK): counts as unoccluded */
                 if (it.dirNeg[node->splitAxis]) {
                     nodesToVisit[toVisitOffset++] = currentNodeIdx + 1;
                     currentNodeIdx = node->secondChildOffset;
@@ -494,7 +498,6 @@ static float shadow_ray(v3 ro, v3 rd, const OrcBvhNode* nodes, const float* tris
                     nodesToVisit[toVisitOffset++] = node->secondChildOffset;
                     currentNodeIdx = currentNodeIdx + 1;
                 }
-                if (toVisitOffset >= ORC_STACK) abort();
             }
         } else {
             if (toVisitOffset == 0) break;

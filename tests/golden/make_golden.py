@@ -12,6 +12,7 @@ reference-compiled sky model under oracle/_ref; everything else comes from the o
                   compiled unmodified (against a glm stand-in) by the survey session.
   duck_render_golden.npz  oracle radiance for a few 16x16 crops of config 2 (Duck.pt, 800x600,
                   default camera/sky) at 8 spp / 4 bounces, f32 sums.
+  duck_render_golden_64spp.npz  the same at config 2's FULL sample count (64 spp): two 16x16 crops.
 """
 import hashlib
 import os
@@ -97,7 +98,22 @@ def duck_render():
                         width=W, height=H, spp=spp, bounces=bounces)
 
 
+def duck_render64():
+    m, P, nodes, idx, depth, tris, pa, va, descs, texels = duck_scene()
+    sc = orc.OracleScene(nodes, pa, va, descs, texels)
+    W, H, spp, bounces = 800, 600, 64, 4          # BASELINE.json config 2
+    rp = orc.make_render_params(W, H, orc.default_pt_camera(W, H), spp, bounces, 0.25, orc.aligned_sky_state())
+    crops = [(392, 292), (300, 200)]
+    out = []
+    for (x0, y0) in crops:
+        img, st = orc.render(sc, rp, 0, spp, x0, y0, x0 + 16, y0 + 16)
+        out.append(img[y0:y0 + 16, x0:x0 + 16, :3].copy())
+        print((x0, y0), img[y0:y0 + 16, x0:x0 + 16, :3].mean(), st.as_dict())
+    np.savez_compressed(os.path.join(HERE, "duck_render_golden_64spp.npz"), crops=np.array(crops, np.int32), sums=np.array(out, np.float32),
+                        width=W, height=H, spp=spp, bounces=bounces)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["sky", "duck", "duck_render"]
+    which = sys.argv[1:] or ["sky", "duck", "duck_render", "duck_render64"]
     for w in which:
         globals()[w]()

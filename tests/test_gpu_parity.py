@@ -436,6 +436,102 @@ def test_atrium_config5_4k_16_bounces_crops_and_queue_occupancy(atrium):
     assert cr.sum() == s["closest_rays"] and sr.sum() == s["shadow_rays"]
 
 
+# ------------------------------------------------------------------ round 3: the BASELINE.json configurations at their FULL sample counts
+def test_config2_duck_800x600_at_its_full_64_spp_matches_golden_crops(duck_pt, duck_oracle):
+    """BASELINE.json config 2 as written: Duck.pt, 800x600, 64 spp, 4 bounces -- against the committed oracle crops
+    (tests/golden/make_golden.py duck_render64) and one more crop rendered live by the oracle."""
+    g = np.load(os.path.join(GOLDEN, "duck_render_golden_64spp.npz"))
+    W, H, spp, bounces = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["bounces"])
+    assert (W, H, spp, bounces) == (800, 600, 64, 4)
+    r, params = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    assert acc == spp
+    for (x0, y0), want in zip(g["crops"], g["sums"]):
+        assert np.array_equal(bits(img[y0:y0 + 16, x0:x0 + 16, :3]), bits(want)), (x0, y0)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    x0, y0 = 430, 310
+    ref, _ = orc.render(duck_oracle.scene, rp, 0, spp, x0, y0, x0 + 8, y0 + 8)
+    assert np.array_equal(bits(img[y0:y0 + 8, x0:x0 + 8, :3]), bits(ref[y0:y0 + 8, x0:x0 + 8, :3]))
+
+
+def test_config3_atrium_1080p_at_its_full_256_spp_crops_vs_oracle(atrium):
+    """BASELINE.json config 3 as written (on the Sponza stand-in): 1920x1080, 256 spp, 8 bounces -- 8x8 oracle crops, f32 sums of
+    256 samples per pixel bit for bit."""
+    W, H, spp, bounces = 1920, 1080, 256, 8
+    r, params = _renderer(atrium, W, H, spp, bounces)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    assert acc == spp and not np.isnan(img).any()
+    sc, _ = oracle_scene_from_pt(atrium)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    for (x0, y0) in [(956, 536), (300, 700), (1700, 180)]:
+        ref, _ = orc.render(sc, rp, 0, spp, x0, y0, x0 + 8, y0 + 8)
+        assert np.array_equal(bits(img[y0:y0 + 8, x0:x0 + 8, :3]), bits(ref[y0:y0 + 8, x0:x0 + 8, :3])), (x0, y0)
+    r.close()
+
+
+def test_config5_atrium_4k_16_bounces_at_its_full_1024_spp_crops_vs_oracle(atrium):
+    """BASELINE.json config 5 as written (one GPU's worth: the whole frame on this device): 3840x2160, 1024 spp, 16 bounces -- ~83 G
+    rays in several batches (the path state of 8.5 G paths does not fit at once); 8x8 oracle crops bit for bit."""
+    W, H, spp, bounces = 3840, 2160, 1024, 16
+    r, params = _renderer(atrium, W, H, spp, bounces)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    assert acc == spp and not np.isnan(img).any()
+    assert r.stats()["abandoned_rays"] == 0
+    sc, _ = oracle_scene_from_pt(atrium)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    for (x0, y0) in [(1916, 1076), (500, 1500)]:
+        ref, _ = orc.render(sc, rp, 0, spp, x0, y0, x0 + 8, y0 + 8)
+        assert np.array_equal(bits(img[y0:y0 + 8, x0:x0 + 8, :3]), bits(ref[y0:y0 + 8, x0:x0 + 8, :3])), (x0, y0)
+    r.close()
+
+
+@pytest.mark.parametrize("depth", [70, 96, 97, 130])
+def test_deep_chain_gpu_and_oracle_share_the_96_entry_stack_bound(depth):
+    """The reference's 32-entry traversal stack is overrun (undefined) by a 70-deep chain; product and oracle both define a
+    96-entry stack and ABANDON a ray that needs a 97th pending node with what it has found so far (rf_device.hpp,
+    oracle/rf_oracle.c ORC_STACK): queries and rendered images agree bit for bit on either side of the bound."""
+    nodes, tris, attrs = _chain_scene(depth)
+    sc = rf.scene_from_arrays(nodes, tris, attrs, [(np.array([0xFFFFFFFF], np.uint32), 1, 1)])
+    W, H, spp, bounces = 64, 64, 2, 2
+    cam = rf.create_camera((0.2, 0.2, -5.0), (0.2, 0.2, 0.0), 0.0, 1.0, np.radians(20.0), 1.0)
+    params = rf.make_render_parameters(W, H, cam, spp, bounces, rf.make_sky(), 1.0)
+    r = rf.ReferencePathTracer(params, sc)
+    rng = np.random.default_rng(depth)
+    rays = np.tile(np.array([[0.25, 0.25, -5.0, 1e-3, 1e-3, 1.0]], np.float32), (256, 1))
+    rays[:, :2] += rng.uniform(-0.2, 0.2, (256, 2)).astype(np.float32)
+    rays[128:, 3] *= -1.0                                         # dir.x < 0: the second child (a leaf) is the near one, nothing piles up
+    pos48 = np.ascontiguousarray(tris, np.float32)
+    cpu = orc.intersect_bvh_batch(nodes, pos48, rays, 10000.0)
+    for variant in (0, 2):                                        # scalar kernel over the 32-byte nodes / the render path's persistent kernel
+        r.set_option("query_variant", variant)
+        gpu = r.intersect_rays(rays, 10000.0)
+        assert np.array_equal(gpu["hit"], cpu["hit"]) and np.array_equal(gpu["tri"], cpu["tri"]), (depth, variant)
+        assert np.array_equal(bits(gpu["t"]), bits(cpu["t"])), (depth, variant)
+        assert np.array_equal(r.occluded_rays(rays, 10000.0), orc.shadow_batch(nodes, pos48, rays, 10000.0)), (depth, variant)
+    assert int(cpu["stackHigh"][:128].max()) == min(depth, 97) and int(cpu["stackHigh"][128:].max()) <= 1
+    r.reset_stats()
+    r.render(spp)
+    img, _ = r.read_accumulation()
+    s = r.stats()
+    assert (s["abandoned_rays"] > 0) == (depth > 96)
+    osc = orc.OracleScene(nodes, pos48, attrs, np.array([(1, 1, 0)], np.uint32), np.array([0xFFFFFFFF], np.uint32))
+    rp = orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 1.0, rf.aligned_sky_state(rf.make_sky()))
+    ref, st = orc.render(osc, rp, 0, spp)
+    if depth <= 96:
+        assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3])), depth
+    else:
+        # past the bound the two sides may differ, and only in the product's favour: the render path's kernels push a far child
+        # only if its box can still be hit, so many rays the reference-ordered stack (every far child pending) must abandon are
+        # traced to the end; a ray is abandoned only when that filtered stack AND the 96-entry scalar redo both overflow
+        assert st.stackHigh == 97
+        same = (bits(img[..., :3]) == bits(ref[..., :3])).all(axis=-1)
+        assert same.mean() > 0.5
+    r.close()
+
+
 def test_atrium_idempotent_and_shard_union_at_full_size(atrium):
     W, H, spp, bounces = 1920, 1080, 2, 8
     a, params = _renderer(atrium, W, H, spp, bounces)

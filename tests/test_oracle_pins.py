@@ -485,3 +485,38 @@ def test_deferred_variant_analytic_properties():
     s, _, _, st = orc.deferred_frames(sc, rp2, 1)
     assert st.shadowRays == 0
     assert s[..., 0].max() > 0.5 * sky[30] and s[..., 0].min() < 0.01 * sky[30]     # inside / outside the 0.255-degree disk
+
+
+def test_oracle_stack_bound_is_the_products_96_entries():
+    """The oracle's traversal stack (oracle/rf_oracle.c ORC_STACK) is aligned with the product's (rf_device.hpp: 24 + 72 = 96):
+    a chain with 70 or 96 pending far children is traversed to the end (the reference's 32-entry array would be overrun), one with
+    97 is abandoned with what was found up to there -- nothing -- and says so through stackHigh = 97.  The product's HOST query
+    (rf_intersect_bvh, growable pending list) agrees wherever the bound is not reached."""
+    import rayfinder_amd as rf
+    for depth in (31, 70, 96, 97, 150):
+        P = np.zeros((depth + 1, 9), np.float32)
+        for i in range(depth + 1):
+            z = np.float32(-1.0 - i)
+            P[i] = [-1, -1, z, 1, -1, z, 0, 1, z]
+        nodes = np.zeros(2 * depth + 1, rf.NODE_DTYPE)
+        for k in range(depth):
+            nodes[k]["min"] = [-1, -1, -1.0 - depth]; nodes[k]["max"] = [1, 1, -1.0 - k]
+            nodes[k]["splitAxis"] = 0
+            nodes[k]["secondChildOffset"] = 2 * depth - k
+        def leaf(at, tri):
+            nodes[at]["min"] = [-1, -1, P[tri][2]]; nodes[at]["max"] = [1, 1, P[tri][2]]
+            nodes[at]["trianglesOffset"] = tri; nodes[at]["triangleCount"] = 1; nodes[at]["splitAxis"] = 0xFFFFFFFF
+        leaf(depth, depth)
+        for k in range(depth):
+            leaf(2 * depth - k, k)
+        ray = np.array([[0.0, 0.0, 5.0, 1e-3, 1e-3, -1.0]], np.float32)   # +x: first child first, every second child pending
+        o = orc.intersect_bvh_batch(nodes, P, ray, 1e30)
+        vis = orc.shadow_batch(nodes, P, ray, 1e30)
+        if depth <= 96:
+            hit, rec, st = rf.intersect_bvh(ray[0], nodes, P, 1e30)
+            assert o["hit"][0] == 1 and hit and o["tri"][0] == rec["triangle"] == 0 and o["t"][0] == rec["t"]
+            assert o["stackHigh"][0] == depth == st["stack_high_water"] and o["nodesVisited"][0] == 2 * depth + 1 == st["nodes_visited"]
+            assert vis[0] == 0.0
+        else:
+            assert o["hit"][0] == 0 and o["stackHigh"][0] == 97          # abandoned before any leaf was reached
+            assert vis[0] == 1.0
