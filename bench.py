@@ -34,7 +34,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -95,28 +94,28 @@ def oracle_scene(pt):
     return orc.OracleScene(a["bvhNodes"], a["trianglePositionAttributes"], a["triangleVertexAttributes"], np.array(descs, np.uint32), texels), a
 
 
-def run_strips(cores, strips, fn):
-    """dynamic scheduling over the host cores: strips pulled from a shared counter (they differ a lot in cost)"""
-    lock = threading.Lock()
-    nxt = [0]
-    out = []
-
-    def work():
-        while True:
-            with lock:
-                i = nxt[0]
-                nxt[0] += 1
-            if i >= len(strips):
-                return
-            r = fn(strips[i])
-            with lock:
-                out.append(r)
-
-    threads = [threading.Thread(target=work) for _ in range(cores)]
-    t0 = time.time()
-    [t.start() for t in threads]
-    [t.join() for t in threads]
-    return out, time.time() - t0
+def host_cpus():
+    """-> (hardware threads this process may run on, CPU quota of the container in CPUs or None).  The GPU boxes report 256
+    hardware threads but run the job under a cgroup CPU quota (cpu.max = 16 CPUs): threads beyond ~2x the quota only add
+    scheduling overhead (tools/cpu_scaling.py: 16 threads 42.6, 32 threads 48.9, 256 threads 27.9 Mrays/s)."""
+    try:
+        hw = len(os.sched_getaffinity(0))
+    except AttributeError:
+        hw = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except Exception:
+            pass
+    return hw, quota
 
 
 def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, gpu_image):
@@ -126,7 +125,8 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     import rayfinder_amd as rf
     from oracle import orc
     sc, a = oracle_scene(pt)
-    cores = os.cpu_count() or 1
+    hw_threads, quota = host_cpus()
+    cores = hw_threads if quota is None else max(1, min(hw_threads, int(round(2 * quota))))     # threads used by the all-cores legs
     cam = rf.camera_to_array(rf.fly_camera(width, height))
     sky = rf.aligned_sky_state(rf.make_sky())
     rp = orc.make_render_params(width, height, cam, spp, bounces, 0.25, sky)
@@ -138,16 +138,20 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     dt1 = max(time.time() - t0, 1e-4)
     single = (st.closestRays + st.shadowRays) / dt1
     rays_per_pixel = (st.closestRays + st.shadowRays) / (cw * ch * 2) * spp        # at the full sample count
-    # crop sized for the budget (parallel efficiency of this memory-latency-bound loop on a many-core host: ~50 % of
-    # linear up to 24 threads, little beyond), at least 64x64 (the parity crop), at most the frame
-    want = seconds_budget * min(cores, 24) * 0.5 * single
-    side = int(min(max(64.0, (want / max(rays_per_pixel, 1.0)) ** 0.5), min(width, height)))
-    cw2, ch2 = min(side // 8 * 8, width), min(side // 4 * 4, height)
+    # crop sized for the budget (assuming ~50 % parallel efficiency up to 64 threads: the loop is memory-latency bound)
+    want = seconds_budget * (cores * 0.5 if quota is None else min(cores, quota) * 0.8) * single
+    area = max(want / max(rays_per_pixel, 1.0), 64.0 * 64.0)
+    # at least two rows per thread (one-row blocks, dealt statically), at least 64x64 (the parity crop), at most the frame
+    ch2 = int(min(height, max(64, 2 * cores, int(area ** 0.5) // 4 * 4)))
+    cw2 = int(min(width, max(64, int(area / ch2) // 8 * 8)))
     x0, y0 = (width - cw2) // 2, (height - ch2) // 2
     image = np.zeros((height, width, 4), np.float32)
-    strips = list(range(y0, y0 + ch2, 4))
-    stats, dt = run_strips(cores, strips, lambda y: orc.render(sc, rp, first_frame, spp, x0, y, x0 + cw2, min(y + 4, y0 + ch2), image=image, accumulated_start=0)[1])
-    rays = sum(s.closestRays + s.shadowRays for s in stats)
+    # all cores: C-side threads inside the oracle (pthreads; rows dealt in static one-row blocks, block b to thread b % cores --
+    # "row-parallel threads, static scanline blocks"); no Python in the timed loop
+    t0 = time.time()
+    _, st_all, started = orc.render_threads(sc, rp, first_frame, spp, x0, y0, x0 + cw2, y0 + ch2, cores, 1, image=image, accumulated_start=0)
+    dt = max(time.time() - t0, 1e-6)
+    rays = st_all.closestRays + st_all.shadowRays
     # parity of the timed GPU frame on that crop
     g, c = gpu_image[y0:y0 + ch2, x0:x0 + cw2, :3], image[y0:y0 + ch2, x0:x0 + cw2, :3]
     same_nan = bool(np.array_equal(np.isnan(g), np.isnan(c)))
@@ -161,11 +165,15 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     t0 = time.time()
     one = orc.bvh_visualize(a["bvhNodes"], tris36, vcam, vw, vh, vh * 3 // 8, vh * 5 // 8)   # the middle quarter of the rows on one thread
     viz_single = vw * (vh * 5 // 8 - vh * 3 // 8) / max(time.time() - t0, 1e-6)
-    _, vdt = run_strips(cores, list(range(0, vh, 8)), lambda r0: orc.bvh_visualize(a["bvhNodes"], tris36, vcam, vw, vh, r0, min(r0 + 8, vh)))
+    t0 = time.time()
+    orc.bvh_visualize_threads(a["bvhNodes"], tris36, vcam, vw, vh, cores, 1)
+    vdt = max(time.time() - t0, 1e-6)
     del one
     base = dict(value=round(rays / dt * 1e-6, 3), unit="Mrays/s", cores=cores, kind="port",
                 sample=f"oracle/rf_oracle.c full path tracer, centred {cw2}x{ch2} crop of the {width}x{height} frame, {spp} spp (the timed frames), {bounces} bounces, "
-                       f"{rays} rays in {dt:.1f} s on {cores} threads (4-row strips, dynamic); 1 thread: {single * 1e-6:.3f} Mrays/s",
+                       f"{rays} rays in {dt:.1f} s on {started} C-side threads (pthreads in the oracle, static one-row blocks; the host has {hw_threads} hardware threads"
+                       + (f", the container a CPU quota of {quota:g} CPUs" if quota is not None else "") + f"); 1 thread: {single * 1e-6:.3f} Mrays/s",
+                host_hardware_threads=hw_threads, cpu_quota=quota,
                 single_thread_value=round(single * 1e-6, 3),
                 bvh_visualizer_primary_rays=dict(unit="Mrays/s", image=f"{vw}x{vh}", one_thread=round(viz_single * 1e-6, 3),
                                                  all_cores=round(vw * vh / vdt * 1e-6, 3), cores=cores,

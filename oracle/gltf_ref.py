@@ -59,6 +59,16 @@ def _load_uri(uri, gltf_path):
     return open(os.path.join(os.path.dirname(gltf_path), unquote(uri)), "rb").read()
 
 
+def _gather(buf, base, count, stride, dt, sz, nc):
+    out = np.zeros((count, nc), dtype=dt)
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    for c in range(nc):
+        idxs = base + np.arange(count) * stride + c * sz
+        comp = np.stack([raw[idxs + k] for k in range(sz)], axis=1).copy().view(dt).reshape(count)
+        out[:, c] = comp
+    return out
+
+
 def read_accessor(js, buffers, idx):
     acc = js["accessors"][idx]
     bv = js["bufferViews"][acc["bufferView"]]
@@ -66,14 +76,47 @@ def read_accessor(js, buffers, idx):
     nc = _NCOMP[acc["type"]]
     base = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
     stride = bv.get("byteStride", 0) or sz * nc
-    buf = buffers[bv["buffer"]]
+    return _gather(buffers[bv["buffer"]], base, acc["count"], stride, dt, sz, nc)
+
+
+_NORM = {5120: 127.0, 5121: 255.0, 5122: 32767.0, 5123: 65535.0}
+
+
+def _as_float(raw, comp_type, normalized):
+    """cgltf 1.13 cgltf_component_read_float (un-vendored dependency, published algorithm): f32 as is, normalized 8/16-bit integers
+    divided by 127 / 255 / 32767 / 65535 in f32 (no clamp to -1), anything else converted as an integer."""
+    if comp_type == 5126:
+        return raw.astype(np.float32)
+    if normalized and comp_type in _NORM:
+        return (raw.astype(np.float32) / np.float32(_NORM[comp_type])).astype(np.float32)
+    return raw.astype(np.float32)
+
+
+def unpack_floats(js, buffers, idx):
+    """cgltf_accessor_unpack_floats (what gltf_model.cpp:400-438 reads the vertex attributes through): the base accessor (zeros
+    without a buffer view), then the sparse overlay -- value k, laid out with the accessor's stride, replaces element indices[k]."""
+    acc = js["accessors"][idx]
+    dt, sz = _COMP[acc["componentType"]]
+    nc = _NCOMP[acc["type"]]
     count = acc["count"]
-    out = np.zeros((count, nc), dtype=dt)
-    raw = np.frombuffer(buf, dtype=np.uint8)
-    for c in range(nc):
-        idxs = base + np.arange(count) * stride + c * sz
-        comp = np.stack([raw[idxs + k] for k in range(sz)], axis=1).copy().view(dt).reshape(count)
-        out[:, c] = comp
+    normalized = bool(acc.get("normalized", False))
+    stride = sz * nc
+    if "bufferView" in acc:
+        bv = js["bufferViews"][acc["bufferView"]]
+        stride = bv.get("byteStride", 0) or stride
+        out = _as_float(_gather(buffers[bv["buffer"]], bv.get("byteOffset", 0) + acc.get("byteOffset", 0), count, stride, dt, sz, nc), acc["componentType"], normalized)
+    else:
+        out = np.zeros((count, nc), np.float32)
+    if "sparse" in acc:
+        sp = acc["sparse"]
+        n = sp["count"]
+        ibv = js["bufferViews"][sp["indices"]["bufferView"]]
+        idt, isz = _COMP[sp["indices"]["componentType"]]
+        where = _gather(buffers[ibv["buffer"]], ibv.get("byteOffset", 0) + sp["indices"].get("byteOffset", 0), n, isz, idt, isz, 1).reshape(-1).astype(np.int64)
+        vbv = js["bufferViews"][sp["values"]["bufferView"]]
+        vals = _as_float(_gather(buffers[vbv["buffer"]], vbv.get("byteOffset", 0) + sp["values"].get("byteOffset", 0), n, stride, dt, sz, nc), acc["componentType"], normalized)
+        for k in range(n):                      # in file order: a repeated index keeps the LAST value, as a sequential overlay does
+            out[where[k]] = vals[k]
     return out
 
 
@@ -246,9 +289,9 @@ def load_model(path):
                     textures.append(pixel_texture(*fac))
                 tidx = factor_lookup[h]
             indices = read_accessor(js, buffers, prim["indices"]).astype(np.uint32).reshape(-1)
-            lp = read_accessor(js, buffers, prim["attributes"]["POSITION"]).astype(np.float32)
-            ln = read_accessor(js, buffers, prim["attributes"]["NORMAL"]).astype(np.float32)
-            uv = read_accessor(js, buffers, prim["attributes"]["TEXCOORD_0"]).astype(np.float32)
+            lp = unpack_floats(js, buffers, prim["attributes"]["POSITION"])
+            ln = unpack_floats(js, buffers, prim["attributes"]["NORMAL"])
+            uv = unpack_floats(js, buffers, prim["attributes"]["TEXCOORD_0"])
             p4 = np.concatenate([lp, np.ones((lp.shape[0], 1), np.float32)], axis=1)
             pos = mat4_mul_vec4(M, p4)[:, :3].astype(np.float32)                      # gltf_model.cpp:413
             n4 = np.concatenate([ln, np.zeros((ln.shape[0], 1), np.float32)], axis=1)

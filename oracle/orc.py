@@ -85,6 +85,10 @@ def lib():
         _lib.orc_render.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
         _lib.orc_render_from.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p]
         _lib.orc_deferred_frame.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 5 + [C.c_void_p] * 4
+        _lib.orc_render_threads.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        _lib.orc_render_threads.restype = C.c_int
+        _lib.orc_bvh_visualize_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
+        _lib.orc_bvh_visualize_threads.restype = C.c_int
         _lib.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]
         _lib.orc_pixar_onb.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_direction_in_cone.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
@@ -312,6 +316,25 @@ def render(scene, rp, first_frame, num_frames, x0=0, y0=0, x1=None, y1=None, ima
     lib().orc_render_from(C.byref(scene.c), C.byref(rp), first_frame, first_frame if accumulated_start is None else accumulated_start, num_frames,
                           x0, y0, x1, y1, _p(image), C.byref(st))
     return image, st
+
+
+def render_threads(scene, rp, first_frame, num_frames, x0, y0, x1, y1, num_threads, rows_per_block=1, image=None, accumulated_start=None):
+    """render() on num_threads C-side threads (pthreads inside the oracle: rows dealt in static blocks, block b to thread
+    b % num_threads) -- bench.py's all-cores cpu_baseline.  -> (image, stats, threads actually started)."""
+    lib()
+    if image is None:
+        image = np.zeros((rp.height, rp.width, 4), np.float32)
+    st = Stats()
+    started = lib().orc_render_threads(C.byref(scene.c), C.byref(rp), first_frame, first_frame if accumulated_start is None else accumulated_start, num_frames,
+                                       x0, y0, x1, y1, _p(image), C.byref(st), num_threads, rows_per_block)
+    return image, st, started
+
+
+def bvh_visualize_threads(nodes, tris, cam19, W, H, num_threads, rows_per_block=1):
+    tris = f32(tris); cam19 = f32(cam19)
+    nv = np.zeros(W * H, np.uint32)
+    started = lib().orc_bvh_visualize_threads(_p(nodes), _p(tris), tris.shape[1], _p(cam19), W, H, _p(nv), num_threads, rows_per_block)
+    return nv, started
 
 
 def deferred_frames(scene, rp, num_frames, x0=0, y0=0, x1=None, y1=None):

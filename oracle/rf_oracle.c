@@ -41,6 +41,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1041,6 +1042,108 @@ ORC_API void orc_render(const OrcScene* sc, const OrcRenderParams* rp, uint32_t 
                         uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float* image, OrcStats* st)
 {
     orc_render_from(sc, rp, firstFrame, firstFrame, numFrames, x0, y0, x1, y1, image, st);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* All-cores drivers for bench.py's cpu_baseline ("row-parallel threads, static   */
+/* scanline blocks").  The reference has no threading anywhere (src/common, bvh-visualizer): these */
+/* only run the single-threaded loops above on disjoint rows.  Block b of `rowsPerBlock` rows      */
+/* belongs to thread b % numThreads (a static deal; interleaved so that sky rows and interior rows */
+/* spread over the threads).  Pixels are independent, so the image is the serial one bit for bit.  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const OrcScene* sc; const OrcRenderParams* rp;
+    uint32_t firstFrame, accumulatedStart, numFrames, x0, y0, x1, y1, rowsPerBlock, thread, numThreads;
+    float* image; OrcStats st;
+    /* bvh-visualizer variant */
+    const OrcBvhNode* nodes; const float* tris; int triStride; const float* cam19; int W, H;
+    uint32_t* nodesVisited;
+} __attribute__((aligned(128))) OrcThreadJob; /* one thread's counters never share a cache line with another's */
+
+static void* render_thread_main(void* arg)
+{
+    OrcThreadJob* j = (OrcThreadJob*)arg;
+    uint32_t b = j->thread;
+    for (;; b += j->numThreads) {
+        const uint64_t r0 = (uint64_t)j->y0 + (uint64_t)b * j->rowsPerBlock;
+        if (r0 >= j->y1) break;
+        const uint32_t r1 = (uint32_t)(r0 + j->rowsPerBlock < j->y1 ? r0 + j->rowsPerBlock : j->y1);
+        orc_render_from(j->sc, j->rp, j->firstFrame, j->accumulatedStart, j->numFrames, j->x0, (uint32_t)r0, j->x1, r1, j->image, &j->st);
+    }
+    return NULL;
+}
+
+static void* visualize_thread_main(void* arg)
+{
+    OrcThreadJob* j = (OrcThreadJob*)arg;
+    uint32_t b = j->thread;
+    for (;; b += j->numThreads) {
+        const uint64_t r0 = (uint64_t)j->y0 + (uint64_t)b * j->rowsPerBlock;
+        if (r0 >= j->y1) break;
+        const uint32_t r1 = (uint32_t)(r0 + j->rowsPerBlock < j->y1 ? r0 + j->rowsPerBlock : j->y1);
+        orc_bvh_visualize(j->nodes, j->tris, j->triStride, j->cam19, j->W, j->H, (int)r0, (int)r1, j->nodesVisited, NULL, NULL, NULL, NULL);
+    }
+    return NULL;
+}
+
+static int run_jobs(OrcThreadJob* jobs, uint32_t n, void* (*fn)(void*))
+{
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n);
+    uint32_t started = 0;
+    if (!th) return -1;
+    for (; started < n; ++started)
+        if (pthread_create(&th[started], NULL, fn, &jobs[started]) != 0) break;
+    for (uint32_t i = started; i < n; ++i) fn(&jobs[i]); /* could not start that many threads: run the rest here */
+    for (uint32_t i = 0; i < started; ++i) pthread_join(th[i], NULL);
+    free(th);
+    return (int)started;
+}
+
+/* -> number of threads actually started (the calling thread runs whatever could not be started) */
+ORC_API int orc_render_threads(const OrcScene* sc, const OrcRenderParams* rp, uint32_t firstFrame, uint32_t accumulatedStart, uint32_t numFrames,
+                               uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float* image, OrcStats* st, uint32_t numThreads, uint32_t rowsPerBlock)
+{
+    if (numThreads == 0) numThreads = 1;
+    if (rowsPerBlock == 0) rowsPerBlock = 1;
+    OrcThreadJob* jobs = (OrcThreadJob*)aligned_alloc(128, (size_t)numThreads * sizeof(OrcThreadJob));
+    if (jobs) memset(jobs, 0, (size_t)numThreads * sizeof(OrcThreadJob));
+    if (!jobs) return -1;
+    for (uint32_t t = 0; t < numThreads; ++t) {
+        OrcThreadJob* j = &jobs[t];
+        j->sc = sc; j->rp = rp; j->firstFrame = firstFrame; j->accumulatedStart = accumulatedStart; j->numFrames = numFrames;
+        j->x0 = x0; j->y0 = y0; j->x1 = x1; j->y1 = y1; j->rowsPerBlock = rowsPerBlock; j->thread = t; j->numThreads = numThreads; j->image = image;
+    }
+    const int started = run_jobs(jobs, numThreads, render_thread_main);
+    if (st) {
+        for (uint32_t t = 0; t < numThreads; ++t) {
+            const OrcStats* a = &jobs[t].st;
+            st->closestRays += a->closestRays; st->shadowRays += a->shadowRays;
+            st->closestNodeVisits += a->closestNodeVisits; st->shadowNodeVisits += a->shadowNodeVisits;
+            st->closestTriTests += a->closestTriTests; st->shadowTriTests += a->shadowTriTests;
+            st->texelOobClamps += a->texelOobClamps; st->nanPixels += a->nanPixels;
+            if (a->stackHigh > st->stackHigh) st->stackHigh = a->stackHigh;
+        }
+    }
+    free(jobs);
+    return started;
+}
+
+ORC_API int orc_bvh_visualize_threads(const OrcBvhNode* nodes, const float* tris, int tri_stride_floats, const float* cam19, int W, int H,
+                                      uint32_t* nodes_visited_out, uint32_t numThreads, uint32_t rowsPerBlock)
+{
+    if (numThreads == 0) numThreads = 1;
+    if (rowsPerBlock == 0) rowsPerBlock = 1;
+    OrcThreadJob* jobs = (OrcThreadJob*)aligned_alloc(128, (size_t)numThreads * sizeof(OrcThreadJob));
+    if (jobs) memset(jobs, 0, (size_t)numThreads * sizeof(OrcThreadJob));
+    if (!jobs) return -1;
+    for (uint32_t t = 0; t < numThreads; ++t) {
+        OrcThreadJob* j = &jobs[t];
+        j->nodes = nodes; j->tris = tris; j->triStride = tri_stride_floats; j->cam19 = cam19; j->W = W; j->H = H; j->nodesVisited = nodes_visited_out;
+        j->y0 = 0; j->y1 = (uint32_t)H; j->rowsPerBlock = rowsPerBlock; j->thread = t; j->numThreads = numThreads;
+    }
+    const int started = run_jobs(jobs, numThreads, visualize_thread_main);
+    free(jobs);
+    return started;
 }
 
 /* ------------------------------------------------------------------------------------------ */

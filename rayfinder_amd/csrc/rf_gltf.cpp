@@ -525,11 +525,30 @@ int componentSize(int type)
     }
 }
 
+struct BufferViewSpan
+{
+    const uint8_t* data = nullptr;
+    std::size_t    size = 0, byteStride = 0;
+};
+
+BufferViewSpan bufferViewSpan(const Document& doc, std::size_t index)
+{
+    const Json&                 bv = doc.json.at("bufferViews").array.at(index);
+    const std::vector<uint8_t>& buffer = doc.buffers.at(bv.at("buffer").index());
+    const std::size_t           offset = bv.has("byteOffset") ? bv.at("byteOffset").index() : 0;
+    const std::size_t           length = bv.has("byteLength") ? bv.at("byteLength").index() : (offset <= buffer.size() ? buffer.size() - offset : 0);
+    if (offset > buffer.size() || length > buffer.size() - offset) throw std::runtime_error("glTF: buffer view exceeds its buffer");
+    BufferViewSpan s;
+    s.data = buffer.data() + offset;
+    s.size = length;
+    s.byteStride = bv.has("byteStride") ? bv.at("byteStride").index() : 0;
+    return s;
+}
+
+// base == nullptr: the accessor has no buffer view (cgltf then reads zeros; only meaningful together with "sparse")
 AccessorView accessorView(const Document& doc, std::size_t index)
 {
-    const Json& acc = doc.json.at("accessors").array.at(index);
-    if (acc.has("sparse")) throw std::runtime_error("glTF: sparse accessors are not supported");
-    const Json&  bv = doc.json.at("bufferViews").array.at(acc.at("bufferView").index());
+    const Json&  acc = doc.json.at("accessors").array.at(index);
     AccessorView v;
     v.componentType = static_cast<int>(acc.at("componentType").number);
     const std::string& type = acc.at("type").string;
@@ -538,14 +557,19 @@ AccessorView accessorView(const Document& doc, std::size_t index)
     v.count = acc.at("count").index();
     v.normalized = acc.has("normalized") && acc.at("normalized").boolean;
     const std::size_t elem = static_cast<std::size_t>(componentSize(v.componentType)) * static_cast<std::size_t>(v.components);
-    v.stride = bv.has("byteStride") && bv.at("byteStride").index() != 0 ? bv.at("byteStride").index() : elem;
-    const std::vector<uint8_t>& buffer = doc.buffers.at(bv.at("buffer").index());
-    const std::size_t offset = (bv.has("byteOffset") ? bv.at("byteOffset").index() : 0) + (acc.has("byteOffset") ? acc.at("byteOffset").index() : 0);
-    if (v.count && offset + (v.count - 1) * v.stride + elem > buffer.size()) throw std::runtime_error("glTF: accessor exceeds its buffer");
-    v.base = buffer.data() + offset;
+    v.stride = elem;
+    if (!acc.has("bufferView")) return v;
+    const BufferViewSpan bv = bufferViewSpan(doc, acc.at("bufferView").index());
+    if (bv.byteStride != 0) v.stride = bv.byteStride;
+    const std::size_t offset = acc.has("byteOffset") ? acc.at("byteOffset").index() : 0;
+    if (v.count && (offset > bv.size || (v.count - 1) * v.stride + elem > bv.size - offset)) throw std::runtime_error("glTF: accessor exceeds its buffer view");
+    v.base = bv.data + offset;
     return v;
 }
 
+// cgltf 1.13 cgltf_component_read_float (un-vendored dependency, published algorithm): f32 as is; normalized integers divided by
+// 127 / 255 / 32767 / 65535 WITHOUT the clamp to -1 the glTF text suggests for the most negative value (so -128 -> -1.00787...);
+// anything else converted as an integer
 float componentAsFloat(const uint8_t* p, int type, bool normalized)
 {
     switch (type)
@@ -559,14 +583,14 @@ float componentAsFloat(const uint8_t* p, int type, bool normalized)
     case 5120:
     {
         const int8_t v = static_cast<int8_t>(*p);
-        return normalized ? std::max(static_cast<float>(v) / 127.0f, -1.0f) : static_cast<float>(v);
+        return normalized ? static_cast<float>(v) / 127.0f : static_cast<float>(v);
     }
     case 5121: return normalized ? static_cast<float>(*p) / 255.0f : static_cast<float>(*p);
     case 5122:
     {
         int16_t v;
         std::memcpy(&v, p, 2);
-        return normalized ? std::max(static_cast<float>(v) / 32767.0f, -1.0f) : static_cast<float>(v);
+        return normalized ? static_cast<float>(v) / 32767.0f : static_cast<float>(v);
     }
     case 5123:
     {
@@ -602,6 +626,46 @@ uint32_t componentAsUint(const uint8_t* p, int type)
     }
     default: throw std::runtime_error("glTF: index accessor must be unsigned");
     }
+}
+
+// cgltf_accessor_unpack_floats (gltf_model.cpp:400-438 reads POSITION / NORMAL / TEXCOORD_0 through it; cgltf 1.13, published
+// algorithm): first the base accessor -- zeros when it has no buffer view, any component type, normalized integers as above,
+// the buffer view's byteStride -- then the "sparse" overlay: value k (laid out with the ACCESSOR's stride, which without a
+// buffer view is the element size) replaces element indices[k].
+std::vector<float> unpackFloats(const Document& doc, std::size_t accessorIndex, int comps, const char* what)
+{
+    const AccessorView v = accessorView(doc, accessorIndex);
+    if (v.components != comps) throw std::runtime_error(std::string("glTF: ") + what + " has the wrong accessor type");
+    std::vector<float> out(v.count * static_cast<std::size_t>(comps), 0.0f);
+    const std::size_t  cs = static_cast<std::size_t>(componentSize(v.componentType));
+    if (v.base != nullptr)
+        for (std::size_t i = 0; i < v.count; ++i)
+            for (int c = 0; c < comps; ++c)
+                out[i * comps + c] = componentAsFloat(v.base + i * v.stride + static_cast<std::size_t>(c) * cs, v.componentType, v.normalized);
+    const Json& acc = doc.json.at("accessors").array.at(accessorIndex);
+    if (acc.has("sparse"))
+    {
+        const Json&       sp = acc.at("sparse");
+        const std::size_t n = sp.at("count").index();
+        const Json&       si = sp.at("indices");
+        const Json&       sv = sp.at("values");
+        const int         indexType = static_cast<int>(si.at("componentType").number);
+        if (indexType != 5121 && indexType != 5123 && indexType != 5125) throw std::runtime_error("glTF: sparse indices must be unsigned");
+        const BufferViewSpan ib = bufferViewSpan(doc, si.at("bufferView").index()), vb = bufferViewSpan(doc, sv.at("bufferView").index());
+        const std::size_t    io = si.has("byteOffset") ? si.at("byteOffset").index() : 0, vo = sv.has("byteOffset") ? sv.at("byteOffset").index() : 0;
+        const std::size_t    is = static_cast<std::size_t>(componentSize(indexType)), elem = cs * static_cast<std::size_t>(comps);
+        if (n && (io > ib.size || n * is > ib.size - io)) throw std::runtime_error("glTF: sparse indices exceed their buffer view");
+        if (n && (vo > vb.size || (n - 1) * v.stride + elem > vb.size - vo)) throw std::runtime_error("glTF: sparse values exceed their buffer view");
+        for (std::size_t k = 0; k < n; ++k)
+        {
+            const std::size_t at = componentAsUint(ib.data + io + k * is, indexType);
+            if (at >= v.count) throw std::runtime_error("glTF: sparse index out of range");
+            for (int c = 0; c < comps; ++c)
+                out[at * comps + c] = componentAsFloat(vb.data + vo + k * v.stride + static_cast<std::size_t>(c) * cs, v.componentType, v.normalized);
+        }
+    }
+    else if (v.base == nullptr) throw std::runtime_error(std::string("glTF: ") + what + " accessor has neither a buffer view nor sparse data");
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -930,6 +994,8 @@ GltfModel loadGltfModel(const std::string& pathString)
                 if (!prim.has("indices")) throw std::runtime_error("glTF: non-indexed primitives are not supported");
                 const AccessorView v = accessorView(doc, prim.at("indices").index());
                 if (v.components != 1) throw std::runtime_error("glTF: index accessor must be SCALAR");
+                // (cgltf_accessor_read_uint returns 0 for a sparse accessor and for one without a buffer view: the reference asserts)
+                if (v.base == nullptr || doc.json.at("accessors").array.at(prim.at("indices").index()).has("sparse")) throw std::runtime_error("glTF: sparse index accessors are not supported");
                 if (v.count % 3 != 0) throw std::runtime_error("glTF: index count is not a multiple of 3");
                 mesh.indices.resize(v.count);
                 for (std::size_t i = 0; i < v.count; ++i) mesh.indices[i] = componentAsUint(v.base + i * v.stride, v.componentType);
@@ -938,14 +1004,7 @@ GltfModel loadGltfModel(const std::string& pathString)
             const Json& attrs = prim.at("attributes");
             const auto  floats = [&](const char* name, int comps) {
                 if (!attrs.has(name)) throw std::runtime_error(std::string("glTF: primitive lacks ") + name);
-                const AccessorView v = accessorView(doc, attrs.at(name).index());
-                if (v.components != comps || v.componentType != 5126) throw std::runtime_error(std::string("glTF: ") + name + " must be f32");
-                std::vector<float> out(v.count * static_cast<std::size_t>(comps));
-                const std::size_t  cs = static_cast<std::size_t>(componentSize(v.componentType));
-                for (std::size_t i = 0; i < v.count; ++i)
-                    for (int c = 0; c < comps; ++c)
-                        out[i * comps + c] = componentAsFloat(v.base + i * v.stride + static_cast<std::size_t>(c) * cs, v.componentType, v.normalized);
-                return out;
+                return unpackFloats(doc, attrs.at(name).index(), comps, name);
             };
             const std::vector<float> pos = floats("POSITION", 3), nrm = floats("NORMAL", 3), uv = floats("TEXCOORD_0", 2);
             if (pos.size() != nrm.size() || pos.size() / 3 != uv.size() / 2) throw std::runtime_error("glTF: attribute counts differ");

@@ -711,3 +711,99 @@ def test_cli_bvh_visualizer_cpu_writes_the_reference_grey_map(duck_pt, tmp_path)
     from oracle import orc
     for n in (0, 1, 49, 50, 99, 100, 101, 157, 5000):
         assert int(rf.bvh_visualizer_grey(np.array([n]))[0]) == orc.lib().orc_bvh_visualizer_pixel(n) & 0xFF
+
+
+def test_gltf_sparse_accessors_and_normalized_integer_attributes(tmp_path):
+    """What the reference gets from cgltf_accessor_unpack_floats (gltf_model.cpp:400-438): POSITION as a sparse accessor over a
+    buffer view and as a sparse accessor over NOTHING (zeros + overlay), NORMAL as normalized int8 in an interleaved (byteStride)
+    view, TEXCOORD_0 as normalized uint16 / int16 -- known answers, and product bake == oracle ingest bit for bit."""
+    import base64
+    blob = bytearray()
+    views = []
+
+    def view(data, stride=None):
+        while len(blob) % 4:
+            blob.append(0)
+        v = {"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)}
+        if stride:
+            v["byteStride"] = stride
+        views.append(v)
+        blob.extend(data)
+        return len(views) - 1
+
+    nv = 6
+    base_pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1]], "<f4")
+    v_pos = view(base_pos.tobytes())
+    sp_idx = np.array([1, 4, 1], "<u2")                       # index 1 twice: the later value wins
+    sp_val = np.array([[9, 9, 9], [0.5, -2, 3], [2, 0.25, -1]], "<f4")
+    v_spi, v_spv = view(sp_idx.tobytes()), view(sp_val.tobytes())
+    sp2_idx = np.array([0, 2, 3, 5], "<u1")
+    sp2_val = np.array([[1, 2, 3], [-1, 0, 2], [4, 4, -4], [0.5, 0.5, 0.5]], "<f4")
+    v_sp2i, v_sp2v = view(sp2_idx.tobytes()), view(sp2_val.tobytes())
+    # interleaved vertex buffer, 8-byte stride: int8 normal xyz (+1 pad), uint16 uv
+    inter = bytearray()
+    nrm8 = np.array([[127, 0, 0], [0, -128, 0], [0, 0, 127], [-127, 64, 3], [90, 90, 0], [1, 2, 3]], np.int8)
+    uv16 = np.array([[0, 65535], [32768, 1], [65535, 65535], [100, 200], [40000, 3], [7, 7]], "<u2")
+    for i in range(nv):
+        inter += nrm8[i].tobytes() + b"\0" + uv16[i].tobytes()
+    v_inter = view(bytes(inter), stride=8)
+    suv16 = np.array([[32767, -32768], [0, 1], [-1, 16384], [5, 5], [-32767, 32767], [1000, -1000]], "<i2")
+    v_suv = view(suv16.tobytes())
+    idx = np.array([0, 1, 2, 2, 1, 3, 4, 5, 0], "<u2")
+    v_idx = view(idx.tobytes())
+    accessors = [
+        {"bufferView": v_pos, "componentType": 5126, "count": nv, "type": "VEC3",
+         "sparse": {"count": 3, "indices": {"bufferView": v_spi, "componentType": 5123}, "values": {"bufferView": v_spv}}},          # 0
+        {"componentType": 5126, "count": nv, "type": "VEC3",
+         "sparse": {"count": 4, "indices": {"bufferView": v_sp2i, "componentType": 5121}, "values": {"bufferView": v_sp2v}}},        # 1
+        {"bufferView": v_inter, "componentType": 5120, "normalized": True, "count": nv, "type": "VEC3"},                             # 2
+        {"bufferView": v_inter, "byteOffset": 4, "componentType": 5123, "normalized": True, "count": nv, "type": "VEC2"},            # 3
+        {"bufferView": v_suv, "componentType": 5122, "normalized": True, "count": nv, "type": "VEC2"},                               # 4
+        {"bufferView": v_idx, "componentType": 5123, "count": idx.size, "type": "SCALAR"},                                           # 5
+    ]
+    js = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 1]}], "nodes": [{"mesh": 0}, {"mesh": 1, "translation": [5, 0, 0]}],
+          "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 2, "TEXCOORD_0": 3}, "indices": 5, "material": 0}]},
+                     {"primitives": [{"attributes": {"POSITION": 1, "NORMAL": 2, "TEXCOORD_0": 4}, "indices": 5, "material": 0}]}],
+          "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [1.0, 0.5, 0.25, 1.0]}}],
+          "accessors": accessors, "bufferViews": views,
+          "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(blob)).decode()}]}
+    p = tmp_path / "sparse.gltf"
+    p.write_text(json.dumps(js))
+    # known answers of the oracle's unpack (cgltf's published algorithm)
+    ojs, obufs = gltf_ref.load_container(str(p))
+    pos0 = gltf_ref.unpack_floats(ojs, obufs, 0)
+    want0 = base_pos.copy(); want0[1] = [2, 0.25, -1]; want0[4] = [0.5, -2, 3]
+    assert np.array_equal(pos0, want0)
+    pos1 = gltf_ref.unpack_floats(ojs, obufs, 1)
+    want1 = np.zeros((nv, 3), np.float32); want1[[0, 2, 3, 5]] = sp2_val
+    assert np.array_equal(pos1, want1)
+    n8 = gltf_ref.unpack_floats(ojs, obufs, 2)
+    assert n8[0, 0] == 1.0 and n8[1, 1] == np.float32(-128) / np.float32(127) and n8[1, 1] < -1.0        # no clamp in cgltf
+    assert np.array_equal(n8, nrm8.astype(np.float32) / np.float32(127))
+    assert np.array_equal(gltf_ref.unpack_floats(ojs, obufs, 3), uv16.astype(np.float32) / np.float32(65535))
+    assert np.array_equal(gltf_ref.unpack_floats(ojs, obufs, 4), suv16.astype(np.float32) / np.float32(32767))
+    # product bake == oracle ingest
+    pt = rf.PtFormat.from_gltf(p)
+    a = pt.arrays()
+    m = gltf_ref.load_model(str(p))
+    P, N, T, I = gltf_ref.flatten(m)
+    onodes, oidx, _ = orc.build_bvh(P)
+    assert a["bvhNodes"].tobytes() == onodes.tobytes()
+    pa, va = gltf_ref.gpu_layout(orc.reorder(P, oidx), orc.reorder(N, oidx), orc.reorder(T, oidx), orc.reorder(I, oidx))
+    assert np.array_equal(bits(a["trianglePositionAttributes"]), bits(pa))
+    assert np.array_equal(bits(a["triangleVertexAttributes"]), bits(va))
+    assert len(P) == 6                                            # 3 triangles per mesh
+    # malformed sparse data is refused, not read out of bounds
+    for mutate in ("index", "values", "sparse_indices_accessor"):
+        bad = json.loads(json.dumps(js))
+        if mutate == "index":
+            bad["accessors"][0]["sparse"]["indices"]["componentType"] = 5125         # 3 x u32 do not fit the 6-byte view
+        elif mutate == "values":
+            bad["accessors"][1]["sparse"]["count"] = 5
+            bad["bufferViews"][v_sp2i]["byteLength"] = 4
+        else:
+            bad["accessors"][5]["sparse"] = {"count": 1, "indices": {"bufferView": v_spi, "componentType": 5123}, "values": {"bufferView": v_idx}}
+        q = tmp_path / f"bad_{mutate}.gltf"
+        q.write_text(json.dumps(bad))
+        with pytest.raises(rf.RayfinderError):
+            rf.PtFormat.from_gltf(q)
