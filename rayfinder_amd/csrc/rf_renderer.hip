@@ -1276,10 +1276,18 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             if (ANY_HIT)
             {
-                const float  visibility = occluded ? 0.0f : 1.0f;
-                const Vec3   add = (load3s(ps.pending + resultIndex) * visibility) * __uint_as_float(kSolarInvPdfBits);
-                const Vec3   radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add; // bounce 1: still 0 (wgsl:183)
-                store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
+                const float visibility = occluded ? 0.0f : 1.0f;
+                const Vec3  add = (load3s(ps.pending + resultIndex) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                // An occluded ray adds pending * 0 = +-0 to a sum that is never -0 (it starts at +0, and x + y = -0 only for two
+                // negative zeros): the sum keeps its bits, so its slot -- a random 16-byte read-modify-write by now -- is left
+                // alone.  Not at bounce 1 (the sum is not in memory yet), and not when the product is NaN (an infinite or NaN
+                // NEE term times 0: the reference's sum turns NaN, and so does this one).
+                const bool unchanged = !firstBounce && add.x == 0.0f && add.y == 0.0f && add.z == 0.0f;
+                if (!unchanged)
+                {
+                    const Vec3 radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add; // bounce 1: still 0 (wgsl:183)
+                    store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
+                }
             }
             else
             {
@@ -2048,7 +2056,7 @@ struct Renderer::Impl
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
-    uint32_t optRefillMinDeep = 22, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at 22 idle lanes
+    uint32_t optRefillMinDeep = 40, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 may refill at another count (22 was best with the 64-byte records, 40 with the quad records)
     // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
