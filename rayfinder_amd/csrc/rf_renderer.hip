@@ -394,8 +394,13 @@ constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
 // the blue-noise triple, the radiance sum -- is touched by the same workgroups as before).  `sortScale`: bin of triangle t =
 // (t * sortScale) >> 32.
 constexpr uint32_t kSortBins = 256;
+#if defined(RF_EXP_SHADE_WAVES)
+#define RF_SHADE_BOUNDS __launch_bounds__(kBlock, RF_EXP_SHADE_WAVES)
+#else
+#define RF_SHADE_BOUNDS __launch_bounds__(kBlock)
+#endif
 template<bool SORTED>
-__global__ __launch_bounds__(kBlock) void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
+__global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                   const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
                                                   uint32_t* missCount, uint32_t bounceFlags, uint32_t sortScale)
 {
