@@ -96,3 +96,55 @@ for i, (key, val) in enumerate([("matrix", [1.0] * 7), ("scale", [1.0]), ("rotat
     out_b = bytearray(glb[:12]) + struct.pack("<I", len(body)) + b"JSON" + body + rest
     struct.pack_into("<I", out_b, 8, len(out_b))
     open(f"{out}/ingest/t{i}.glb", "wb").write(bytes(out_b))
+# sparse accessors / normalized integers / byteStride (round 3): a small .gltf with a data-URI buffer whose accessor and
+# buffer-view numbers are corrupted one or two at a time (counts, offsets, strides, component types, view indices)
+import base64
+blob = bytearray(); views = []
+def _view(data, stride=None):
+    while len(blob) % 4: blob.append(0)
+    v = {"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)}
+    if stride: v["byteStride"] = stride
+    views.append(v); blob.extend(data); return len(views) - 1
+nv = 6
+v_pos = _view(np.arange(nv * 3, dtype="<f4").tobytes())
+v_spi, v_spv = _view(np.array([1, 4, 1], "<u2").tobytes()), _view(np.arange(9, dtype="<f4").tobytes())
+v_sp2i, v_sp2v = _view(np.array([0, 2, 3, 5], "<u1").tobytes()), _view(np.arange(12, dtype="<f4").tobytes())
+inter = bytearray()
+for k in range(nv): inter += np.array([k, -k, 3], np.int8).tobytes() + b"\0" + np.array([k * 1000, 65535 - k], "<u2").tobytes()
+v_inter = _view(bytes(inter), stride=8)
+v_suv = _view(np.arange(nv * 2, dtype="<i2").tobytes())
+v_idx = _view(np.array([0, 1, 2, 2, 1, 3, 4, 5, 0], "<u2").tobytes())
+sp_js = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 1]}], "nodes": [{"mesh": 0}, {"mesh": 1, "translation": [5, 0, 0]}],
+         "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 2, "TEXCOORD_0": 3}, "indices": 5, "material": 0}]},
+                    {"primitives": [{"attributes": {"POSITION": 1, "NORMAL": 2, "TEXCOORD_0": 4}, "indices": 5, "material": 0}]}],
+         "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [1.0, 0.5, 0.25, 1.0]}}],
+         "accessors": [
+             {"bufferView": v_pos, "componentType": 5126, "count": nv, "type": "VEC3",
+              "sparse": {"count": 3, "indices": {"bufferView": v_spi, "componentType": 5123}, "values": {"bufferView": v_spv}}},
+             {"componentType": 5126, "count": nv, "type": "VEC3",
+              "sparse": {"count": 4, "indices": {"bufferView": v_sp2i, "componentType": 5121}, "values": {"bufferView": v_sp2v}}},
+             {"bufferView": v_inter, "componentType": 5120, "normalized": True, "count": nv, "type": "VEC3"},
+             {"bufferView": v_inter, "byteOffset": 4, "componentType": 5123, "normalized": True, "count": nv, "type": "VEC2"},
+             {"bufferView": v_suv, "componentType": 5122, "normalized": True, "count": nv, "type": "VEC2"},
+             {"bufferView": v_idx, "componentType": 5123, "count": 9, "type": "SCALAR"}],
+         "bufferViews": views,
+         "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(bytes(blob)).decode()}]}
+open(f"{out}/ingest/s_ok.gltf", "w").write(json.dumps(sp_js))
+def _numeric_slots(o, path=()):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            if k in ("uri", "asset", "materials"): continue
+            yield from _numeric_slots(v, path + (k,))
+    elif isinstance(o, list):
+        for k, v in enumerate(o): yield from _numeric_slots(v, path + (k,))
+    elif isinstance(o, (int, float)) and not isinstance(o, bool):
+        yield path
+slots = list(_numeric_slots(sp_js))
+for i in range(400):
+    j2 = json.loads(json.dumps(sp_js))
+    for _ in range(1 + i % 2):
+        path = slots[int(rng.integers(0, len(slots)))]
+        o = j2
+        for k in path[:-1]: o = o[k]
+        o[path[-1]] = int(rng.choice([0, 1, 2, 3, 5, 7, 8, 255, 4096, 2**31, 2**32 - 1, 5120, 5121, 5123, 5125, 5126, int(rng.integers(0, 200))]))
+    open(f"{out}/ingest/s{i}.gltf", "w").write(json.dumps(j2))
