@@ -149,6 +149,7 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_build_bvh": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_int32)]),
     "rf_check_wide_layouts": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "rf_wide_layout_stats": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "rf_build_bvh_gpu": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "rf_create_camera": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Camera)]),
     "rf_fly_camera": (C.c_int, [C.c_void_p] + [C.c_float] * 6 + [C.POINTER(Camera)]),

@@ -633,6 +633,20 @@ int rf_check_wide_layouts(const void* nodes48, uint64_t num_nodes, uint32_t* fla
     });
 }
 
+int rf_wide_layout_stats(const void* nodes48, uint64_t num_nodes, uint32_t* flags_out, float* quad_half_area_ratio)
+{
+    return guarded([&] {
+        require(nodes48, "null argument");
+        std::span<const rf::BvhNode> nodes{static_cast<const rf::BvhNode*>(nodes48), static_cast<size_t>(num_nodes)};
+        rf::validateScene(nodes, static_cast<size_t>(-1), {}, 0);
+        float          ratio = 0.0f;
+        const uint32_t flags = rf::checkWideLayouts(nodes, &ratio);
+        if (flags_out) *flags_out = flags;
+        if (quad_half_area_ratio) *quad_half_area_ratio = ratio;
+        return RF_OK;
+    });
+}
+
 int rf_build_bvh_gpu(const float* positions36, uint64_t num_triangles, void* nodes_out, uint64_t* num_nodes_out, uint64_t* triangle_indices_out,
                      int32_t* depth_out, int32_t device_ordinal, float* build_ms_out)
 {

@@ -689,6 +689,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
     constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
     static_assert(!(COMPACT != 0 && COUNT), "the compact-record and quad-record variants have no counting build");
+    static_assert(COMPACT >= 0 && COMPACT <= 4, "0: 64-byte records, 1: compact-capable, 2: 32-byte, 3: quad, 4: half-precision quad");
     __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
@@ -717,6 +718,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     bool  haveOuter = false;
     // COMPACT == 2 (32-byte records): the t-values of all six planes of that node's box
     BoxT  own{};
+    // COMPACT == 4 (half-precision quad records): b = -(o / d) per axis, the addend of t' = fma(plane', 1/d, b)
+    float hbx = 0.0f, hby = 0.0f, hbz = 0.0f;
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
@@ -827,6 +830,27 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 rayTris = 0;
                 rayStackHigh = 0;
                 needScalar = rayClass == kRayIrregular;
+                if constexpr (COMPACT == 4)
+                {
+                    // the margin of the half-precision planes covers origins within wide.originBound and 1/direction components of
+                    // ordinary magnitude (or +-inf: those axes drop out as NaNs): anything else takes the scalar traversal
+                    const auto ordinary = [](float inv) { const float a = fabsf(inv); return (a >= 1e-18f && a <= 1e18f) || a == __uint_as_float(0x7F800000u); };
+                    const bool inside = fabsf(o.x) <= wide.originBound && fabsf(o.y) <= wide.originBound && fabsf(o.z) <= wide.originBound;
+                    if (!(inside && ordinary(ray.invDir.x) && ordinary(ray.invDir.y) && ordinary(ray.invDir.z))) needScalar = true;
+                    // An infinite 1/d (axis-parallel ray, class B) is replaced by +-1e30 IN THE CONSERVATIVE TESTS: the margin argument
+                    // does not depend on the size of 1/d, so the ray is still accepted wherever the reference accepts it (strictly inside
+                    // the slab: [-huge, +huge]; within the margin of a plane: accepted as well) and rejected when it is outside the
+                    // conservative slab by more than rounding -- instead of being left unconstrained on that axis, which sent such rays
+                    // through whole slices of the scene (and over the 12-entry stack: 150 x the scalar redos).  The leaf phase puts the
+                    // infinity back for its exact test (a genuine |1/d| of 1e30 never gets here: see `ordinary`).
+                    const float inf = __uint_as_float(0x7F800000u);
+                    if (fabsf(pr.iXY.x) == inf) pr.iXY.x = __builtin_copysignf(1e30f, pr.iXY.x);
+                    if (fabsf(pr.iXY.y) == inf) pr.iXY.y = __builtin_copysignf(1e30f, pr.iXY.y);
+                    if (fabsf(pr.iZ) == inf) pr.iZ = __builtin_copysignf(1e30f, pr.iZ);
+                    hbx = -(o.x * pr.iXY.x);
+                    hby = -(o.y * pr.iXY.y);
+                    hbz = -(o.z * pr.iZ);
+                }
                 float      rootTMin;
                 const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
                 node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
@@ -845,7 +869,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             if (static_cast<int32_t>(node) >= 0)
             {
                 if (COUNT) ++recordFetches;
-                if constexpr (COMPACT == 3)
+                if constexpr (COMPACT == 3 || COMPACT == 4)
                 {
                     // ---- quad records (rf_wide.hpp): the boxes of the node's (up to) four grandchildren in ONE 128-byte record --
                     // two levels of the reference's tree per dependent fetch.  Entries 0,1 belong to the first child, 2,3 to the
@@ -853,42 +877,79 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     float    tq0, tq1, tq2, tq3;
                     bool     okq0, okq1, okq2, okq3, hasNaN = false;
                     uint32_t w0, w1, w2, w3;
-                    const auto quadStep = [&](float4 a0, float4 a1, float4 a2, float4 a3, float4 a4, float4 a5) {
-                        float f0, f1, f2, f3;
-                        slabPairBounds(pr, a0, a1, a2, tq0, f0, tq1, f1);
-                        slabPairBounds(pr, a3, a4, a5, tq2, f2, tq3, f3);
-                        asm volatile("" : "+v"(tq0), "+v"(f0), "+v"(tq1), "+v"(f1), "+v"(tq2), "+v"(f2), "+v"(tq3), "+v"(f3)); // (min/max chains stay with their products: see slabStep)
-                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2) || slabPairHasNaN(pr, a3, a4, a5);
+                    if constexpr (COMPACT == 3)
+                    {
+                        const auto quadStep = [&](float4 a0, float4 a1, float4 a2, float4 a3, float4 a4, float4 a5) {
+                            float f0, f1, f2, f3;
+                            slabPairBounds(pr, a0, a1, a2, tq0, f0, tq1, f1);
+                            slabPairBounds(pr, a3, a4, a5, tq2, f2, tq3, f3);
+                            asm volatile("" : "+v"(tq0), "+v"(f0), "+v"(tq1), "+v"(f1), "+v"(tq2), "+v"(f2), "+v"(tq3), "+v"(f3)); // (min/max chains stay with their products: see slabStep)
+                            if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2) || slabPairHasNaN(pr, a3, a4, a5);
+                            okq0 = tq0 <= f0 && f0 > 0.0f;
+                            okq1 = tq1 <= f1 && f1 > 0.0f;
+                            okq2 = tq2 <= f2 && f2 > 0.0f;
+                            okq3 = tq3 <= f3 && f3 > 0.0f;
+                        };
+                        const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
+                        if (uniformFetch && __ballot(node != uNode) == 0ull)
+                        {
+                            typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+                            typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+                            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                            const float4* un = wide.quad + 8 * static_cast<size_t>(uNode);
+                            u16v          a;
+                            u8v           b;
+                            u4v           c;
+                            asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&s"(a), "=&s"(b), "=&s"(c)
+                                         : "s"(un)
+                                         : "memory");
+                            const auto f4 = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w)); };
+                            quadStep(f4(a.s0, a.s1, a.s2, a.s3), f4(a.s4, a.s5, a.s6, a.s7), f4(a.s8, a.s9, a.sa, a.sb), f4(a.sc, a.sd, a.se, a.sf), f4(b.s0, b.s1, b.s2, b.s3),
+                                     f4(b.s4, b.s5, b.s6, b.s7));
+                            w0 = c.x, w1 = c.y, w2 = c.z, w3 = c.w;
+                        }
+                        else
+                        {
+                            const float4* n = wide.quad + 8 * static_cast<size_t>(node);
+                            const float4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3], v4 = n[4], v5 = n[5], v6 = n[6];
+                            w0 = __float_as_uint(v6.x), w1 = __float_as_uint(v6.y), w2 = __float_as_uint(v6.z), w3 = __float_as_uint(v6.w);
+                            quadStep(v0, v1, v2, v3, v4, v5);
+                        }
+                    }
+                    else
+                    {
+                        // ---- half-precision quad records (rf_wide.hpp, WideBuild::quadHalf): the same four entries, planes as binary16,
+                        // 64 bytes -- four loads.  CONSERVATIVE tests (a superset passes; the leaf phase applies the exact boxes).
+                        const float bx = hbx, by = hby, bz = hbz;
+                        float       f0, f1, f2, f3;
+                        const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
+                        if (uniformFetch && __ballot(node != uNode) == 0ull)
+                        {
+                            typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+                            const uint4*     un = wide.quadHalf + 4 * static_cast<size_t>(uNode);
+                            u16v             a;
+                            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(un) : "memory");
+                            halfEntryBounds<true>(a.s0, a.s1, a.s2, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
+                            halfEntryBounds<true>(a.s3, a.s4, a.s5, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
+                            halfEntryBounds<true>(a.s6, a.s7, a.s8, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
+                            halfEntryBounds<true>(a.s9, a.sa, a.sb, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
+                            w0 = a.sc, w1 = a.sd, w2 = a.se, w3 = a.sf;
+                        }
+                        else
+                        {
+                            const uint4* n = wide.quadHalf + 4 * static_cast<size_t>(node);
+                            const uint4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3];
+                            halfEntryBounds<false>(v0.x, v0.y, v0.z, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
+                            halfEntryBounds<false>(v0.w, v1.x, v1.y, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
+                            halfEntryBounds<false>(v1.z, v1.w, v2.x, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
+                            halfEntryBounds<false>(v2.y, v2.z, v2.w, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
+                            w0 = v3.x, w1 = v3.y, w2 = v3.z, w3 = v3.w;
+                        }
                         okq0 = tq0 <= f0 && f0 > 0.0f;
                         okq1 = tq1 <= f1 && f1 > 0.0f;
                         okq2 = tq2 <= f2 && f2 > 0.0f;
                         okq3 = tq3 <= f3 && f3 > 0.0f;
-                    };
-                    const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
-                    if (uniformFetch && __ballot(node != uNode) == 0ull)
-                    {
-                        typedef uint32_t u16v __attribute__((ext_vector_type(16)));
-                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                        const float4* un = wide.quad + 8 * static_cast<size_t>(uNode);
-                        u16v          a;
-                        u8v           b;
-                        u4v           c;
-                        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&s"(a), "=&s"(b), "=&s"(c)
-                                     : "s"(un)
-                                     : "memory");
-                        const auto f4 = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w)); };
-                        quadStep(f4(a.s0, a.s1, a.s2, a.s3), f4(a.s4, a.s5, a.s6, a.s7), f4(a.s8, a.s9, a.sa, a.sb), f4(a.sc, a.sd, a.se, a.sf), f4(b.s0, b.s1, b.s2, b.s3),
-                                 f4(b.s4, b.s5, b.s6, b.s7));
-                        w0 = c.x, w1 = c.y, w2 = c.z, w3 = c.w;
-                    }
-                    else
-                    {
-                        const float4* n = wide.quad + 8 * static_cast<size_t>(node);
-                        const float4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3], v4 = n[4], v5 = n[5], v6 = n[6];
-                        w0 = __float_as_uint(v6.x), w1 = __float_as_uint(v6.y), w2 = __float_as_uint(v6.z), w3 = __float_as_uint(v6.w);
-                        quadStep(v0, v1, v2, v3, v4, v5);
                     }
                     if (__builtin_expect(hasNaN, 0))
                     {
@@ -1209,6 +1270,37 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             bool finished = false;
             if (COUNT) ++wLeafPhase;
+            float4 firstA{}, firstB{}, firstC{};
+            if constexpr (COMPACT == 4)
+            {
+                // The half-precision quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
+                // test its box, exactly, with its own formula, against the rayTMax of this moment -- happens here.  The leaf's box
+                // rides in the spare floats of its first triangle record (leafBoxesIntoTriangles): the same 64-byte line.
+                const float4* t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
+                firstA = t0[0], firstB = t0[1], firstC = t0[2];
+                const v3f hi = *reinterpret_cast<const v3f*>(t0 + 3);
+                float     bn, bf;
+                bool      boxNaN;
+                PackedRay exact = pr;
+                if (__builtin_expect((negMask & 8u) != 0u, 0))
+                {
+                    // class B: the infinite components of 1/d that the conservative tests replaced by +-1e30 (refill) are infinite again
+                    const float inf = __uint_as_float(0x7F800000u);
+                    if (fabsf(exact.iXY.x) == 1e30f) exact.iXY.x = __builtin_copysignf(inf, exact.iXY.x);
+                    if (fabsf(exact.iXY.y) == 1e30f) exact.iXY.y = __builtin_copysignf(inf, exact.iXY.y);
+                    if (fabsf(exact.iZ) == 1e30f) exact.iZ = __builtin_copysignf(inf, exact.iZ);
+                }
+                slabSingleBounds(exact, firstA.w, firstB.w, firstC.w, hi.x, hi.y, hi.z, bn, bf, boxNaN);
+                if (__builtin_expect((negMask & 8u) != 0u && boxNaN, 0))
+                {
+                    // class B ray with a 0 * inf product at this box: the reference's NaN rules apply -- the whole ray is redone by
+                    // the scalar traversal (as the exact-record kernels do for any step with such a product)
+                    needScalar = true;
+                    stackSize = 0;
+                    n = 0;
+                }
+                else if (!(bn <= bf && bf > 0.0f && bn < rayTMax)) n = 0; // the reference rejects this leaf: no triangle is tested
+            }
             for (uint32_t i = 0; i < n; ++i)
             {
                 if (COUNT) ++wLeaf;
@@ -1216,7 +1308,11 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 Vec3           p0, p1, p2;
                 // the same triangle in every lane of this leaf phase (one pixel's samples reaching the same leaf): scalar cache
                 const uint32_t uTri = __builtin_amdgcn_readfirstlane(tri);
-                if (uniformTri && __ballot(tri != uTri) == 0ull)
+                if (COMPACT == 4 && i == 0u)
+                {
+                    p0 = vec3(firstA.x, firstA.y, firstA.z), p1 = vec3(firstB.x, firstB.y, firstB.z), p2 = vec3(firstC.x, firstC.y, firstC.z);
+                }
+                else if (uniformTri && __ballot(tri != uTri) == 0ull)
                 {
                     typedef uint32_t u8v __attribute__((ext_vector_type(8)));
                     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -2011,6 +2107,7 @@ struct Renderer::Impl
     hipStream_t stream = nullptr;
 
     DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact, wideHot, wideOwn, wideQuad;
+    DeviceBuffer<uint4>             wideQuadHalf;
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
     DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
@@ -2071,6 +2168,8 @@ struct Renderer::Impl
     uint32_t               optCompactShadowFromBounce = 2; // ... and the shadow launches of bounce >= this
     uint32_t               optQuadFromBounce = 1, optQuadShadowFromBounce = 1; // the 128-byte quad records (two levels per fetch) from this bounce on (0: never); takes precedence over the others
     uint32_t               optQuadExceptMask = 0, optQuadShadowExceptMask = 0; // ... except at the bounces whose bit (bounce - 1) is set here
+    uint32_t               optQuadHalfFromBounce = 0, optQuadHalfShadowFromBounce = 0; // quad launches of bounce >= this read the 64-byte half-precision quad records (0: never; set to 1 at upload when the scene suits them)
+    float                  quadHalfAreaRatio = 0.0f;
     uint32_t               optHotFromBounce = 0, optHotShadowFromBounce = 0; // the 32-byte records (all six planes carried) from this bounce on (0: never); takes precedence
     int                    optQueryCompact = 0;            // the ray-query entry points use the compact-capable (1) / 32-byte (2) records too (tests)
     uint32_t               optExtraLds = 0;      // experiment: dynamic LDS bytes added to the kTraceWide launches (lowers the occupancy)
@@ -2286,7 +2385,13 @@ struct Renderer::Impl
             RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
             RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
-            if (shadowNearestFirst && optQueryCompact == 3 && wide.quad != nullptr)
+            if (shadowNearestFirst && optQueryCompact == 4 && wide.quadHalf != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (optQueryCompact == 4 && wide.quadHalf != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (shadowNearestFirst && optQueryCompact == 3 && wide.quad != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
             else if (optQueryCompact == 3 && wide.quad != nullptr)
@@ -2307,7 +2412,10 @@ struct Renderer::Impl
         }
         else
         {
-            if (optQueryCompact == 3 && wide.quad != nullptr)
+            if (optQueryCompact == 4 && wide.quadHalf != nullptr)
+                hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+            else if (optQueryCompact == 3 && wide.quad != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
             else if (optQueryCompact == 2 && wide.hot != nullptr)
@@ -2415,6 +2523,10 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (bounce <= optPacketBounces)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
+                else if (wide.quadHalf != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
+                         optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce)
+                    hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
@@ -2455,6 +2567,10 @@ struct Renderer::Impl
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+                    else if (wide.quadHalf != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
+                             optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce)
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
                         hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
@@ -2553,6 +2669,18 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             m.wideQuad.upload(wb.quad.data(), wb.quad.size());
             m.wide.quad = m.wideQuad.ptr;
         }
+        m.wide.quadHalf = nullptr;
+        m.wide.originBound = wb.originBound;
+        if (!wb.quadHalf.empty())
+        {
+            m.wideQuadHalf.upload(wb.quadHalf.data(), wb.quadHalf.size());
+            m.wide.quadHalf = m.wideQuadHalf.ptr;
+            // default: every quad launch reads the half-precision records -- unless the binary16 grid is too coarse for this scene
+            // (its boxes' surface area, i.e. the number of boxes a ray hits, grows by more than 13 % / 7 %): then the exact quad records
+            m.optQuadHalfFromBounce = wb.quadHalfAreaRatio <= kQuadHalfMaxAreaRatio ? 1u : 0u;
+            m.optQuadHalfShadowFromBounce = wb.quadHalfAreaRatio <= kQuadHalfShadowMaxAreaRatio ? 1u : 0u;
+            m.quadHalfAreaRatio = wb.quadHalfAreaRatio;
+        }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
         m.wide.rootHi = wb.rootHi;
@@ -2571,6 +2699,8 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             padded[kTriStride * i + 1] = make_float4(t.p1.x, t.p1.y, t.p1.z, 0.0f);
             padded[kTriStride * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
         }
+        // ... and the exact box of every leaf in the spare floats of its first triangle (read by the half-precision quad kernels)
+        leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n);
         m.triangles.upload(padded.data(), padded.size());
     }
     {
@@ -2838,7 +2968,7 @@ void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, ui
     pathsAllocated = m.allocatedPaths;
     pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
     maxPathsPerBatch = m.maxPaths;
-    sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
+    sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
                  m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2);
 }
 uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }
@@ -2973,6 +3103,8 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "query_compact") mImpl->optQueryCompact = static_cast<int>(value);
     else if (name == "quad_from_bounce") mImpl->optQuadFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "quad_shadow_from_bounce") mImpl->optQuadShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "quad_half_from_bounce") mImpl->optQuadHalfFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "quad_half_shadow_from_bounce") mImpl->optQuadHalfShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "quad_except_mask") mImpl->optQuadExceptMask = static_cast<uint32_t>(value);
     else if (name == "quad_shadow_except_mask") mImpl->optQuadShadowExceptMask = static_cast<uint32_t>(value);
     else if (name == "hot_from_bounce") mImpl->optHotFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
@@ -3158,13 +3290,46 @@ void Renderer::occludedRays(const float* rays6, uint64_t numRays, float tMax, fl
     RF_HIP(hipStreamSynchronize(m.stream));
     RF_HIP(hipMemcpy(visibilityOut, vis.ptr, numRays * 4, hipMemcpyDeviceToHost));
 }
-uint32_t checkWideLayouts(std::span<const BvhNode> nodes)
+uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRatio)
 {
     if (nodes.empty()) throw std::runtime_error("checkWideLayouts: no nodes");
     const WideBuild wb = buildWide(nodes.data(), nodes.size());
-    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u) | (!wb.quad.empty() ? 8u : 0u);
+    if (quadHalfAreaRatio) *quadHalfAreaRatio = wb.quadHalf.empty() ? 0.0f : wb.quadHalfAreaRatio;
+    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u) | (!wb.quad.empty() ? 8u : 0u) | (!wb.quadHalf.empty() ? 16u : 0u);
     const size_t    records = wb.nodes.size() / 4;
     const auto      fail = [](size_t r, const char* what) { throw std::runtime_error("wide layout mismatch at record " + std::to_string(r) + ": " + what); };
+    if (!wb.quadHalf.empty())
+    {
+        // The half-precision quad records: same words as the f32 quad records, every binary16 plane on the conservative side of the f32
+        // plane by at least the margin of the proof (rf_wide.hpp), never subnormal, finite.
+        if (wb.quadHalf.size() * 2 != wb.quad.size()) throw std::runtime_error("wide layout mismatch: half-precision quad records do not pair up with the quad records");
+        double R = 0.0;
+        for (const float c : {wb.rootLo.x, wb.rootLo.y, wb.rootLo.z, wb.rootHi.x, wb.rootHi.y, wb.rootHi.z}) R = std::max(R, static_cast<double>(std::fabs(c)));
+        const double margin = 1.1920928955078125e-07 * (4.0 * static_cast<double>(wb.originBound) + 3.0 * R) * 1.0001; // what the proof needs (the builder leaves twice that)
+        if (!(static_cast<double>(wb.originBound) >= 4.0 * R)) throw std::runtime_error("wide layout mismatch: origin bound of the half-precision quad records");
+        for (size_t r = 0; r < wb.quadHalf.size() / 4; ++r)
+        {
+            const float4* q = &wb.quad[8 * r];
+            const uint4*  h = &wb.quadHalf[4 * r];
+            const uint32_t d[16] = {h[0].x, h[0].y, h[0].z, h[0].w, h[1].x, h[1].y, h[1].z, h[1].w, h[2].x, h[2].y, h[2].z, h[2].w, h[3].x, h[3].y, h[3].z, h[3].w};
+            if (d[12] != floatBits(q[6].x) || d[13] != floatBits(q[6].y) || d[14] != floatBits(q[6].z) || d[15] != floatBits(q[6].w)) fail(r, "half-precision quad record: words differ");
+            for (int k = 0; k < 2; ++k)
+            {
+                const float4 a = q[3 * k], z = q[3 * k + 1], b = q[3 * k + 2];
+                const float  lo[2][3] = {{a.x, a.y, z.x}, {b.x, b.y, z.z}}, hi[2][3] = {{a.z, a.w, z.y}, {b.z, b.w, z.w}};
+                for (int j = 0; j < 2; ++j)
+                    for (int ax = 0; ax < 3; ++ax)
+                    {
+                        const uint32_t w = d[3 * (2 * k + j) + ax];
+                        const uint16_t l16 = static_cast<uint16_t>(w & 0xFFFFu), h16 = static_cast<uint16_t>(w >> 16);
+                        for (const uint16_t v : {l16, h16})
+                            if (((v >> 10) & 0x1Fu) == 0x1Fu || (((v >> 10) & 0x1Fu) == 0u && (v & 0x3FFu) != 0u)) fail(r, "half-precision quad record: a plane is not a normal number or zero");
+                        if (!(static_cast<double>(halfBitsToFloat(l16)) <= static_cast<double>(lo[j][ax]) - margin)) fail(r, "half-precision quad record: a lower plane is not below its f32 plane by the margin");
+                        if (!(static_cast<double>(halfBitsToFloat(h16)) >= static_cast<double>(hi[j][ax]) + margin)) fail(r, "half-precision quad record: an upper plane is not above its f32 plane by the margin");
+                    }
+            }
+        }
+    }
     if (!wb.quad.empty())
     {
         // Walk the quad records from the root next to the 64-byte records: the entries of a quad record must be the children of

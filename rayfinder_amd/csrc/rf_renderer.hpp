@@ -177,5 +177,5 @@ private:
 // compact-capable / 32-byte variants and verifies that every variant decodes to the same child planes and child words as the
 // plain record, and that the carried "own" planes are the union of the children's.  Returns bit 0: boxes regular (wide layout
 // usable), bit 1: compact-capable records usable, bit 2: 32-byte records usable; throws std::runtime_error on a mismatch.
-uint32_t checkWideLayouts(std::span<const BvhNode> nodes);
+uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRatio = nullptr);
 } // namespace rf

@@ -32,7 +32,10 @@
 
 #include "rf_device.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <initializer_list>
+#include <limits>
 #include <vector>
 
 namespace rf
@@ -41,6 +44,10 @@ constexpr uint32_t kWideLeafBit = 0x80000000u;
 constexpr uint32_t kWideIndexBits = 26;  // record / first-triangle / big-leaf index
 constexpr uint32_t kWideAxisShift = 29;  // bits 30..29 of the FIRST child word carry the node's split axis
 constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is interior
+// half-precision quad records by default where WideBuild::quadHalfAreaRatio stays below these (tools/half_ratio_sweep.py on the atrium at
+// tessellation scales 1 / 2 / 3 / 4 / 6 / 8 = ratios 1.035 / 1.063 / 1.089 / 1.117 / 1.166 / 1.223: closest-hit -12 / -12 / -11 / -7 / 0 / +8 %,
+// shadow -4 / -1 / +4 / +12 / +33 / +52 %)
+constexpr float    kQuadHalfMaxAreaRatio = 1.13f, kQuadHalfShadowMaxAreaRatio = 1.07f;
 constexpr uint32_t kQuadEmpty = 0xFFFFFFFFu; // quad records: an entry slot that holds no node (its child is a leaf and fills one slot only)
 #if defined(RF_EXP_WAVES)
 constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment builds: resident workgroups per CU of kTraceWide
@@ -58,6 +65,8 @@ struct WideScene
     const float4* hot;       // 2 float4 per interior node: the 32-byte records of the all-planes-carried layout (see buildWide), or nullptr
     const float4* own;       // 2 float4 per interior node: the node's own box {lo.x lo.y hi.x hi.y} {lo.z hi.z - -} (read after a pop only)
     const float4* quad;      // 8 float4 per quad record: TWO levels in one 128-byte record (see buildWide), or nullptr
+    const uint4*  quadHalf;  // 4 uint4 per quad record: the same records with CONSERVATIVE half-precision planes, 64 bytes (see buildWide), or nullptr
+    float         originBound; // quadHalf: rays whose origin has a coordinate beyond this magnitude take the scalar traversal (margin proof)
     const uint2*  bigLeaves; // {first triangle, count}
     float4        rootLo;    // root box (w unused)
     float4        rootHi;
@@ -91,6 +100,27 @@ struct WideBuild
     // subtrees the reference enters, in its order.  Not for the counting build (nodesVisited counts the skipped level).
     std::vector<float4> quad;
     bool                quadUsable = true; // every plane of every interior node is attained by one of its children (unions), indices fit
+    // Half-precision quad records (kTraceWide<..., COMPACT = 4>): the quad records with their 24 planes stored as IEEE binary16,
+    // 64 bytes -- four 16-byte loads per step instead of seven, half the bytes from L2:
+    //     dword 3e + a (entry e = 0..3, axis a = 0..2) = {lo plane in the low half, hi plane in the high half};  dwords 12..15 = the quad record's words.
+    // The planes are CONSERVATIVE: lo' <= lo - margin (rounded down to binary16), hi' >= hi + margin (rounded up); never subnormal.
+    // The step evaluates t' = fma(plane', 1/d, -(o * 1/d)) in one v_fma_mix_f32 per plane (binary16 source, f32 result: no decode
+    // instruction) where the reference evaluates t = ((plane - o) * 1/d) with two roundings.  With u = 2^-24, |o| <= originBound and
+    // |plane| <= R (the root box):  t' <= T' + u |o / d| + u |t'|  and  t >= T - 2u |T|  for the real values T' = (plane' - o) / d,
+    // T = (plane - o) / d, so  margin >= u (4 originBound + 3 R + margin)  makes every near t' <= its t and every far t' >= its t
+    // (margin = 2^-21 (originBound + R): twice that).  NaNs (an axis-parallel ray: inf - inf) drop out of v_min / v_max, i.e. that
+    // axis does not constrain: conservative as well.  So a quad-half step accepts a SUPERSET of what the exact step accepts --
+    // which is all an interior test has to do, because every LEAF is then tested against its EXACT box (kept in the spare floats
+    // of the leaf's first 64-byte triangle record: leafBoxesIntoTriangles) with the reference's formula, a leaf's exact slab
+    // interval lies inside every ancestor's (boxes are unions, rounding is monotone), and entries are visited in the same order:
+    // the same leaves have their triangles tested, in the same order, against the same rayTMax.
+    std::vector<uint4>  quadHalf;
+    float               originBound = 0.0f;
+    // sum of the surface areas of the half-precision boxes / of the exact boxes, over all entries: how many more boxes a random ray
+    // hits because of the binary16 grid (absolute coordinates: ~2^-11 of the coordinate's magnitude).  The renderer uses the half records
+    // by default only where this stays below kQuadHalfMaxAreaRatio / kQuadHalfShadowMaxAreaRatio (a 17 M-triangle scene of centimetre
+    // triangles: 1.22 -> slower).
+    float               quadHalfAreaRatio = 0.0f;
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
@@ -98,6 +128,43 @@ struct WideBuild
 };
 
 // Host: 48-byte reference nodes -> wide records.
+// binary16 <-> f32 for the half-precision quad records (host side; normal numbers and zero only: the builder never emits a subnormal)
+inline float halfBitsToFloat(uint16_t h)
+{
+    const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    if (e == 0) return bitsFloat(sign); // (+-0; subnormals are not produced)
+    return bitsFloat(sign | ((e + 112u) << 23) | (m << 13));
+}
+// the largest binary16 <= v (down = true) / the smallest binary16 >= v (down = false); |v| must be finite; `ok` = false beyond +-65504
+inline uint16_t halfDirected(float v, bool down, bool& ok)
+{
+    if (!(std::fabs(v) <= 65504.0f)) { ok = false; return 0; }
+    if (v == 0.0f) return 0;
+    const bool neg = v < 0.0f;
+    if (std::fabs(v) < 6.103515625e-05f) // below the smallest normal binary16 (2^-14): 0 or +-2^-14, whichever lies on the requested side
+        return (neg == down) ? static_cast<uint16_t>((neg ? 0x8000u : 0u) | 0x0400u) : static_cast<uint16_t>(0);
+    const uint32_t b = floatBits(std::fabs(v));
+    uint32_t       h = (((b >> 23) - 112u) << 10) | ((b >> 13) & 0x3FFu); // magnitude truncated towards zero
+    const bool     inexact = (b & 0x1FFFu) != 0u;
+    if (inexact && (neg == down)) ++h; // away from zero on the side that was asked for
+    if (h > 0x7BFFu) { ok = false; return 0; }
+    return static_cast<uint16_t>((neg ? 0x8000u : 0u) | h);
+}
+
+// The EXACT box of every leaf, written into the spare floats of the leaf's FIRST device triangle record (64 bytes: {p0 .} {p1 .} {p2 .}
+// {. . . .}):  lo = (record[0].w, record[1].w, record[2].w),  hi = record[3].xyz.  Read by the half-precision quad kernels only.
+inline void leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles)
+{
+    for (size_t i = 0; i < count; ++i)
+    {
+        const BvhNode& n = nodes[i];
+        if (n.triangleCount == 0 || n.trianglesOffset >= numTriangles) continue;
+        float4* t = triangles + 4 * static_cast<size_t>(n.trianglesOffset);
+        t[0].w = n.aabb.min.x, t[1].w = n.aabb.min.y, t[2].w = n.aabb.min.z;
+        t[3] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, 0.0f);
+    }
+}
+
 inline WideBuild buildWide(const BvhNode* nodes, size_t count)
 {
     WideBuild             out;
@@ -280,6 +347,68 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
     if (out.bigLeaves.empty()) out.bigLeaves.push_back(make_uint2(0, 0));
     if (!out.boxesRegular || numInterior == 0) out.quadUsable = false;
     if (!out.quadUsable) out.quad.clear();
+    if (!out.quad.empty())
+    {
+        // ---- half-precision quad records (see WideBuild::quadHalf)
+        double R = 0.0;
+        for (const float c : {out.rootLo.x, out.rootLo.y, out.rootLo.z, out.rootHi.x, out.rootHi.y, out.rootHi.z}) R = std::max(R, static_cast<double>(std::fabs(c)));
+        const double bound = 4.0 * R + 1.0;
+        out.originBound = static_cast<float>(bound);
+        if (static_cast<double>(out.originBound) > bound) out.originBound = std::nextafterf(out.originBound, 0.0f);
+        const double margin = (static_cast<double>(out.originBound) + R) * 4.76837158203125e-07; // 2^-21
+        const size_t numQuad = out.quad.size() / 8;
+        out.quadHalf.assign(4 * numQuad, make_uint4(0u, 0u, 0u, 0u));
+        bool ok = true;
+        const auto lower = [&](float v) { // the largest f32 <= v - margin, then down to binary16
+            const double target = static_cast<double>(v) - margin;
+            float        f = static_cast<float>(target);
+            if (static_cast<double>(f) > target) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+            return halfDirected(f, true, ok);
+        };
+        const auto upper = [&](float v) {
+            const double target = static_cast<double>(v) + margin;
+            float        f = static_cast<float>(target);
+            if (static_cast<double>(f) < target) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+            return halfDirected(f, false, ok);
+        };
+        double areaExact = 0.0, areaHalf = 0.0;
+        const auto area = [](const double lo[3], const double hi[3]) {
+            const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+            return 2.0 * (ex * ey + ey * ez + ez * ex);
+        };
+        for (size_t r = 0; r < numQuad && ok; ++r)
+        {
+            const float4* q = &out.quad[8 * r];
+            uint32_t      d[16];
+            for (int k = 0; k < 2; ++k) // entries 2k, 2k + 1 (see the quad layout above)
+            {
+                const float4 a = q[3 * k], z = q[3 * k + 1], b = q[3 * k + 2];
+                const float  lo[2][3] = {{a.x, a.y, z.x}, {b.x, b.y, z.z}}, hi[2][3] = {{a.z, a.w, z.y}, {b.z, b.w, z.w}};
+                for (int j = 0; j < 2; ++j)
+                    for (int ax = 0; ax < 3; ++ax)
+                        d[3 * (2 * k + j) + ax] = static_cast<uint32_t>(lower(lo[j][ax])) | (static_cast<uint32_t>(upper(hi[j][ax])) << 16);
+            }
+            d[12] = floatBits(q[6].x), d[13] = floatBits(q[6].y), d[14] = floatBits(q[6].z), d[15] = floatBits(q[6].w);
+            for (int k = 0; k < 4; ++k) out.quadHalf[4 * r + k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+            for (int e = 0; e < 4 && ok; ++e)
+            {
+                if (d[12 + e] == kQuadEmpty) continue;
+                const int    k = e / 2, j = e % 2;
+                const float4 a = q[3 * k], z = q[3 * k + 1], b = q[3 * k + 2];
+                const double lo[3] = {j ? b.x : a.x, j ? b.y : a.y, j ? z.z : z.x}, hi[3] = {j ? b.z : a.z, j ? b.w : a.w, j ? z.w : z.y};
+                double       hlo[3], hhi[3];
+                for (int ax = 0; ax < 3; ++ax)
+                {
+                    hlo[ax] = halfBitsToFloat(static_cast<uint16_t>(d[3 * e + ax] & 0xFFFFu));
+                    hhi[ax] = halfBitsToFloat(static_cast<uint16_t>(d[3 * e + ax] >> 16));
+                }
+                areaExact += area(lo, hi);
+                areaHalf += area(hlo, hhi);
+            }
+        }
+        out.quadHalfAreaRatio = areaExact > 0.0 ? static_cast<float>(areaHalf / areaExact) : 1.0f;
+        if (!ok) out.quadHalf.clear(); // a coordinate beyond the binary16 range: the f32 quad records serve
+    }
     if (!out.boxesRegular) out.compactUsable = false;
     if (!out.compactUsable || numInterior == 0) out.compact.clear();
     if (!out.boxesRegular) out.hotUsable = false;
@@ -495,6 +624,35 @@ __device__ __forceinline__ bool slabPairCompactHasNaN(const PackedRay& r, float4
     const float cx = (q1.x - r.oZ) * r.iZ, cy = (q1.y - r.oZ) * r.iZ, dx = (q1.z - r.oZ) * r.iZ, dy = (q1.w - r.oZ) * r.iZ;
     return __builtin_isunordered(c0LoX, c0HiX) || __builtin_isunordered(c1LoX, c1HiX) || __builtin_isunordered(ay, by) || __builtin_isunordered(cx, cy) ||
            __builtin_isunordered(dx, dy) || __builtin_isunordered(ey, fy);
+}
+
+// Half-precision quad records: t' = fma(plane', inv, b) with plane' the low / high binary16 half of `h` (converted exactly), one
+// rounding (v_fma_mix_f32: no decode instruction).  The S variants take the word from an SGPR (wave-uniform steps).
+__device__ __forceinline__ float fmixLo(uint32_t h, float inv, float b) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(inv), "v"(b)); return r; }
+__device__ __forceinline__ float fmixHi(uint32_t h, float inv, float b) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(inv), "v"(b)); return r; }
+__device__ __forceinline__ float fmixLoS(uint32_t h, float inv, float b) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "s"(h), "v"(inv), "v"(b)); return r; }
+__device__ __forceinline__ float fmixHiS(uint32_t h, float inv, float b) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "s"(h), "v"(inv), "v"(b)); return r; }
+// conservative [near, far] of one entry from its three plane words (x, y, z); NaNs drop out of v_min / v_max (see WideBuild::quadHalf)
+template<bool SCALAR>
+__device__ __forceinline__ void halfEntryBounds(uint32_t wx, uint32_t wy, uint32_t wz, float ix, float iy, float iz, float bx, float by, float bz, float& near, float& far)
+{
+    const float lx = SCALAR ? fmixLoS(wx, ix, bx) : fmixLo(wx, ix, bx), hx = SCALAR ? fmixHiS(wx, ix, bx) : fmixHi(wx, ix, bx);
+    const float ly = SCALAR ? fmixLoS(wy, iy, by) : fmixLo(wy, iy, by), hy = SCALAR ? fmixHiS(wy, iy, by) : fmixHi(wy, iy, by);
+    const float lz = SCALAR ? fmixLoS(wz, iz, bz) : fmixLo(wz, iz, bz), hz = SCALAR ? fmixHiS(wz, iz, bz) : fmixHi(wz, iz, bz);
+    near = isaMax3(isaMin(lx, hx), isaMin(ly, hy), isaMin(lz, hz));
+    far = isaMin3(isaMax(lx, hx), isaMax(ly, hy), isaMax(lz, hz));
+}
+// The EXACT slab bounds of one box (a leaf's, from its triangle record) in the packed arithmetic of slabPairBounds: same planes, same
+// (plane - o) * inv per plane, so the same decisions as the reference's whenever no product is NaN; `hasNaN` says whether one is.
+__device__ __forceinline__ void slabSingleBounds(const PackedRay& r, float loX, float loY, float loZ, float hiX, float hiY, float hiZ, float& near, float& far, bool& hasNaN)
+{
+    const v2f oZZ = v2f{r.oZ, r.oZ}, iZZ = v2f{r.iZ, r.iZ};
+    const v2f a = (v2f{loX, loY} - r.oXY) * r.iXY; // t(lo.x), t(lo.y)
+    const v2f b = (v2f{hiX, hiY} - r.oXY) * r.iXY; // t(hi.x), t(hi.y)
+    const v2f c = (v2f{loZ, hiZ} - oZZ) * iZZ;     // t(lo.z), t(hi.z)
+    near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)), __builtin_fminf(c.x, c.y));
+    far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(c.x, c.y));
+    hasNaN = __builtin_isunordered(a.x, a.y) || __builtin_isunordered(b.x, b.y) || __builtin_isunordered(c.x, c.y);
 }
 
 // Class B lanes only: is any of the twelve slab products of this record NaN (0 * inf)?
