@@ -178,8 +178,8 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *   compact_from_bounce, compact_shadow_from_bounce   first bounce whose closest-hit / shadow launch reads the compact-capable records
  *                                      (three loads per descending step; defaults 3 / 2; 0 = never)
  *   hot_from_bounce, hot_shadow_from_bounce           the same for the 32-byte records (two loads per step; default 0 = never)
- *   refill_min, refill_min_deep, refill_deep_from_bounce   idle lanes at which a wave refills (40; closest-hit launches from bounce 3 on: 40 as well with the
- *                                      quad records -- 22 was best with the 64-byte records)
+ *   refill_min, refill_min_deep, refill_deep_from_bounce   idle lanes at which a wave refills (40; closest-hit launches from bounce 3 on: 22 on the 64-byte and the
+ *                                      half-precision quad records, 40 on the exact quad records)
  *   leaf_vote                          descending lanes below which a wave processes its parked leaves (20)
  *   chunk, chunk_early, chunk_early_bounces   queue entries per cursor claim (128; 256 at bounces 1-2)
  *   shade_sort_from_bounce             first bounce whose shading stage appends each 1024-entry tile's surviving paths in the order of

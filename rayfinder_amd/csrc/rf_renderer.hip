@@ -720,6 +720,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     BoxT  own{};
     // COMPACT == 4 (half-precision quad records): b = -(o / d) per axis, the addend of t' = fma(plane', 1/d, b)
     float hbx = 0.0f, hby = 0.0f, hbz = 0.0f;
+    uint32_t hrot = 0u; // ... and (1/d.x < 0) << 4 | (1/d.y < 0) << 12 | (1/d.z < 0) << 20: rotate amounts that bring a plane word's NEAR plane into its low half
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
@@ -850,6 +851,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     hbx = -(o.x * pr.iXY.x);
                     hby = -(o.y * pr.iXY.y);
                     hbz = -(o.z * pr.iZ);
+                    hrot = (ray.negX << 4) | (ray.negY << 12) | (ray.negZ << 20);
                 }
                 float      rootTMin;
                 const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
@@ -921,7 +923,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     {
                         // ---- half-precision quad records (rf_wide.hpp, WideBuild::quadHalf): the same four entries, planes as binary16,
                         // 64 bytes -- four loads.  CONSERVATIVE tests (a superset passes; the leaf phase applies the exact boxes).
-                        const float bx = hbx, by = hby, bz = hbz;
+                        const float    bx = hbx, by = hby, bz = hbz;
+                        const uint32_t rx = hrot, ry = hrot >> 8, rz = hrot >> 16;
                         float       f0, f1, f2, f3;
                         const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
                         if (uniformFetch && __ballot(node != uNode) == 0ull)
@@ -930,20 +933,20 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                             const uint4*     un = wide.quadHalf + 4 * static_cast<size_t>(uNode);
                             u16v             a;
                             asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(un) : "memory");
-                            halfEntryBounds<true>(a.s0, a.s1, a.s2, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
-                            halfEntryBounds<true>(a.s3, a.s4, a.s5, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
-                            halfEntryBounds<true>(a.s6, a.s7, a.s8, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
-                            halfEntryBounds<true>(a.s9, a.sa, a.sb, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
+                            halfEntryBounds<true>(a.s0, a.s1, a.s2, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
+                            halfEntryBounds<true>(a.s3, a.s4, a.s5, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
+                            halfEntryBounds<true>(a.s6, a.s7, a.s8, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
+                            halfEntryBounds<true>(a.s9, a.sa, a.sb, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
                             w0 = a.sc, w1 = a.sd, w2 = a.se, w3 = a.sf;
                         }
                         else
                         {
                             const uint4* n = wide.quadHalf + 4 * static_cast<size_t>(node);
                             const uint4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3];
-                            halfEntryBounds<false>(v0.x, v0.y, v0.z, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
-                            halfEntryBounds<false>(v0.w, v1.x, v1.y, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
-                            halfEntryBounds<false>(v1.z, v1.w, v2.x, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
-                            halfEntryBounds<false>(v2.y, v2.z, v2.w, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
+                            halfEntryBounds<false>(v0.x, v0.y, v0.z, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
+                            halfEntryBounds<false>(v0.w, v1.x, v1.y, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
+                            halfEntryBounds<false>(v1.z, v1.w, v2.x, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
+                            halfEntryBounds<false>(v2.y, v2.z, v2.w, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
                             w0 = v3.x, w1 = v3.y, w2 = v3.z, w3 = v3.w;
                         }
                         okq0 = tq0 <= f0 && f0 > 0.0f;
@@ -2158,7 +2161,8 @@ struct Renderer::Impl
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
-    uint32_t optRefillMinDeep = 40, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 may refill at another count (22 was best with the 64-byte records, 40 with the quad records)
+    uint32_t optRefillMinDeep = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at another count: 22 idle lanes on the 64-byte and the
+                                                                                             // half-precision quad records (VALU bound: idle lanes cost most), 40 on the exact quad records (L1 bound: a refill is a wave-wide stall)
     // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
@@ -2509,7 +2513,9 @@ struct Renderer::Impl
             // ... and the coherent launches of the first bounces, whose rays are short and alike, claim larger chunks (one cursor atomic = one
             // wave-wide stall: bounce 1 -4 % at 256 entries, the deep bounces +0.5 %)
             const uint32_t chunkNow = bounce <= optChunkEarlyBounces ? optChunkEarly : optChunk;
-            const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? optRefillMinDeep : optRefillMin;
+            const bool     quadNow = wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
+            const bool     halfNow = quadNow && wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce;
+            const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (quadNow && !halfNow ? optRefillMinDeepQuad : optRefillMinDeep) : optRefillMin;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
                 {
@@ -3087,8 +3093,8 @@ void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
 void Renderer::setOption(const std::string& name, int64_t value)
 {
     if (name == "traversal_variant") mImpl->traversalVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
-    else if (name == "refill_min") mImpl->optRefillMin = mImpl->optRefillMinDeep = static_cast<uint32_t>(value); // (both: a sweep of one value covers every launch)
-    else if (name == "refill_min_deep") mImpl->optRefillMinDeep = static_cast<uint32_t>(value);
+    else if (name == "refill_min") mImpl->optRefillMin = mImpl->optRefillMinDeep = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value); // (all: a sweep of one value covers every launch)
+    else if (name == "refill_min_deep") mImpl->optRefillMinDeep = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value);
     else if (name == "refill_deep_from_bounce") mImpl->optRefillDeepFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 1));
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "chunk") mImpl->optChunk = mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20)); // (both, as refill_min)

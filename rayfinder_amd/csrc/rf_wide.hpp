@@ -633,14 +633,16 @@ __device__ __forceinline__ float fmixHi(uint32_t h, float inv, float b) { float 
 __device__ __forceinline__ float fmixLoS(uint32_t h, float inv, float b) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "s"(h), "v"(inv), "v"(b)); return r; }
 __device__ __forceinline__ float fmixHiS(uint32_t h, float inv, float b) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "s"(h), "v"(inv), "v"(b)); return r; }
 // conservative [near, far] of one entry from its three plane words (x, y, z); NaNs drop out of v_min / v_max (see WideBuild::quadHalf)
+// `rx ry rz`: 0 or 16 in bits 4..0 -- the plane word rotated by 16 when 1/d < 0 on that axis, so that its low half is the NEAR plane (the
+// reference's sign-selected planes: no per-axis min / max; the conservative planes keep near' < far' by the margin even for a flat box).
 template<bool SCALAR>
-__device__ __forceinline__ void halfEntryBounds(uint32_t wx, uint32_t wy, uint32_t wz, float ix, float iy, float iz, float bx, float by, float bz, float& near, float& far)
+__device__ __forceinline__ void halfEntryBounds(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t rx, uint32_t ry, uint32_t rz, float ix, float iy, float iz, float bx, float by,
+                                                float bz, float& near, float& far)
 {
-    const float lx = SCALAR ? fmixLoS(wx, ix, bx) : fmixLo(wx, ix, bx), hx = SCALAR ? fmixHiS(wx, ix, bx) : fmixHi(wx, ix, bx);
-    const float ly = SCALAR ? fmixLoS(wy, iy, by) : fmixLo(wy, iy, by), hy = SCALAR ? fmixHiS(wy, iy, by) : fmixHi(wy, iy, by);
-    const float lz = SCALAR ? fmixLoS(wz, iz, bz) : fmixLo(wz, iz, bz), hz = SCALAR ? fmixHiS(wz, iz, bz) : fmixHi(wz, iz, bz);
-    near = isaMax3(isaMin(lx, hx), isaMin(ly, hy), isaMin(lz, hz));
-    far = isaMin3(isaMax(lx, hx), isaMax(ly, hy), isaMax(lz, hz));
+    const uint32_t sx = __builtin_amdgcn_alignbit(wx, wx, rx), sy = __builtin_amdgcn_alignbit(wy, wy, ry), sz = __builtin_amdgcn_alignbit(wz, wz, rz);
+    (void)SCALAR;
+    near = isaMax3(fmixLo(sx, ix, bx), fmixLo(sy, iy, by), fmixLo(sz, iz, bz));
+    far = isaMin3(fmixHi(sx, ix, bx), fmixHi(sy, iy, by), fmixHi(sz, iz, bz));
 }
 // The EXACT slab bounds of one box (a leaf's, from its triangle record) in the packed arithmetic of slabPairBounds: same planes, same
 // (plane - o) * inv per plane, so the same decisions as the reference's whenever no product is NaN; `hasNaN` says whether one is.
