@@ -550,6 +550,17 @@ def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(du
     for i, (lo, hi) in ((2, ((-2, -2, -1), (-1, -1, 1))), (3, ((-2, 1, -1), (-1, 2, 1))), (4, ((1, -1, -1), (6, 6, 6)))):
         deep[i]["min"] = lo; deep[i]["max"] = hi; deep[i]["trianglesOffset"] = i - 2; deep[i]["triangleCount"] = 1; deep[i]["splitAxis"] = 0xFFFFFFFF
     assert rf.check_wide_layouts(deep)["quad"] is False
+    # coordinates beyond the binary16 range: no half-precision quad records (the exact quad records serve); tiny and huge boxes inside
+    # the range keep the conservative margin on every plane (checked record by record inside rf_check_wide_layouts)
+    rng = np.random.default_rng(5)
+    for scale, want in ((1.0, True), (3000.0, True), (9000.0, False), (1e-3, True)):
+        tris = (rng.uniform(-9.0, 9.0, (300, 3, 3)) * scale).astype(np.float32)
+        tris[:40] = np.round(tris[:40])                                  # flat, lattice-aligned boxes
+        big, _, _ = rf.build_bvh(tris.reshape(300, 9))
+        st = rf.wide_layout_stats(big)
+        assert bool(st["flags"] & 16) is want and bool(st["flags"] & 8)
+        if want:
+            assert 1.0 < st["quad_half_area_ratio"] < 3.0
     # non-finite boxes: the packed slab test is not used at all
     nodes[1]["max"] = (np.inf, 0.5, 0.5)
     assert rf.check_wide_layouts(nodes)["regular"] is False
