@@ -140,6 +140,19 @@ def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tm
         ax = int(rng.integers(0, 3))
         rays[1000 + i, ax] = nd["min" if i % 2 else "max"][ax]
         rays[1000 + i, 3 + ax] = np.float32(0.0) if i % 4 < 2 else np.float32(-0.0)
+    # grazing rays: the origin ON a face of a node's box (exactly, or one ulp to either side), the direction almost inside that face --
+    # where a conservative interior test and the exact leaf test (half-precision quad records) have to agree with the reference
+    for i in range(4000):
+        nd = nodes[rng.integers(0, len(nodes))]
+        ax = int(rng.integers(0, 3))
+        o = rng.uniform(nd["min"].astype(np.float64), nd["max"].astype(np.float64)).astype(np.float32)
+        o[ax] = nd["min" if i % 2 else "max"][ax]
+        if i % 3:
+            o[ax] = np.nextafter(o[ax], np.float32(np.inf if i % 3 == 1 else -np.inf))
+        d = rng.normal(size=3).astype(np.float32)
+        d[ax] = np.float32(rng.choice([1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3, 1e-12, -1e-12]))
+        rays[4000 + i, :3] = o
+        rays[4000 + i, 3:] = d
     r, _ = _renderer(duck_pt, 64, 64, 1, 1)
     r.set_option("query_variant", 2)
     with np.errstate(all="ignore"):
