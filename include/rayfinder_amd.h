@@ -173,8 +173,10 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *                                      levels of the tree per dependent fetch; defaults 1 / 1; 0 = never; takes precedence over the layouts below)
  *   quad_except_mask, quad_shadow_except_mask         ... except at bounce b when bit b-1 is set (default 0)
  *   quad_half_from_bounce, quad_half_shadow_from_bounce   first bounce whose quad launch reads the 64-byte half-precision quad records
- *                                      (conservative binary16 planes, exact boxes at the leaves; default 1 / 1 when the scene suits
- *                                      them -- rf_wide_layout_stats -- else 0 = never)
+ *                                      (conservative binary16 planes, exact boxes at the leaves; 0 = never; defaults chosen per scene:
+ *                                      rf_wide_layout_stats)
+ *   quad_local_from_bounce, quad_local_shadow_from_bounce   the same for the 64-byte local-grid quad records (8-bit planes on a
+ *                                      per-record power-of-two grid); the half-precision records take precedence
  *   compact_from_bounce, compact_shadow_from_bounce   first bounce whose closest-hit / shadow launch reads the compact-capable records
  *                                      (three loads per descending step; defaults 3 / 2; 0 = never)
  *   hot_from_bounce, hot_shadow_from_bounce           the same for the 32-byte records (two loads per step; default 0 = never)
@@ -189,7 +191,7 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *   packet_bounces n                   bounces 1..n traced by lockstep wave packets (default 0)
  *   slot_group_shift, sample_sort, accumulate_runs, shade_blocks, reserve_samples, persistent_blocks, extra_lds
  *                                      path-slot order, accumulation kernel, grid sizes, occupancy experiments
- *   query_variant 0 | 2, query_compact 0 .. 4       kernels / record layout behind rf_renderer_intersect_rays / _occluded_rays (tests) */
+ *   query_variant 0 | 2, query_compact 0 .. 5       kernels / record layout behind rf_renderer_intersect_rays / _occluded_rays (tests) */
 RF_API int rf_renderer_set_option(rf_renderer* r, const char* name, int64_t value);
 RF_API int rf_renderer_reset_stats(rf_renderer* r);
 RF_API int rf_renderer_get_stats(rf_renderer* r, rf_stats* out);
@@ -334,7 +336,8 @@ RF_API int rf_build_bvh_gpu(const float* positions36, uint64_t num_triangles, vo
 RF_API int rf_check_wide_layouts(const void* nodes48, uint64_t num_nodes, uint32_t* flags_out);
 /* The same check, plus (bit 3 = quad records usable, bit 4 = half-precision quad records usable) the figure the renderer's default
  * layout choice rests on: the surface area of the half-precision (binary16, conservative) child boxes relative to the exact ones,
- * summed over the tree -- the half-precision records are the default where it is <= 1.13 (closest-hit launches) / 1.07 (shadow).  Either output may be NULL. */
+ * summed over the tree -- the closest-hit launches read the half-precision records where it is <= 1.075 and the local-grid records
+ * (bit 5) beyond; the shadow launches the local-grid records where it is <= 1.10 and the exact quad records beyond.  Either output may be NULL. */
 RF_API int rf_wide_layout_stats(const void* nodes48, uint64_t num_nodes, uint32_t* flags_out, float* quad_half_area_ratio);
 
 /* Camera createCamera(origin, lookAt, aperture, focusDistance, vfov, aspectRatio)

@@ -159,12 +159,12 @@ def check_wide_layouts(nodes):
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     flags = C.c_uint32(0)
     check(lib.rf_check_wide_layouts(_ptr(nodes), nodes.shape[0], C.byref(flags)))
-    return {"regular": bool(flags.value & 1), "compact": bool(flags.value & 2), "hot": bool(flags.value & 4), "quad": bool(flags.value & 8), "quad_half": bool(flags.value & 16)}
+    return {"regular": bool(flags.value & 1), "compact": bool(flags.value & 2), "hot": bool(flags.value & 4), "quad": bool(flags.value & 8), "quad_half": bool(flags.value & 16), "quad_local": bool(flags.value & 32)}
 
 
 def wide_layout_stats(nodes):
     """Flags of check_wide_layouts plus the surface-area ratio of the half-precision quad boxes (the renderer uses them by default
-    where it is <= 1.13 / 1.07: closest-hit / shadow launches)."""
+    closest-hit: half-precision records up to 1.075, local-grid beyond; shadow: local-grid up to 1.10, exact beyond)."""
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     flags = C.c_uint32(0); ratio = C.c_float(0.0)
     check(lib.rf_wide_layout_stats(_ptr(nodes), nodes.shape[0], C.byref(flags), C.byref(ratio)))

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
     constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
     static_assert(!(COMPACT != 0 && COUNT), "the compact-record and quad-record variants have no counting build");
-    static_assert(COMPACT >= 0 && COMPACT <= 4, "0: 64-byte records, 1: compact-capable, 2: 32-byte, 3: quad, 4: half-precision quad");
+    static_assert(COMPACT >= 0 && COMPACT <= 5, "0: 64-byte records, 1: compact-capable, 2: 32-byte, 3: quad, 4: half-precision quad, 5: local-grid quad");
     __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
@@ -720,6 +720,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     BoxT  own{};
     // COMPACT == 4 (half-precision quad records): b = -(o / d) per axis, the addend of t' = fma(plane', 1/d, b)
     float hbx = 0.0f, hby = 0.0f, hbz = 0.0f;
+    uint32_t lselX = 0u, lselY = 0u, lselZ = 0u; // COMPACT == 5 (local-grid quad records): per-axis v_perm_b32 selectors (see localEntryBounds)
     uint32_t hrot = 0u; // ... and (1/d.x < 0) << 4 | (1/d.y < 0) << 12 | (1/d.z < 0) << 20: rotate amounts that bring a plane word's NEAR plane into its low half
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
@@ -831,9 +832,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 rayTris = 0;
                 rayStackHigh = 0;
                 needScalar = rayClass == kRayIrregular;
-                if constexpr (COMPACT == 4)
+                if constexpr (COMPACT == 4 || COMPACT == 5)
                 {
-                    // the margin of the half-precision planes covers origins within wide.originBound and 1/direction components of
+                    // the margin of the half-precision / local-grid planes covers origins within wide.originBound and 1/direction components of
                     // ordinary magnitude (or +-inf: those axes drop out as NaNs): anything else takes the scalar traversal
                     const auto ordinary = [](float inv) { const float a = fabsf(inv); return (a >= 1e-18f && a <= 1e18f) || a == __uint_as_float(0x7F800000u); };
                     const bool inside = fabsf(o.x) <= wide.originBound && fabsf(o.y) <= wide.originBound && fabsf(o.z) <= wide.originBound;
@@ -852,6 +853,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     hby = -(o.y * pr.iXY.y);
                     hbz = -(o.z * pr.iZ);
                     hrot = (ray.negX << 4) | (ray.negY << 12) | (ray.negZ << 20);
+                    lselX = ray.negX ? 0x00040005u : 0x00050004u, lselY = ray.negY ? 0x00040005u : 0x00050004u, lselZ = ray.negZ ? 0x00040005u : 0x00050004u;
                 }
                 float      rootTMin;
                 const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             if (static_cast<int32_t>(node) >= 0)
             {
                 if (COUNT) ++recordFetches;
-                if constexpr (COMPACT == 3 || COMPACT == 4)
+                if constexpr (COMPACT == 3 || COMPACT == 4 || COMPACT == 5)
                 {
                     // ---- quad records (rf_wide.hpp): the boxes of the node's (up to) four grandchildren in ONE 128-byte record --
                     // two levels of the reference's tree per dependent fetch.  Entries 0,1 belong to the first child, 2,3 to the
@@ -918,6 +920,40 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                             w0 = __float_as_uint(v6.x), w1 = __float_as_uint(v6.y), w2 = __float_as_uint(v6.z), w3 = __float_as_uint(v6.w);
                             quadStep(v0, v1, v2, v3, v4, v5);
                         }
+                    }
+                    else if constexpr (COMPACT == 5)
+                    {
+                        // ---- local-grid quad records (rf_wide.hpp, WideBuild::quadLocal): 8-bit planes on the record's own power-of-two grid,
+                        // 64 bytes -- four loads.  CONSERVATIVE tests, as with the half-precision records; the leaf phase applies the exact boxes.
+                        float          f0, f1, f2, f3;
+                        const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
+                        uint4          v0, v1, v2, v3;
+                        if (uniformFetch && __ballot(node != uNode) == 0ull)
+                        {
+                            typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+                            const uint4*     un = wide.quadLocal + 4 * static_cast<size_t>(uNode);
+                            u16v             a;
+                            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(un) : "memory");
+                            v0 = make_uint4(a.s0, a.s1, a.s2, a.s3), v1 = make_uint4(a.s4, a.s5, a.s6, a.s7), v2 = make_uint4(a.s8, a.s9, a.sa, a.sb), v3 = make_uint4(a.sc, a.sd, a.se, a.sf);
+                        }
+                        else
+                        {
+                            const uint4* n = wide.quadLocal + 4 * static_cast<size_t>(node);
+                            v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3];
+                        }
+                        // A = scale / d (exact: a power of two times 1/d), B = (anchor - o) / d - 1024 A (one FMA)
+                        const float ax = __uint_as_float(v0.w) * pr.iXY.x, ay = __uint_as_float(v1.x) * pr.iXY.y, az = __uint_as_float(v1.y) * pr.iZ;
+                        const float bx = __builtin_fmaf(-1024.0f, ax, (__uint_as_float(v0.x) - pr.oXY.x) * pr.iXY.x), by = __builtin_fmaf(-1024.0f, ay, (__uint_as_float(v0.y) - pr.oXY.y) * pr.iXY.y),
+                                    bz = __builtin_fmaf(-1024.0f, az, (__uint_as_float(v0.z) - pr.oZ) * pr.iZ);
+                        localEntryBounds<0>(v1.z, v2.x, v2.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq0, f0);
+                        localEntryBounds<1>(v1.z, v2.x, v2.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq1, f1);
+                        localEntryBounds<0>(v1.w, v2.y, v2.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq2, f2);
+                        localEntryBounds<1>(v1.w, v2.y, v2.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq3, f3);
+                        w0 = v3.x, w1 = v3.y, w2 = v3.z, w3 = v3.w;
+                        okq0 = tq0 <= f0 && f0 > 0.0f;
+                        okq1 = tq1 <= f1 && f1 > 0.0f;
+                        okq2 = tq2 <= f2 && f2 > 0.0f;
+                        okq3 = tq3 <= f3 && f3 > 0.0f;
                     }
                     else
                     {
@@ -1274,9 +1310,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             bool finished = false;
             if (COUNT) ++wLeafPhase;
             float4 firstA{}, firstB{}, firstC{};
-            if constexpr (COMPACT == 4)
+            if constexpr (COMPACT == 4 || COMPACT == 5)
             {
-                // The half-precision quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
+                // The half-precision / local-grid quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
                 // test its box, exactly, with its own formula, against the rayTMax of this moment -- happens here.  The leaf's box
                 // rides in the spare floats of its first triangle record (leafBoxesIntoTriangles): the same 64-byte line.
                 const float4* t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
@@ -1311,7 +1347,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 Vec3           p0, p1, p2;
                 // the same triangle in every lane of this leaf phase (one pixel's samples reaching the same leaf): scalar cache
                 const uint32_t uTri = __builtin_amdgcn_readfirstlane(tri);
-                if (COMPACT == 4 && i == 0u)
+                if ((COMPACT == 4 || COMPACT == 5) && i == 0u)
                 {
                     p0 = vec3(firstA.x, firstA.y, firstA.z), p1 = vec3(firstB.x, firstB.y, firstB.z), p2 = vec3(firstC.x, firstC.y, firstC.z);
                 }
@@ -2110,7 +2146,7 @@ struct Renderer::Impl
     hipStream_t stream = nullptr;
 
     DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact, wideHot, wideOwn, wideQuad;
-    DeviceBuffer<uint4>             wideQuadHalf;
+    DeviceBuffer<uint4>             wideQuadHalf, wideQuadLocal;
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
     DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
@@ -2175,6 +2211,7 @@ struct Renderer::Impl
     uint32_t               optQuadExceptMask = 0, optQuadShadowExceptMask = 0; // ... except at the bounces whose bit (bounce - 1) is set here
     uint32_t               optQuadHalfFromBounce = 0, optQuadHalfShadowFromBounce = 0; // quad launches of bounce >= this read the 64-byte half-precision quad records (0: never; set to 1 at upload when the scene suits them)
     float                  quadHalfAreaRatio = 0.0f;
+    uint32_t               optQuadLocalFromBounce = 0, optQuadLocalShadowFromBounce = 0; // ... the 64-byte local-grid quad records (0: never; set to 1 at upload when the half-precision ones do not suit the scene)
     uint32_t               optHotFromBounce = 0, optHotShadowFromBounce = 0; // the 32-byte records (all six planes carried) from this bounce on (0: never); takes precedence
     int                    optQueryCompact = 0;            // the ray-query entry points use the compact-capable (1) / 32-byte (2) records too (tests)
     uint32_t               optExtraLds = 0;      // experiment: dynamic LDS bytes added to the kTraceWide launches (lowers the occupancy)
@@ -2390,7 +2427,13 @@ struct Renderer::Impl
             RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
             RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
-            if (shadowNearestFirst && optQueryCompact == 4 && wide.quadHalf != nullptr)
+            if (shadowNearestFirst && optQueryCompact == 5 && wide.quadLocal != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (optQueryCompact == 5 && wide.quadLocal != nullptr)
+                hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+            else if (shadowNearestFirst && optQueryCompact == 4 && wide.quadHalf != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
             else if (optQueryCompact == 4 && wide.quadHalf != nullptr)
@@ -2417,7 +2460,10 @@ struct Renderer::Impl
         }
         else
         {
-            if (optQueryCompact == 4 && wide.quadHalf != nullptr)
+            if (optQueryCompact == 5 && wide.quadLocal != nullptr)
+                hipLaunchKernelGGL((kTraceWide<false, false, false, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+            else if (optQueryCompact == 4 && wide.quadHalf != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
                                    queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
             else if (optQueryCompact == 3 && wide.quad != nullptr)
@@ -2515,7 +2561,8 @@ struct Renderer::Impl
             // wave-wide stall: bounce 1 -4 % at 256 entries, the deep bounces +0.5 %)
             const uint32_t chunkNow = bounce <= optChunkEarlyBounces ? optChunkEarly : optChunk;
             const bool     quadNow = wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
-            const bool     halfNow = quadNow && wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce;
+            const bool     halfNow = quadNow && ((wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce) ||
+                                                 (wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce));
             const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (quadNow && !halfNow ? optRefillMinDeepQuad : optRefillMinDeep) : optRefillMin;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
@@ -2533,6 +2580,9 @@ struct Renderer::Impl
                 else if (wide.quadHalf != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                          optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce)
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
+                else if (quadNow && wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce)
+                    hipLaunchKernelGGL((kTraceWide<false, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
@@ -2583,6 +2633,16 @@ struct Renderer::Impl
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
                             hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+                    }
+                    else if (wide.quadLocal != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
+                             optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce)
+                    {
+                        if (optShadowSignOrder)
+                            hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+                        else
+                            hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
@@ -2688,11 +2748,22 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         {
             m.wideQuadHalf.upload(wb.quadHalf.data(), wb.quadHalf.size());
             m.wide.quadHalf = m.wideQuadHalf.ptr;
-            // default: every quad launch reads the half-precision records -- unless the binary16 grid is too coarse for this scene
-            // (its boxes' surface area, i.e. the number of boxes a ray hits, grows by more than 13 % / 7 %): then the exact quad records
+            // default (rf_wide.hpp, kQuadHalfMaxAreaRatio): the closest-hit launches read the half-precision records unless the binary16
+            // grid is too coarse for this scene; the shadow launches prefer the local-grid records (below)
             m.optQuadHalfFromBounce = wb.quadHalfAreaRatio <= kQuadHalfMaxAreaRatio ? 1u : 0u;
-            m.optQuadHalfShadowFromBounce = wb.quadHalfAreaRatio <= kQuadHalfShadowMaxAreaRatio ? 1u : 0u;
+            m.optQuadHalfShadowFromBounce = 0u;
             m.quadHalfAreaRatio = wb.quadHalfAreaRatio;
+        }
+        m.wide.quadLocal = nullptr;
+        if (!wb.quadLocal.empty())
+        {
+            m.wideQuadLocal.upload(wb.quadLocal.data(), wb.quadLocal.size());
+            m.wide.quadLocal = m.wideQuadLocal.ptr;
+            // closest-hit: the per-record 8-bit grid where binary16 of absolute coordinates is too coarse (small triangles far from the
+            // origin); shadow: the local grid unless the scene is so finely tessellated that the exact records win (kQuadLocalShadowMaxAreaRatio)
+            const float ratio = wb.quadHalf.empty() ? 2.0f : wb.quadHalfAreaRatio;
+            m.optQuadLocalFromBounce = m.optQuadHalfFromBounce == 0u ? 1u : 0u;
+            m.optQuadLocalShadowFromBounce = ratio <= kQuadLocalShadowMaxAreaRatio ? 1u : 0u;
         }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
@@ -2981,7 +3052,7 @@ void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, ui
     pathsAllocated = m.allocatedPaths;
     pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
     maxPathsPerBatch = m.maxPaths;
-    sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
+    sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.wideQuadLocal.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
                  m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2);
 }
 uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }
@@ -3116,6 +3187,8 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "query_compact") mImpl->optQueryCompact = static_cast<int>(value);
     else if (name == "quad_from_bounce") mImpl->optQuadFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "quad_shadow_from_bounce") mImpl->optQuadShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "quad_local_from_bounce") mImpl->optQuadLocalFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "quad_local_shadow_from_bounce") mImpl->optQuadLocalShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "quad_half_from_bounce") mImpl->optQuadHalfFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "quad_half_shadow_from_bounce") mImpl->optQuadHalfShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "quad_except_mask") mImpl->optQuadExceptMask = static_cast<uint32_t>(value);
@@ -3309,7 +3382,7 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
     if (nodes.empty()) throw std::runtime_error("checkWideLayouts: no nodes");
     const WideBuild wb = buildWide(nodes.data(), nodes.size());
     if (quadHalfAreaRatio) *quadHalfAreaRatio = wb.quadHalf.empty() ? 0.0f : wb.quadHalfAreaRatio;
-    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u) | (!wb.quad.empty() ? 8u : 0u) | (!wb.quadHalf.empty() ? 16u : 0u);
+    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u) | (!wb.quad.empty() ? 8u : 0u) | (!wb.quadHalf.empty() ? 16u : 0u) | (!wb.quadLocal.empty() ? 32u : 0u);
     const size_t    records = wb.nodes.size() / 4;
     const auto      fail = [](size_t r, const char* what) { throw std::runtime_error("wide layout mismatch at record " + std::to_string(r) + ": " + what); };
     if (!wb.quadHalf.empty())
@@ -3341,6 +3414,42 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
                         if (!(static_cast<double>(halfBitsToFloat(l16)) <= static_cast<double>(lo[j][ax]) - margin)) fail(r, "half-precision quad record: a lower plane is not below its f32 plane by the margin");
                         if (!(static_cast<double>(halfBitsToFloat(h16)) >= static_cast<double>(hi[j][ax]) + margin)) fail(r, "half-precision quad record: an upper plane is not above its f32 plane by the margin");
                     }
+            }
+        }
+    }
+    if (!wb.quadLocal.empty())
+    {
+        // The local-grid quad records: same words, power-of-two scales, every decoded plane (anchor + byte * scale, exact in double) on the
+        // conservative side of the f32 plane by at least the margin of the proof (rf_wide.hpp).
+        if (wb.quadLocal.size() * 2 != wb.quad.size()) throw std::runtime_error("wide layout mismatch: local-grid quad records do not pair up with the quad records");
+        double R = 0.0;
+        for (const float c : {wb.rootLo.x, wb.rootLo.y, wb.rootLo.z, wb.rootHi.x, wb.rootHi.y, wb.rootHi.z}) R = std::max(R, static_cast<double>(std::fabs(c)));
+        for (size_t r = 0; r < wb.quadLocal.size() / 4; ++r)
+        {
+            const float4*  q = &wb.quad[8 * r];
+            const uint4*   l = &wb.quadLocal[4 * r];
+            const uint32_t words[4] = {l[3].x, l[3].y, l[3].z, l[3].w};
+            if (words[0] != floatBits(q[6].x) || words[1] != floatBits(q[6].y) || words[2] != floatBits(q[6].z) || words[3] != floatBits(q[6].w)) fail(r, "local-grid quad record: words differ");
+            const float    anchor[3] = {bitsFloat(l[0].x), bitsFloat(l[0].y), bitsFloat(l[0].z)}, scale[3] = {bitsFloat(l[0].w), bitsFloat(l[1].x), bitsFloat(l[1].y)};
+            const uint32_t axisWords[3][2] = {{l[1].z, l[1].w}, {l[2].x, l[2].y}, {l[2].z, l[2].w}};
+            for (int ax = 0; ax < 3; ++ax)
+            {
+                int          ex = 0;
+                const double m = std::frexp(static_cast<double>(scale[ax]), &ex);
+                if (!(m == 0.5) || !std::isfinite(anchor[ax])) fail(r, "local-grid quad record: scale is not a power of two, or the anchor is not finite");
+                const double margin = 5.9604644775390625e-08 * (6.03 * (static_cast<double>(wb.originBound) + R) + 1024.0 * static_cast<double>(scale[ax])) * 1.0001;
+                for (int e = 0; e < 4; ++e)
+                {
+                    if (words[e] == kQuadEmpty) continue;
+                    const int    k = e / 2, j = e % 2;
+                    const float4 a = q[3 * k], z = q[3 * k + 1], b = q[3 * k + 2];
+                    const double lo = ax == 0 ? (j ? b.x : a.x) : ax == 1 ? (j ? b.y : a.y) : (j ? z.z : z.x), hi = ax == 0 ? (j ? b.z : a.z) : ax == 1 ? (j ? b.w : a.w) : (j ? z.w : z.y);
+                    const uint32_t pair = (axisWords[ax][e / 2] >> (16 * (e % 2))) & 0xFFFFu;
+                    const double   dlo = static_cast<double>(anchor[ax]) + static_cast<double>(pair & 0xFFu) * static_cast<double>(scale[ax]),
+                                 dhi = static_cast<double>(anchor[ax]) + static_cast<double>(pair >> 8) * static_cast<double>(scale[ax]);
+                    if (!(dlo <= lo - margin)) fail(r, "local-grid quad record: a lower plane is not below its f32 plane by the margin");
+                    if (!(dhi >= hi + margin)) fail(r, "local-grid quad record: an upper plane is not above its f32 plane by the margin");
+                }
             }
         }
     }

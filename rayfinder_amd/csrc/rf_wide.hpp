@@ -44,10 +44,15 @@ constexpr uint32_t kWideLeafBit = 0x80000000u;
 constexpr uint32_t kWideIndexBits = 26;  // record / first-triangle / big-leaf index
 constexpr uint32_t kWideAxisShift = 29;  // bits 30..29 of the FIRST child word carry the node's split axis
 constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is interior
-// half-precision quad records by default where WideBuild::quadHalfAreaRatio stays below these (tools/half_ratio_sweep.py on the atrium at
-// tessellation scales 1 / 2 / 3 / 4 / 6 / 8 = ratios 1.035 / 1.063 / 1.089 / 1.117 / 1.166 / 1.223: closest-hit -12 / -12 / -11 / -7 / 0 / +8 %,
-// shadow -4 / -1 / +4 / +12 / +33 / +52 %)
-constexpr float    kQuadHalfMaxAreaRatio = 1.13f, kQuadHalfShadowMaxAreaRatio = 1.07f;
+// Which 64-byte quad records a scene gets by default, from WideBuild::quadHalfAreaRatio (how coarse binary16 of absolute coordinates is for
+// its boxes).  tools/half_ratio_sweep.py on the atrium at tessellation scales 1 / 2 / 3 / 4 / 6 / 8 = ratios 1.035 / 1.063 / 1.089 / 1.117 /
+// 1.166 / 1.223, launch time against the exact quad records:
+//     closest-hit   half-precision  -17 / -17 / -14 / -10 /  -3 /  +7 %      local grid  -14 / -15 / -15 / -15 / -13 /  -9 %
+//     shadow        half-precision   -7 /  -5 /  -1 / +10 / +28 / +54 %      local grid   -8 /  -8 /  -5 /  -1 /  +4 / +20 %
+// (a shadow ray crosses the whole scene: every leaf box it only grazes conservatively costs a triangle line, from HBM in a large scene)
+// -> closest-hit: half-precision up to kQuadHalfMaxAreaRatio, local grid beyond; shadow: local grid up to kQuadLocalShadowMaxAreaRatio,
+//    exact quad records beyond.
+constexpr float    kQuadHalfMaxAreaRatio = 1.075f, kQuadLocalShadowMaxAreaRatio = 1.10f;
 constexpr uint32_t kQuadEmpty = 0xFFFFFFFFu; // quad records: an entry slot that holds no node (its child is a leaf and fills one slot only)
 #if defined(RF_EXP_WAVES)
 constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment builds: resident workgroups per CU of kTraceWide
@@ -66,7 +71,8 @@ struct WideScene
     const float4* own;       // 2 float4 per interior node: the node's own box {lo.x lo.y hi.x hi.y} {lo.z hi.z - -} (read after a pop only)
     const float4* quad;      // 8 float4 per quad record: TWO levels in one 128-byte record (see buildWide), or nullptr
     const uint4*  quadHalf;  // 4 uint4 per quad record: the same records with CONSERVATIVE half-precision planes, 64 bytes (see buildWide), or nullptr
-    float         originBound; // quadHalf: rays whose origin has a coordinate beyond this magnitude take the scalar traversal (margin proof)
+    float         originBound; // quadHalf / quadLocal: rays whose origin has a coordinate beyond this magnitude take the scalar traversal (margin proofs)
+    const uint4*  quadLocal; // 4 uint4 per quad record: conservative 8-bit planes on a per-record grid, 64 bytes (see buildWide), or nullptr
     const uint2*  bigLeaves; // {first triangle, count}
     float4        rootLo;    // root box (w unused)
     float4        rootHi;
@@ -118,9 +124,22 @@ struct WideBuild
     float               originBound = 0.0f;
     // sum of the surface areas of the half-precision boxes / of the exact boxes, over all entries: how many more boxes a random ray
     // hits because of the binary16 grid (absolute coordinates: ~2^-11 of the coordinate's magnitude).  The renderer uses the half records
-    // by default only where this stays below kQuadHalfMaxAreaRatio / kQuadHalfShadowMaxAreaRatio (a 17 M-triangle scene of centimetre
-    // triangles: 1.22 -> slower).
+    // by default only where this stays below kQuadHalfMaxAreaRatio (a 17 M-triangle scene of centimetre triangles: 1.22 -> the local grid).
     float               quadHalfAreaRatio = 0.0f;
+    // Local-grid quad records (kTraceWide<..., COMPACT = 5>): the same idea with the planes as 8-bit steps of a PER-RECORD power-of-two grid,
+    // for scenes whose triangles are small against their coordinates (where binary16 of absolute coordinates is too coarse):
+    //     {anchor.x anchor.y anchor.z scale.x} {scale.y scale.z X0 X1} {Y0 Y1 Z0 Z1} {word0..3}
+    // anchor: a point below every lower plane of the record; scale = 2^e per axis (f32); axis words: X0 = {lo0 hi0 lo1 hi1} (one byte each,
+    // entries 0 and 1), X1 = entries 2 and 3; plane' = anchor + byte * scale, lo' <= lo - margin, hi' >= hi + margin.
+    // The step evaluates t' = fma(1024 + byte, A, B') with A = scale / d (exact: a power of two times 1/d), B' = ((anchor - o) / d) - 1024 A
+    // -- "1024 + byte" is the binary16 0x6400 | byte, built by one v_perm_b32 per pair of planes (which also puts the NEAR plane into the
+    // low half: the selector depends on the sign of 1/d), and v_fma_mix_f32 takes it straight into the f32 FMA.  Roundings: two in
+    // (anchor - o) / d, one in B', one in t', against two in the reference's t: with u = 2^-24 and everything within originBound / R,
+    //     |t' - T'| <= u (3.02 |anchor - o| + 1024 scale + |plane' - o|) / |d|,   |t - T| <= 2.01 u |plane - o| / |d|,
+    // so  margin >= u (6.03 (originBound + R) + 1024 scale)  keeps every near t' <= its t and every far t' >= its t; 1024 scale <= 16.2 R,
+    // i.e. u (46 R + 6) with originBound = 4 R + 1, and the builder leaves 2^-18 (originBound + R) = u (320 R + 64): 6.9 x that.
+    std::vector<uint4>  quadLocal;
+    float               quadLocalAreaRatio = 0.0f;
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
@@ -408,6 +427,65 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         }
         out.quadHalfAreaRatio = areaExact > 0.0 ? static_cast<float>(areaHalf / areaExact) : 1.0f;
         if (!ok) out.quadHalf.clear(); // a coordinate beyond the binary16 range: the f32 quad records serve
+        // ---- local-grid quad records (see WideBuild::quadLocal)
+        {
+            const double marginL = (static_cast<double>(out.originBound) + R) * 3.814697265625e-06; // 2^-18
+            out.quadLocal.assign(4 * numQuad, make_uint4(0u, 0u, 0u, 0u));
+            double aExact = 0.0, aLocal = 0.0;
+            bool   okL = true;
+            for (size_t r = 0; r < numQuad && okL; ++r)
+            {
+                const float4* q = &out.quad[8 * r];
+                const uint32_t words[4] = {floatBits(q[6].x), floatBits(q[6].y), floatBits(q[6].z), floatBits(q[6].w)};
+                double         lo[4][3], hi[4][3];
+                for (int e = 0; e < 4; ++e)
+                {
+                    const int    k = e / 2, j = e % 2;
+                    const float4 a = q[3 * k], z = q[3 * k + 1], b = q[3 * k + 2];
+                    lo[e][0] = j ? b.x : a.x, lo[e][1] = j ? b.y : a.y, lo[e][2] = j ? z.z : z.x;
+                    hi[e][0] = j ? b.z : a.z, hi[e][1] = j ? b.w : a.w, hi[e][2] = j ? z.w : z.y;
+                }
+                float    anchor[3], scale[3];
+                uint32_t axisWords[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
+                double   dlo[4][3], dhi[4][3];
+                for (int ax = 0; ax < 3; ++ax)
+                {
+                    double nlo = std::numeric_limits<double>::infinity(), nhi = -nlo;
+                    for (int e = 0; e < 4; ++e)
+                        if (words[e] != kQuadEmpty) nlo = std::min(nlo, lo[e][ax]), nhi = std::max(nhi, hi[e][ax]);
+                    const double target = nlo - marginL;
+                    float        an = static_cast<float>(target);
+                    if (static_cast<double>(an) > target) an = std::nextafterf(an, -std::numeric_limits<float>::infinity());
+                    const double span = (nhi + marginL) - static_cast<double>(an);
+                    int          ex = 0;
+                    (void)std::frexp(span / 254.0, &ex); // span / 254 = m * 2^ex, m in [0.5, 1): 2^ex >= span / 254
+                    if (!(span > 0.0) || ex < -100 || ex > 100) { okL = false; break; }
+                    const double sc = std::ldexp(1.0, ex);
+                    anchor[ax] = an, scale[ax] = static_cast<float>(sc);
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        uint32_t bl = 0u, bh = 0u;
+                        if (words[e] != kQuadEmpty)
+                        {
+                            const double fl = std::floor((lo[e][ax] - marginL - static_cast<double>(an)) / sc), ch = std::ceil((hi[e][ax] + marginL - static_cast<double>(an)) / sc);
+                            if (!(fl >= 0.0 && ch <= 255.0 && fl <= ch)) { okL = false; break; }
+                            bl = static_cast<uint32_t>(fl), bh = static_cast<uint32_t>(ch);
+                        }
+                        dlo[e][ax] = static_cast<double>(an) + bl * sc, dhi[e][ax] = static_cast<double>(an) + bh * sc;
+                        axisWords[ax][e / 2] |= (bl | (bh << 8)) << (16 * (e % 2));
+                    }
+                }
+                if (!okL) break;
+                out.quadLocal[4 * r] = make_uint4(floatBits(anchor[0]), floatBits(anchor[1]), floatBits(anchor[2]), floatBits(scale[0]));
+                out.quadLocal[4 * r + 1] = make_uint4(floatBits(scale[1]), floatBits(scale[2]), axisWords[0][0], axisWords[0][1]);
+                out.quadLocal[4 * r + 2] = make_uint4(axisWords[1][0], axisWords[1][1], axisWords[2][0], axisWords[2][1]);
+                out.quadLocal[4 * r + 3] = make_uint4(words[0], words[1], words[2], words[3]);
+                for (int e = 0; e < 4; ++e)
+                    if (words[e] != kQuadEmpty) aExact += area(lo[e], hi[e]), aLocal += area(dlo[e], dhi[e]);
+            }
+            out.quadLocalAreaRatio = aExact > 0.0 ? static_cast<float>(aLocal / aExact) : 1.0f;
+            if (!okL) out.quadLocal.clear();
+        }
     }
     if (!out.boxesRegular) out.compactUsable = false;
     if (!out.compactUsable || numInterior == 0) out.compact.clear();
@@ -643,6 +721,19 @@ __device__ __forceinline__ void halfEntryBounds(uint32_t wx, uint32_t wy, uint32
     (void)SCALAR;
     near = isaMax3(fmixLo(sx, ix, bx), fmixLo(sy, iy, by), fmixLo(sz, iz, bz));
     far = isaMin3(fmixHi(sx, ix, bx), fmixHi(sy, iy, by), fmixHi(sz, iz, bz));
+}
+// Local-grid quad records: conservative [near, far] of entry `pair` (0 / 1) of the axis words wx wy wz.  sx sy sz: the v_perm_b32 selectors of
+// pair 0 -- 0x00050004 when 1/d >= 0 on that axis (low half = 1024 + lo byte, high half = 1024 + hi byte), 0x00040005 when 1/d < 0 (swapped:
+// the low half is always the NEAR plane); pair 1 sits two bytes further (+ 0x00020002).  A = scale / d, B = (anchor - o) / d - 1024 A.
+template<int PAIR>
+__device__ __forceinline__ void localEntryBounds(uint32_t wx, uint32_t wy, uint32_t wz, uint32_t sx, uint32_t sy, uint32_t sz, float ax, float ay, float az, float bx, float by,
+                                                 float bz, float& near, float& far)
+{
+    constexpr uint32_t kStep = PAIR ? 0x00020002u : 0u;
+    const uint32_t     px = __builtin_amdgcn_perm(wx, 0x64646464u, sx + kStep), py = __builtin_amdgcn_perm(wy, 0x64646464u, sy + kStep),
+                   pz = __builtin_amdgcn_perm(wz, 0x64646464u, sz + kStep);
+    near = isaMax3(fmixLo(px, ax, bx), fmixLo(py, ay, by), fmixLo(pz, az, bz));
+    far = isaMin3(fmixHi(px, ax, bx), fmixHi(py, ay, by), fmixHi(pz, az, bz));
 }
 // The EXACT slab bounds of one box (a leaf's, from its triangle record) in the packed arithmetic of slabPairBounds: same planes, same
 // (plane - o) * inv per plane, so the same decisions as the reference's whenever no product is NaN; `hasNaN` says whether one is.

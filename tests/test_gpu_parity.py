@@ -170,7 +170,7 @@ def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tm
     # step; 2: 32-byte records, two loads, all six planes carried): the same planes and products, so the same bits on the same
     # hostile rays
     r.set_option("shadow_nearest_first", 1)
-    for mode in (1, 2, 3, 4):                             # (3: the 128-byte quad records, two levels of the tree per fetch; 4: their
+    for mode in (1, 2, 3, 4, 5):                          # (5: the local-grid quad records; 3: the 128-byte quad records, two levels of the tree per fetch; 4: their
                                                           # half-precision form -- conservative interior tests, exact boxes at the leaves)
         r.set_option("query_compact", mode)
         gpu_c = r.intersect_rays(rays, tmax)
@@ -775,6 +775,11 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
     if seed % 5 in (1, 3):                                      # the quad launches (if any) on the exact quad records / the half-precision ones
         r.set_option("quad_half_from_bounce", 0 if seed % 5 == 1 else 1 + seed % 3)   # (default since the end of round 3: half precision, where the scene suits it)
         r.set_option("quad_half_shadow_from_bounce", 0 if seed % 5 == 1 else 1 + seed % 2)
+    if seed % 7 in (2, 5):                                      # the quad launches on the local-grid quad records (they take over where the half-precision ones are off)
+        r.set_option("quad_half_from_bounce", 0 if seed % 7 == 2 else 3)
+        r.set_option("quad_half_shadow_from_bounce", 0)
+        r.set_option("quad_local_from_bounce", 1)
+        r.set_option("quad_local_shadow_from_bounce", 1 + seed % 2)
     if seed % 3 == 2:                                           # ... on the 32-byte records
         r.set_option("hot_from_bounce", 1)
         r.set_option("hot_shadow_from_bounce", 1)
@@ -1030,6 +1035,8 @@ def test_slot_order_batching_and_accumulation_variants_give_identical_images(duc
                 dict(quad_from_bounce=2, quad_shadow_from_bounce=1, uniform_fetch=0), dict(quad_from_bounce=1, quad_shadow_from_bounce=3, quad_except_mask=2, quad_shadow_except_mask=8),
                 dict(quad_half_from_bounce=0, quad_half_shadow_from_bounce=0), dict(quad_half_from_bounce=2, quad_half_shadow_from_bounce=1, uniform_fetch=0),
                 dict(quad_half_from_bounce=3, quad_half_shadow_from_bounce=2, shade_sort_from_bounce=0), dict(quad_half_from_bounce=0, quad_half_shadow_from_bounce=1),
+                dict(quad_half_from_bounce=0, quad_half_shadow_from_bounce=0, quad_local_from_bounce=1, quad_local_shadow_from_bounce=1),
+                dict(quad_half_from_bounce=0, quad_half_shadow_from_bounce=0, quad_local_from_bounce=2, quad_local_shadow_from_bounce=1, uniform_fetch=0, shadow_sign_order=0),
                 dict(shade_sort_from_bounce=1), dict(shade_sort_from_bounce=2, shade_blocks=5), dict(shade_sort_from_bounce=0)]
     for opts in variants:
         for max_paths in (0, 5 * 15 * 1024):                  # default batch (all 23 samples at once) / 5 samples per batch -> 5, 5, 5, 4, 4

@@ -528,11 +528,11 @@ def test_wide_record_layouts_decode_to_the_same_planes(seed, n):
     tris[: n // 4] = np.round(tris[: n // 4] * 2) / 2               # lattice coordinates: shared planes, zero-thickness boxes
     nodes, _, _ = rf.build_bvh(tris.reshape(n, 9))
     got = rf.check_wide_layouts(nodes)
-    assert got == {"regular": True, "compact": n > 1, "hot": n > 1, "quad": n > 1, "quad_half": n > 1}   # (a single-leaf tree has no interior record)
+    assert got == {"regular": True, "compact": n > 1, "hot": n > 1, "quad": n > 1, "quad_half": n > 1, "quad_local": n > 1}   # (a single-leaf tree has no interior record)
 
 
 def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(duck_oracle):
-    assert rf.check_wide_layouts(duck_oracle.nodes) == {"regular": True, "compact": True, "hot": True, "quad": True, "quad_half": True}
+    assert rf.check_wide_layouts(duck_oracle.nodes) == {"regular": True, "compact": True, "hot": True, "quad": True, "quad_half": True, "quad_local": True}
     # a hand-made tree whose root box is LARGER than the union of its children: the lane cannot carry the node's planes,
     # so the renderer falls back to the plain records
     nodes = np.zeros(3, dtype=rf.NODE_DTYPE)
@@ -541,7 +541,7 @@ def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(du
         nodes[i]["min"] = (x - 0.5, -0.5, -0.5); nodes[i]["max"] = (x + 0.5, 0.5, 0.5)
         nodes[i]["trianglesOffset"] = i - 1; nodes[i]["triangleCount"] = 1; nodes[i]["splitAxis"] = 0xFFFFFFFF
     # (the quad records skip the level BELOW the node they belong to; here that level holds only leaves, so nothing is skipped)
-    assert rf.check_wide_layouts(nodes) == {"regular": True, "compact": False, "hot": False, "quad": True, "quad_half": True}
+    assert rf.check_wide_layouts(nodes) == {"regular": True, "compact": False, "hot": False, "quad": True, "quad_half": True, "quad_local": True}
     # ... but a CHILD whose box is larger than the union of its children cannot be skipped: "a grandchild passes" would no
     # longer imply "the child passes" with the same planes
     deep = np.zeros(5, dtype=rf.NODE_DTYPE)
@@ -558,7 +558,7 @@ def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(du
         tris[:40] = np.round(tris[:40])                                  # flat, lattice-aligned boxes
         big, _, _ = rf.build_bvh(tris.reshape(300, 9))
         st = rf.wide_layout_stats(big)
-        assert bool(st["flags"] & 16) is want and bool(st["flags"] & 8)
+        assert bool(st["flags"] & 16) is want and bool(st["flags"] & 8) and bool(st["flags"] & 32)      # (the local-grid records have no range limit)
         if want:
             assert 1.0 < st["quad_half_area_ratio"] < 3.0
     # non-finite boxes: the packed slab test is not used at all
