@@ -176,7 +176,7 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *                                      (conservative binary16 planes, exact boxes at the leaves; 0 = never; defaults chosen per scene:
  *                                      rf_wide_layout_stats)
  *   quad_local_from_bounce, quad_local_shadow_from_bounce   the same for the 64-byte local-grid quad records (8-bit planes on a
- *                                      per-record power-of-two grid); the half-precision records take precedence
+ *                                      per-record power-of-two grid); closest-hit launches: the half-precision records take precedence; shadow launches: these do
  *   compact_from_bounce, compact_shadow_from_bounce   first bounce whose closest-hit / shadow launch reads the compact-capable records
  *                                      (three loads per descending step; defaults 3 / 2; 0 = never)
  *   hot_from_bounce, hot_shadow_from_bounce           the same for the 32-byte records (two loads per step; default 0 = never)
@@ -337,7 +337,8 @@ RF_API int rf_check_wide_layouts(const void* nodes48, uint64_t num_nodes, uint32
 /* The same check, plus (bit 3 = quad records usable, bit 4 = half-precision quad records usable) the figure the renderer's default
  * layout choice rests on: the surface area of the half-precision (binary16, conservative) child boxes relative to the exact ones,
  * summed over the tree -- the closest-hit launches read the half-precision records where it is <= 1.075 and the local-grid records
- * (bit 5) beyond; the shadow launches the local-grid records where it is <= 1.10 and the exact quad records beyond.  Either output may be NULL. */
+ * (bit 5, from bounce 2) beyond; the shadow launches the local-grid records from bounce 2 where it is <= 1.10 (bounce 1: the half-precision
+ * records where they suit) and the exact quad records otherwise.  Either output may be NULL. */
 RF_API int rf_wide_layout_stats(const void* nodes48, uint64_t num_nodes, uint32_t* flags_out, float* quad_half_area_ratio);
 
 /* Camera createCamera(origin, lookAt, aperture, focusDistance, vfov, aspectRatio)

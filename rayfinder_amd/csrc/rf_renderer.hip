@@ -2625,16 +2625,6 @@ struct Renderer::Impl
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    else if (wide.quadHalf != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
-                             optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce)
-                    {
-                        if (optShadowSignOrder)
-                            hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                        else
-                            hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    }
                     else if (wide.quadLocal != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                              optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce)
                     {
@@ -2643,6 +2633,16 @@ struct Renderer::Impl
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
                             hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+                    }
+                    else if (wide.quadHalf != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
+                             optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce)
+                    {
+                        if (optShadowSignOrder)
+                            hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+                        else
+                            hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
@@ -2750,8 +2750,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             m.wide.quadHalf = m.wideQuadHalf.ptr;
             // default (rf_wide.hpp, kQuadHalfMaxAreaRatio): the closest-hit launches read the half-precision records unless the binary16
             // grid is too coarse for this scene; the shadow launches prefer the local-grid records (below)
-            m.optQuadHalfFromBounce = wb.quadHalfAreaRatio <= kQuadHalfMaxAreaRatio ? 1u : 0u;
-            m.optQuadHalfShadowFromBounce = 0u;
+            m.optQuadHalfFromBounce = m.optQuadHalfShadowFromBounce = wb.quadHalfAreaRatio <= kQuadHalfMaxAreaRatio ? 1u : 0u;
             m.quadHalfAreaRatio = wb.quadHalfAreaRatio;
         }
         m.wide.quadLocal = nullptr;
@@ -2762,8 +2761,10 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             // closest-hit: the per-record 8-bit grid where binary16 of absolute coordinates is too coarse (small triangles far from the
             // origin); shadow: the local grid unless the scene is so finely tessellated that the exact records win (kQuadLocalShadowMaxAreaRatio)
             const float ratio = wb.quadHalf.empty() ? 2.0f : wb.quadHalfAreaRatio;
-            m.optQuadLocalFromBounce = m.optQuadHalfFromBounce == 0u ? 1u : 0u;
-            m.optQuadLocalShadowFromBounce = ratio <= kQuadLocalShadowMaxAreaRatio ? 1u : 0u;
+            // (from bounce 2: the coherent launches of bounce 1 gain nothing from it and lose 5 - 25 % in the larger scenes; the shadow launches
+            // of bounce 1 stay on the half-precision records where those suit the scene, on the exact ones elsewhere)
+            m.optQuadLocalFromBounce = m.optQuadHalfFromBounce == 0u ? 2u : 0u;
+            m.optQuadLocalShadowFromBounce = ratio <= kQuadLocalShadowMaxAreaRatio ? 2u : 0u;
         }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
