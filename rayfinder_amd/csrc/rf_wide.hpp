@@ -59,7 +59,11 @@ constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment buil
 constexpr int      kWideLdsStack = 160 * 1024 / RF_EXP_WAVES / 2048; // as deep as the LDS allows at that occupancy (7: 11, 8: 10)
 #else
 constexpr int      kWideWaves = 6;
+#if defined(RF_EXP_STACK)
+constexpr int      kWideLdsStack = RF_EXP_STACK; // experiment builds: a shallower LDS stack (what would it cost to free LDS for other lane state?)
+#else
 constexpr int      kWideLdsStack = 12;
+#endif
 #endif
 // kWideLdsStack: (child word, tmin) pairs per lane, all in LDS; deeper rays are redone by the scalar traversal
 
