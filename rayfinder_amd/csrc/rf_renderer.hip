@@ -728,9 +728,14 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     float     rayTMax = tMax;
     int       stackSize = 0;
     bool      needScalar = false; // irregular ray or stack overflow: redo with the scalar traversal
+    // An any-hit ray's rayTMax never changes, so an entry that passed `tmin < rayTMax` when it was pushed passes it when it is popped: such a
+    // kernel keeps only the words on its stack (no tmin to select, store and compare) -- except the reference-bookkeeping build, which
+    // pushes missed children with tmin = +inf to count them.
+    constexpr bool kStackWordsOnly = ANY_HIT && !kRefCount;
     auto      push = [&](uint32_t word, float tmin) -> bool {
         if (stackSize >= kDepth) return false;
-        sStack[stackSize * kBlock + threadIdx.x] = make_uint2(word, __float_as_uint(tmin));
+        if constexpr (kStackWordsOnly) sStack[stackSize * kBlock + threadIdx.x].x = word;
+        else sStack[stackSize * kBlock + threadIdx.x] = make_uint2(word, __float_as_uint(tmin));
         ++stackSize;
         return true;
     };
@@ -745,6 +750,16 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     auto popNext = [&]() {
         if (COMPACT != 0) haveOuter = false;
         node = kNodeDone;
+        if constexpr (kStackWordsOnly)
+        {
+            if (stackSize > 0)
+            {
+                --stackSize;
+                node = sStack[stackSize * kBlock + threadIdx.x].x;
+                if (COUNT) ++wPop;
+            }
+            return;
+        }
         while (stackSize > 0)
         {
             --stackSize;
