@@ -188,6 +188,8 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *                                      the triangles they hit (default 2; 0 = never: input order)
  *   uniform_fetch 0 | 1 | 2 | -1       scalar-cache fetch of wave-uniform records (1), and leaf triangles (2, default); -1: bounces 1-2 only
  *   shadow_nearest_first 0 | 1         any-hit child order: the reference's split-axis order | nearer slab entry first (default)
+ *   shadow_record_order 0 | 1          shadow launches on the 64-byte quad layouts: nearest-first | entries in record order (default: the
+ *                                      cheaper step wins where the VALU binds)
  *   packet_bounces n                   bounces 1..n traced by lockstep wave packets (default 0)
  *   slot_group_shift, sample_sort, accumulate_runs, shade_blocks, reserve_samples, persistent_blocks, extra_lds
  *                                      path-slot order, accumulation kernel, grid sizes, occupancy experiments
