@@ -32,8 +32,10 @@
  *     operation order: dot=(x+y)+z, normalize = v*(1/sqrt(dot)), min(a,b)=(b<a)?b:a,
  *     max(a,b)=(a<b)?b:a.
  *   - WGSL transcendental builtins (sin cos acos exp pow) have implementation-defined precision;
- *     the documented choice here is the correctly rounded f32 result, obtained by evaluating in
- *     f64 and rounding once (W_SIN etc. below).  sqrt and division are IEEE f32.
+ *     the documented choice here is the f32 rounding of a SPECIFIED f64 evaluation (fdlibm kernels
+ *     written out as IEEE f64 operations: d_exp / d_sin / d_cos / d_acos below; pow(x, 1.5) =
+ *     x * sqrt(x) in f64) -- the correctly rounded f32 except about once in 2^29 calls, and the
+ *     same bits on the GPU, which runs the same sequences.  sqrt and division are IEEE f32.
  *   - sky_state_new (host C code in the reference) uses libm float functions powf/fmodf exactly
  *     as hw_skymodel.c does.
  */
@@ -780,12 +782,119 @@ ORC_API int orc_aligned_sky_state(float turbidity, const float* albedo3, float s
 /* ------------------------------------------------------------------------------------------ */
 /* WGSL path tracer  (pt/reference_path_tracer.wgsl)                                            */
 /* ------------------------------------------------------------------------------------------ */
-/* WGSL builtins, correctly rounded f32 (see header). */
-static inline float W_SIN(float x) { return (float)sin((double)x); }
-static inline float W_COS(float x) { return (float)cos((double)x); }
-static inline float W_ACOS(float x) { return (float)acos((double)x); }
-static inline float W_EXP(float x) { return (float)exp((double)x); }
+/* WGSL builtins with implementation-defined precision (sin cos acos exp, and the one pow(x, 1.5) of the sky model).  Documented choice
+ * since round 3: the f32 rounding of a SPECIFIED f64 evaluation -- the classic fdlibm kernels (Sun Microsystems, freely distributable),
+ * written out below as plain sequences of IEEE f64 operations (+ - * / sqrt fma rint ldexp), each within about one ulp(f64) of the true
+ * value, i.e. the correctly rounded f32 except about once in 2^29 calls.  The product evaluates the SAME sequences on the GPU
+ * (rf_device.hpp), so the two sides agree bit for bit by construction; with the C library's functions on one side and ocml's on the
+ * other they differed in the last f64 bit now and then, and once in ~10^9 calls that bit decided an f32 rounding (2 of 20 000 fuzz scenes).
+ * pow() proper is kept for the two display-side uses (sRGB -> linear table, built on the host on both sides; tonemap, quantised to 8 bits). */
+static double d_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.0) return INFINITY;
+    if (x < -745.0) return 0.0;
+    const double k = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    /* exp(r), |r| <= 0.3466: Taylor polynomial of degree 13, Horner with fma */
+    double p = 1.6059043836821613e-10;           /* 1/13! */
+    p = fma(p, r, 2.08767569878681e-09);        /* 1/12! */
+    p = fma(p, r, 2.505210838544172e-08);       /* 1/11! */
+    p = fma(p, r, 2.755731922398589e-07);       /* 1/10! */
+    p = fma(p, r, 2.7557319223985893e-06);      /* 1/9! */
+    p = fma(p, r, 2.48015873015873e-05);        /* 1/8! */
+    p = fma(p, r, 0.0001984126984126984);       /* 1/7! */
+    p = fma(p, r, 0.001388888888888889);        /* 1/6! */
+    p = fma(p, r, 0.008333333333333333);        /* 1/5! */
+    p = fma(p, r, 0.041666666666666664);        /* 1/4! */
+    p = fma(p, r, 0.16666666666666666);         /* 1/3! */
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+/* sin and cos of r in [-pi/4, pi/4] (fdlibm __kernel_sin / __kernel_cos without the tail argument) */
+static double d_ksin(double r)
+{
+    const double z = r * r;
+    const double t = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    return r + (r * z) * t;
+}
+static double d_kcos(double r)
+{
+    const double z = r * r;
+    const double t = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    return (1.0 - 0.5 * z) + (z * z) * t;
+}
+/* argument reduction by pi/2 in three parts (exact products through fma); meant for the |x| <= 2 pi of this renderer, defined for all x */
+static double d_reduce(double x, long long* quadrant)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    *quadrant = (long long)k;
+    return r;
+}
+static double d_sin(double x)
+{
+    if (!(fabs(x) < 1.0e15)) return x - x; /* inf, NaN (and arguments no f32 angle of this renderer reaches): NaN */
+    long long q;
+    const double r = d_reduce(x, &q);
+    switch (q & 3) { case 0: return d_ksin(r); case 1: return d_kcos(r); case 2: return -d_ksin(r); default: return -d_kcos(r); }
+}
+static double d_cos(double x)
+{
+    if (!(fabs(x) < 1.0e15)) return x - x;
+    long long q;
+    const double r = d_reduce(x, &q);
+    switch (q & 3) { case 0: return d_kcos(r); case 1: return -d_ksin(r); case 2: return -d_kcos(r); default: return d_ksin(r); }
+}
+/* fdlibm __ieee754_acos */
+static double d_acos_ratio(double z)
+{
+    const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 + z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+    const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+    return p / q;
+}
+static double d_acos(double x)
+{
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
+    if (x != x) return x;
+    if (fabs(x) >= 1.0)
+    {
+        if (x == 1.0) return 0.0;
+        if (x == -1.0) return pi + 2.0 * pio2_lo;
+        return (x - x) / (x - x); /* |x| > 1: NaN */
+    }
+    if (fabs(x) < 0.5)
+    {
+        if (fabs(x) <= 6.938893903907228e-18) return pio2_hi + pio2_lo; /* 2^-57 */
+        const double r = d_acos_ratio(x * x);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (x < 0.0)
+    {
+        const double z = (1.0 + x) * 0.5, s = sqrt(z), r = d_acos_ratio(z), w = r * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    }
+    const double z = (1.0 - x) * 0.5, s = sqrt(z);
+    uint64_t bits; memcpy(&bits, &s, 8); bits &= 0xFFFFFFFF00000000ull;
+    double df; memcpy(&df, &bits, 8);
+    const double c = (z - df * df) / (s + df), r = d_acos_ratio(z), w = r * s + c;
+    return 2.0 * (df + w);
+}
+ORC_API double orc_d_exp(double x) { return d_exp(x); }
+ORC_API double orc_d_sin(double x) { return d_sin(x); }
+ORC_API double orc_d_cos(double x) { return d_cos(x); }
+ORC_API double orc_d_acos(double x) { return d_acos(x); }
+static inline float W_SIN(float x) { return (float)d_sin((double)x); }
+static inline float W_COS(float x) { return (float)d_cos((double)x); }
+static inline float W_ACOS(float x) { return (float)d_acos((double)x); }
+static inline float W_EXP(float x) { return (float)d_exp((double)x); }
 static inline float W_POW(float x, float y) { return (float)pow((double)x, (double)y); }
+static inline float W_POW15(float x) { const double xd = (double)x; return (float)(xd * sqrt(xd)); } /* pow(x, 1.5f): within 1.5 ulp(f64) */
 static inline float W_FRACT(float x) { return x - floorf(x); } /* WGSL fract = e - floor(e) */
 
 static const float W_PI = 3.1415927f;       /* wgsl:68 */
@@ -859,7 +968,7 @@ static float sky_radiance(const float* sky, float theta, float gamma, uint32_t c
     const float expM = W_EXP(p[4] * gamma);
     const float rayM = cosGamma2;
     const float mieMLhs = 1.0f + cosGamma2;
-    const float mieMRhs = W_POW(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma, 1.5f);
+    const float mieMRhs = W_POW15(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma);
     const float mieM = mieMLhs / mieMRhs;
     const float zenith = sqrtf(cosTheta);
     const float radianceLhs = 1.0f + p[0] * W_EXP(p[1] / (cosTheta + 0.01f));

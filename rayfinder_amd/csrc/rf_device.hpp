@@ -248,32 +248,122 @@ __device__ __forceinline__ bool traverse(const DeviceScene& scene, Vec3 origin, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// WGSL builtins with implementation-defined precision: documented choice = correctly rounded f32,
-// obtained by evaluating in f64 and rounding once (DESIGN.md "Floating point policy").
+// WGSL builtins with implementation-defined precision (sin cos acos exp, and the sky model's pow(x, 1.5)).  Documented choice since
+// round 3 (DESIGN.md "Floating point policy"): the f32 rounding of a SPECIFIED f64 evaluation -- the classic fdlibm kernels written
+// out as plain sequences of IEEE f64 operations (+ - * / sqrt fma rint ldexp), each within about an ulp(f64) of the true value, i.e.
+// the correctly rounded f32 except about once in 2^29 calls.  The test oracle evaluates the same sequences on the CPU, so the two sides agree
+// bit for bit by construction (ocml against the C library did not: they differ in the last f64 bit now and then, and once in ~10^9
+// calls that bit decided an f32 rounding).  No special cases beyond NaN / out-of-range: leaner than the library calls as well.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wSin(float x) { return static_cast<float>(sin(static_cast<double>(x))); }
-__device__ __forceinline__ float wCos(float x) { return static_cast<float>(cos(static_cast<double>(x))); }
-__device__ __forceinline__ float wAcos(float x) { return static_cast<float>(acos(static_cast<double>(x))); }
-__device__ __forceinline__ float wExp(float x) { return static_cast<float>(exp(static_cast<double>(x))); }
+__device__ __forceinline__ double dExp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.0) return __builtin_inf();
+    if (x < -745.0) return 0.0;
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    double       r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                 // 1/13!: Taylor polynomial of degree 13 on |r| <= 0.3466, Horner with fma
+    p = __builtin_fma(p, r, 2.08767569878681e-09);    // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);   // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);   // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);  // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);    // 1/8!
+    p = __builtin_fma(p, r, 0.0001984126984126984);   // 1/7!
+    p = __builtin_fma(p, r, 0.001388888888888889);    // 1/6!
+    p = __builtin_fma(p, r, 0.008333333333333333);    // 1/5!
+    p = __builtin_fma(p, r, 0.041666666666666664);    // 1/4!
+    p = __builtin_fma(p, r, 0.16666666666666666);     // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, static_cast<int>(k));
+}
+// sin and cos on [-pi/4, pi/4] (fdlibm __kernel_sin / __kernel_cos without the tail argument)
+__device__ __forceinline__ double dKSin(double r)
+{
+    const double z = r * r;
+    const double t = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    return r + (r * z) * t;
+}
+__device__ __forceinline__ double dKCos(double r)
+{
+    const double z = r * r;
+    const double t = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    return (1.0 - 0.5 * z) + (z * z) * t;
+}
+// argument reduction by pi/2 in three parts (exact products through fma); meant for the |x| <= 2 pi of this renderer, defined for all x
+__device__ __forceinline__ double dReduce(double x, long long& quadrant)
+{
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+    double       r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
+    r = __builtin_fma(-k, 2.02226624879595063154e-21, r);
+    quadrant = static_cast<long long>(k);
+    return r;
+}
+__device__ __forceinline__ double dSin(double x)
+{
+    if (!(__builtin_fabs(x) < 1.0e15)) return x - x; // inf, NaN: NaN
+    long long    q;
+    const double r = dReduce(x, q), s = dKSin(r), c = dKCos(r);
+    switch (q & 3) { case 0: return s; case 1: return c; case 2: return -s; default: return -c; }
+}
+__device__ __forceinline__ double dCos(double x)
+{
+    if (!(__builtin_fabs(x) < 1.0e15)) return x - x;
+    long long    q;
+    const double r = dReduce(x, q), s = dKSin(r), c = dKCos(r);
+    switch (q & 3) { case 0: return c; case 1: return -s; case 2: return -c; default: return s; }
+}
+// fdlibm __ieee754_acos
+__device__ __forceinline__ double dAcosRatio(double z)
+{
+    const double p = z * (1.66666666666666657415e-01 + z * (-3.25565818622400915405e-01 + z * (2.01212532134862925881e-01 + z * (-4.00555345006794114027e-02 + z * (7.91534994289814532176e-04 + z * 3.47933107596021167570e-05)))));
+    const double q = 1.0 + z * (-2.40339491173441421878e+00 + z * (2.02094576023350569471e+00 + z * (-6.88283971605453293030e-01 + z * 7.70381505559019352791e-02)));
+    return p / q;
+}
+__device__ __forceinline__ double dAcos(double x)
+{
+    const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
+    if (x != x) return x;
+    if (__builtin_fabs(x) >= 1.0)
+    {
+        if (x == 1.0) return 0.0;
+        if (x == -1.0) return pi + 2.0 * pio2_lo;
+        return (x - x) / (x - x); // |x| > 1: NaN
+    }
+    if (__builtin_fabs(x) < 0.5)
+    {
+        if (__builtin_fabs(x) <= 6.938893903907228e-18) return pio2_hi + pio2_lo; // 2^-57
+        const double r = dAcosRatio(x * x);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (x < 0.0)
+    {
+        const double z = (1.0 + x) * 0.5, s = __builtin_sqrt(z), r = dAcosRatio(z), w = r * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    }
+    const double z = (1.0 - x) * 0.5, s = __builtin_sqrt(z);
+    const double df = __longlong_as_double(__double_as_longlong(s) & static_cast<long long>(0xFFFFFFFF00000000ull));
+    const double c = (z - df * df) / (s + df), r = dAcosRatio(z), w = r * s + c;
+    return 2.0 * (df + w);
+}
+__device__ __forceinline__ float wSin(float x) { return static_cast<float>(dSin(static_cast<double>(x))); }
+__device__ __forceinline__ float wCos(float x) { return static_cast<float>(dCos(static_cast<double>(x))); }
+__device__ __forceinline__ float wAcos(float x) { return static_cast<float>(dAcos(static_cast<double>(x))); }
+__device__ __forceinline__ float wExp(float x) { return static_cast<float>(dExp(static_cast<double>(x))); }
+// (display side only -- the tonemap's pow(y, 1 / 2.2), quantised to 8 bits: the library call)
 __device__ __forceinline__ float wPow(float x, float y)
 {
     return static_cast<float>(pow(static_cast<double>(x), static_cast<double>(y)));
 }
-// pow(x, 1.5f) of the sky model's Mie term (three per path that leaves the scene; the f64 pow is by far the most expensive call
-// of kSky).  x * sqrt(x) in f64 is within 1.5 ulp(f64) of x^1.5 (correctly rounded sqrt, one rounded product), so it rounds to the
-// same f32 as the correctly rounded result unless it lies within a few ulp(f64) of an f32 rounding boundary -- the bit pattern
-// 1000..0 in the 29 mantissa bits an f32 drops; only then (8 of 2^29 arguments) is the real pow() evaluated.  Same value for
-// every input: negative x gives NaN on both routes, -0 gives +0, inf gives inf; f32-subnormal results take the pow() route.
+// pow(x, 1.5f) of the sky model's Mie term = x * sqrt(x) in f64 (correctly rounded sqrt, one rounded product: within 1.5 ulp(f64) of
+// x^1.5), the same expression in the test oracle.  Negative x gives NaN, -0 gives +0... as pow does.
 __device__ __forceinline__ float wPow15(float x)
 {
-    const double   xd = static_cast<double>(x);
-    const double   y = xd * sqrt(xd);
-    const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(y));
-    const uint32_t low = static_cast<uint32_t>(bits) & 0x1FFFFFFFu;           // the mantissa bits below an f32's last place
-    const uint32_t dist = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low; // distance from the rounding boundary, in ulp(f64)
-    const bool     normalF32 = y >= 1.1754943508222875e-38 || y == 0.0;       // (below that the f32 grid is coarser than assumed here)
-    if (__builtin_expect(dist > 8u && normalF32, 1)) return static_cast<float>(y);
-    return static_cast<float>(pow(xd, 1.5));
+    const double xd = static_cast<double>(x);
+    return static_cast<float>(xd * __builtin_sqrt(xd));
 }
 __device__ __forceinline__ float wFract(float x) { return x - floorf(x); }
 

@@ -520,3 +520,32 @@ def test_oracle_stack_bound_is_the_products_96_entries():
         else:
             assert o["hit"][0] == 0 and o["stackHigh"][0] == 97          # abandoned before any leaf was reached
             assert vis[0] == 1.0
+
+
+def test_wgsl_builtins_are_the_specified_f64_evaluations():
+    """sin / cos / acos / exp of the WGSL restatement are the f32 roundings of SPECIFIED f64 sequences (fdlibm kernels, rf_oracle.c d_exp
+    ...; the product runs the same sequences on the GPU): within a few ulp(f64) of the C library over the argument ranges the renderer
+    uses -- so the f32 rounding is the correctly rounded value except about once in 2^29 calls -- and the IEEE special cases hold."""
+    import ctypes as C
+    import math
+    L = orc.lib()
+    for n in ("orc_d_exp", "orc_d_sin", "orc_d_cos", "orc_d_acos"):
+        f = getattr(L, n); f.restype = C.c_double; f.argtypes = [C.c_double]
+    rng = np.random.default_rng(3)
+    def worst(f, g, xs, absolute_floor=0.0):
+        w = 0.0
+        for x in xs:
+            a, b = f(float(x)), g(float(x))
+            w = max(w, abs(a - b) / max(math.ulp(b), absolute_floor))
+        return w
+    ex = np.concatenate([rng.uniform(-90, 90, 40000), rng.uniform(-1, 1, 20000) * 10.0 ** rng.uniform(-8, 1, 20000)]).astype(np.float32)
+    assert worst(L.orc_d_exp, math.exp, ex) <= 1.5
+    an = np.concatenate([rng.uniform(0, 2 * np.pi, 60000), rng.uniform(-7, 7, 20000)]).astype(np.float32)
+    # (near the zeros of sin / cos the error is a few ulp of the tiny RESULT, i.e. ~1e-17 absolute: far below an f32's half ulp)
+    assert worst(L.orc_d_sin, math.sin, an, absolute_floor=2.0 ** -54) <= 2.0
+    assert worst(L.orc_d_cos, math.cos, an, absolute_floor=2.0 ** -54) <= 2.0
+    ac = np.concatenate([rng.uniform(-1, 1, 60000), [1.0, -1.0, 0.0, 0.5, -0.5, np.nextafter(np.float32(1), np.float32(0)), np.float32(0.49999997)]]).astype(np.float32)
+    assert worst(L.orc_d_acos, math.acos, ac) <= 1.5
+    assert math.isnan(L.orc_d_acos(1.5)) and math.isnan(L.orc_d_acos(float("nan"))) and math.isnan(L.orc_d_sin(float("inf")))
+    assert L.orc_d_exp(-800.0) == 0.0 and L.orc_d_exp(800.0) == float("inf") and L.orc_d_exp(0.0) == 1.0
+    assert L.orc_d_acos(1.0) == 0.0 and L.orc_d_cos(0.0) == 1.0 and L.orc_d_sin(0.0) == 0.0
