@@ -745,6 +745,12 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     uint32_t          rayNodes = 0, rayTris = 0, rayStackHigh = 0;  // COUNT: the ray in flight
     uint32_t          recordFetches = 0;
     uint32_t          wDescend = 0, wLeaf = 0, wLeafPhase = 0, wRefill = 0, wPop = 0, wOuter = 0; // COUNT: loop trips
+#if defined(RF_EXP_PHASE)
+    constexpr bool kPhase = true; // experiment build: the wave-trip / lane-trip counters of the COUNT build in EVERY kTraceWide (RF_DEBUG_COUNTERS prints them)
+    uint32_t       phaseTris = 0, phaseLeafWave = 0;
+#else
+    constexpr bool kPhase = COUNT;
+#endif
 
     // Pop entries until one passes `tmin < rayTMax` (the reference's box test at pop time).
     auto popNext = [&]() {
@@ -777,13 +783,13 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 
     for (;;)
     {
-        if (COUNT) ++wOuter;
+        if (kPhase) ++wOuter;
         // ---- refill idle lanes from the wave's chunk
         const unsigned long long idleMask = __ballot(node == kNodeIdle);
         const uint32_t           idleCount = __popcll(idleMask);
         if (!exhausted && idleCount >= refillMin)
         {
-            if (COUNT) ++wRefill;
+            if (kPhase) ++wRefill;
             // queue positions for the idle lanes, in lane order; a refill that reaches the end of the wave's chunk goes on in the
             // next one (it used to stop there and leave the remaining lanes idle until the next refill: one refill in three)
             const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
@@ -884,10 +890,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         // ---- descend: one 64-byte record = both children of an accepted interior node
         do
         {
-            if (COUNT) ++wDescend;
+            if (kPhase) ++wDescend;
             if (static_cast<int32_t>(node) >= 0)
             {
-                if (COUNT) ++recordFetches;
+                if (kPhase) ++recordFetches;
                 if constexpr (COMPACT == 3 || COMPACT == 4 || COMPACT == 5)
                 {
                     // ---- quad records (rf_wide.hpp): the boxes of the node's (up to) four grandchildren in ONE 128-byte record --
@@ -1320,6 +1326,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         } while (__popcll(__ballot(static_cast<int32_t>(node) >= 0)) >= leafVote);
 
         // ---- leaves
+#if defined(RF_EXP_PHASE)
+        if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull) ++phaseLeafWave;
+#endif
         if (node - kWideLeafBit < kNodeDone - kWideLeafBit)
         {
             uint32_t first = node & ((1u << kWideIndexBits) - 1u), n = ((node >> kWideIndexBits) & 7u) + 1u;
@@ -1330,7 +1339,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 n = big.y;
             }
             bool finished = false;
-            if (COUNT) ++wLeafPhase;
+            if (kPhase) ++wLeafPhase;
             float4 firstA{}, firstB{}, firstC{};
             if constexpr (COMPACT == 4 || COMPACT == 5)
             {
@@ -1364,7 +1373,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             for (uint32_t i = 0; i < n; ++i)
             {
-                if (COUNT) ++wLeaf;
+                if (kPhase) ++wLeaf;
                 const uint32_t tri = first + i;
                 Vec3           p0, p1, p2;
                 // the same triangle in every lane of this leaf phase (one pixel's samples reaching the same leaf): scalar cache
@@ -1393,6 +1402,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
                 }
                 if (COUNT) ++rayTris;
+#if defined(RF_EXP_PHASE)
+                ++phaseTris;
+#endif
                 TriangleHit th;
                 if (intersectTriangle(vec3(pr.oXY.x, pr.oXY.y, pr.oZ), rayDir, p0, p1, p2, rayTMax, th))
                 {
@@ -1487,6 +1499,24 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             atomicAdd(&counters->outerTrips[k], static_cast<unsigned long long>(o));
         }
     }
+#if defined(RF_EXP_PHASE)
+    if (!COUNT)
+    {
+        const int                k = ANY_HIT ? 1 : 0;
+        const unsigned long long laneSteps = waveSum(recordFetches), laneLeaves = waveSum(wLeafPhase), laneTris = waveSum(phaseTris);
+        const uint32_t           d = waveMax(wDescend), lp = waveMax(phaseLeafWave), r = waveMax(wRefill), o = waveMax(wOuter);
+        if (lane == 0)
+        {
+            atomicAdd(ANY_HIT ? &counters->shadowRecordFetches : &counters->closestRecordFetches, laneSteps);
+            atomicAdd(&counters->descendTrips[k], static_cast<unsigned long long>(d));
+            atomicAdd(&counters->leafPhases[k], static_cast<unsigned long long>(lp));
+            atomicAdd(&counters->leafTrips[k], laneLeaves);
+            atomicAdd(&counters->popLaneTrips[k], laneTris);
+            atomicAdd(&counters->refillTrips[k], static_cast<unsigned long long>(r));
+            atomicAdd(&counters->outerTrips[k], static_cast<unsigned long long>(o));
+        }
+    }
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
 }
 
@@ -3287,6 +3317,21 @@ RenderStats Renderer::stats()
     s.scalarRedoRays = c.scalarRedo[0] + c.scalarRedo[1];
     if (std::getenv("RF_DEBUG_COUNTERS"))
         std::fprintf(stderr, "[rf] rays redone by the scalar traversal: closest %llu of %llu, shadow %llu of %llu\n", c.scalarRedo[0], c.closestRays, c.scalarRedo[1], c.shadowRays);
+#if defined(RF_EXP_PHASE)
+    if (std::getenv("RF_DEBUG_COUNTERS") && !m.counting)
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            const double rays = static_cast<double>(k ? c.shadowRays : c.closestRays), steps = static_cast<double>(k ? c.shadowRecordFetches : c.closestRecordFetches);
+            std::fprintf(stderr,
+                         "[rf-phase] %s: rays %.0f | per ray: steps %.2f leaf visits %.2f triangle tests %.2f | wave trips per 64 rays: outer %.2f descend %.2f leaf phase %.2f refill %.2f"
+                         " | lanes busy: descend %.3f leaf phase %.3f\n",
+                         k ? "shadow " : "closest", rays, steps / rays, c.leafTrips[k] / rays, c.popLaneTrips[k] / rays, c.outerTrips[k] * 64.0 / rays,
+                         c.descendTrips[k] * 64.0 / rays, c.leafPhases[k] * 64.0 / rays, c.refillTrips[k] * 64.0 / rays, steps / (64.0 * c.descendTrips[k]),
+                         c.leafTrips[k] / (64.0 * c.leafPhases[k]));
+        }
+    }
+#endif
     if (std::getenv("RF_DEBUG_COUNTERS") && m.counting)
     {
         for (int k = 0; k < 2; ++k)
