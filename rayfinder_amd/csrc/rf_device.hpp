@@ -279,19 +279,6 @@ __device__ __forceinline__ double dExp(double x)
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, static_cast<int>(k));
 }
-// sin and cos on [-pi/4, pi/4] (fdlibm __kernel_sin / __kernel_cos without the tail argument)
-__device__ __forceinline__ double dKSin(double r)
-{
-    const double z = r * r;
-    const double t = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-    return r + (r * z) * t;
-}
-__device__ __forceinline__ double dKCos(double r)
-{
-    const double z = r * r;
-    const double t = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
-    return (1.0 - 0.5 * z) + (z * z) * t;
-}
 // argument reduction by pi/2 in three parts (exact products through fma); meant for the |x| <= 2 pi of this renderer, defined for all x
 __device__ __forceinline__ double dReduce(double x, long long& quadrant)
 {
@@ -302,19 +289,31 @@ __device__ __forceinline__ double dReduce(double x, long long& quadrant)
     quadrant = static_cast<long long>(k);
     return r;
 }
+// sin or cos on [-pi/4, pi/4]: fdlibm __kernel_sin / __kernel_cos without the tail argument.  One polynomial per call -- which of the
+// two the quadrant asks for is decided first (the other one's value is never used, and a `switch` over both would evaluate both for
+// every lane of the wave); the operations on the chosen path are the kernel's own.
+__device__ __forceinline__ double dSinCosKernel(double r, bool cosine)
+{
+    const double z = r * r;
+    const double c5 = cosine ? -1.13596475577881948265e-11 : 1.58969099521155010221e-10, c4 = cosine ? 2.08757232129817482790e-09 : -2.50507602534068634195e-08;
+    const double c3 = cosine ? -2.75573143513906633035e-07 : 2.75573137070700676789e-06, c2 = cosine ? 2.48015872894767294178e-05 : -1.98412698298579493134e-04;
+    const double c1 = cosine ? -1.38888888888741095749e-03 : 8.33333333332248946124e-03, c0 = cosine ? 4.16666666666666019037e-02 : -1.66666666666666324348e-01;
+    const double t = c0 + z * (c1 + z * (c2 + z * (c3 + z * (c4 + z * c5))));
+    return cosine ? (1.0 - 0.5 * z) + (z * z) * t : r + (r * z) * t;
+}
 __device__ __forceinline__ double dSin(double x)
 {
     if (!(__builtin_fabs(x) < 1.0e15)) return x - x; // inf, NaN: NaN
     long long    q;
-    const double r = dReduce(x, q), s = dKSin(r), c = dKCos(r);
-    switch (q & 3) { case 0: return s; case 1: return c; case 2: return -s; default: return -c; }
+    const double r = dReduce(x, q), v = dSinCosKernel(r, (q & 1) != 0);
+    return (q & 2) ? -v : v; // quadrants 0..3: s, c, -s, -c
 }
 __device__ __forceinline__ double dCos(double x)
 {
     if (!(__builtin_fabs(x) < 1.0e15)) return x - x;
     long long    q;
-    const double r = dReduce(x, q), s = dKSin(r), c = dKCos(r);
-    switch (q & 3) { case 0: return c; case 1: return -s; case 2: return -c; default: return s; }
+    const double r = dReduce(x, q), v = dSinCosKernel(r, (q & 1) == 0);
+    return ((q + 1) & 2) ? -v : v; // quadrants 0..3: c, -s, -c, s
 }
 // fdlibm __ieee754_acos
 __device__ __forceinline__ double dAcosRatio(double z)
@@ -333,20 +332,22 @@ __device__ __forceinline__ double dAcos(double x)
         if (x == -1.0) return pi + 2.0 * pio2_lo;
         return (x - x) / (x - x); // |x| > 1: NaN
     }
-    if (__builtin_fabs(x) < 0.5)
+    // The three ranges of fdlibm share ONE evaluation of the rational function and ONE square root (the lanes of a wave fall into all
+    // three, and as separate branches each would run its own division and square root for the whole wave); every lane still performs
+    // exactly the operations of its own range.
+    const bool   small = __builtin_fabs(x) < 0.5, negative = x < 0.0;
+    if (small && __builtin_fabs(x) <= 6.938893903907228e-18) return pio2_hi + pio2_lo; // 2^-57
+    const double z = small ? x * x : (negative ? (1.0 + x) * 0.5 : (1.0 - x) * 0.5);
+    const double r = dAcosRatio(z);
+    if (small) return pio2_hi - (x - (pio2_lo - x * r));
+    const double s = __builtin_sqrt(z);
+    if (negative)
     {
-        if (__builtin_fabs(x) <= 6.938893903907228e-18) return pio2_hi + pio2_lo; // 2^-57
-        const double r = dAcosRatio(x * x);
-        return pio2_hi - (x - (pio2_lo - x * r));
-    }
-    if (x < 0.0)
-    {
-        const double z = (1.0 + x) * 0.5, s = __builtin_sqrt(z), r = dAcosRatio(z), w = r * s - pio2_lo;
+        const double w = r * s - pio2_lo;
         return pi - 2.0 * (s + w);
     }
-    const double z = (1.0 - x) * 0.5, s = __builtin_sqrt(z);
     const double df = __longlong_as_double(__double_as_longlong(s) & static_cast<long long>(0xFFFFFFFF00000000ull));
-    const double c = (z - df * df) / (s + df), r = dAcosRatio(z), w = r * s + c;
+    const double c = (z - df * df) / (s + df), w = r * s + c;
     return 2.0 * (df + w);
 }
 __device__ __forceinline__ float wSin(float x) { return static_cast<float>(dSin(static_cast<double>(x))); }
