@@ -1824,7 +1824,11 @@ __global__ __launch_bounds__(kBlock) void kAccumulate(FrameParams fp, const uint
 // 320 spp of a 1080p frame).  Here one wave takes kAccPixels pixels: their runs are read coalesced (1 KiB per load) into LDS, then
 // one lane per (pixel, channel) adds its samples in sample-index order -- the order is the result (f32, H15), so the
 // additions stay sequential; only the memory traffic changes.  Dynamic LDS: kAccPixels * numSamples * 12 bytes.
+#if defined(RF_EXP_ACC_PIXELS)
+constexpr uint32_t kAccPixels = RF_EXP_ACC_PIXELS;
+#else
 constexpr uint32_t kAccPixels = 4;
+#endif
 constexpr uint32_t kAccMaxSamples = 1024;
 
 __global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image)
@@ -1840,10 +1844,12 @@ __global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint
         float*        dst = sRun + px * 3u * S;
         for (uint32_t p = lane; p < S; p += 64u)
         {
-            const Vec3 v = load3(run + p);
-            dst[p] = v.x;
-            dst[S + p] = v.y;
-            dst[2u * S + p] = v.z;
+            // position p of the run holds sample samplePerm[p]: stored at ITS index, so that the sums below walk LDS in order
+            const Vec3     v = load3(run + p);
+            const uint32_t k = fp.samplePerm ? fp.samplePerm[p] : p;
+            dst[k] = v.x;
+            dst[S + k] = v.y;
+            dst[2u * S + k] = v.z;
         }
     }
     __syncthreads();
@@ -1855,7 +1861,8 @@ __global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint
     float*       out = reinterpret_cast<float*>(image + lp) + c;
     float        acc = *out;
     const float* src = sRun + (px * 3u + c) * S;
-    for (uint32_t k = 0; k < S; ++k) acc += src[fp.sampleInvPerm ? fp.sampleInvPerm[k] : k];
+#pragma unroll 8
+    for (uint32_t k = 0; k < S; ++k) acc += src[k]; // sample order (wgsl:56-57): one dependent chain of f32 additions per channel
     *out = acc;
 }
 
