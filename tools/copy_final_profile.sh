@@ -1,0 +1,15 @@
+#!/bin/bash
+# After `gpurun -- bash tools/final_profile_r03.sh`: copy what was merged into gpurun_out/ into the tracked profiles/ directories
+# (container side; the recipe's directory is called `roofline`, the profile name inside the json files is set to the directory's).
+set -e
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+cd $REPO
+F=gpurun_out/r03_final; P=profiles/r03_final
+cp $F/roofline/*.txt $F/roofline/*.csv $F/roofline/*.json $F/roofline/*.jsonl $F/roofline/trace.log $P/
+cp $F/bench_*.json $F/shard_emulation.log $P/
+tail -3 $F/pytest_gpu.log > $P/pytest_gpu.txt
+cp $F/pmc_per_ray.json profiles/pmc_per_ray.json
+cp $F/pmc_per_ray_x8.json profiles/pmc_per_ray_x8.json
+for f in $(ls gpurun_out/r03_hbm | grep -v bench.err); do cp gpurun_out/r03_hbm/$f profiles/r03_hbm/$f; done
+sed -i 's/"profile": "roofline"/"profile": "r03_final"/' profiles/pmc_per_ray.json $P/pmc_per_ray.json $P/per_bounce.json
+git status --short profiles | wc -l
