@@ -397,7 +397,7 @@ constexpr uint32_t kSortBins = 256;
 #if defined(RF_EXP_SHADE_WAVES)
 #define RF_SHADE_BOUNDS __launch_bounds__(kBlock, RF_EXP_SHADE_WAVES)
 #else
-#define RF_SHADE_BOUNDS __launch_bounds__(kBlock)
+#define RF_SHADE_BOUNDS __launch_bounds__(kBlock) // (SORTED: 137 registers, three waves per SIMD; forced into 128 for four it is 2.5 % slower)
 #endif
 template<bool SORTED>
 __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
@@ -408,6 +408,8 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     __shared__ uint32_t sScratch[8];
     __shared__ uint32_t sHist[SORTED ? kSortBins : 1], sStart[SORTED ? kSortBins : 1], sPerm[SORTED ? kItems * kBlock : 1];
     __shared__ float    sLut[256];
+    constexpr uint32_t  kTile = kItems * kBlock;
+    __shared__ float    sIn[SORTED ? 9 * kTile : 1]; // SORTED: throughput, blue-noise triple and {triangle, u, v} of the tile's hits, [component][entry of the tile]
     const uint32_t      count = *queueCount;
     // grid-stride over tiles of kItems * kBlock queue entries: the grid is capped (kShadeMaxBlocks), so late bounces, whose
     // queues hold a sixth of the paths, do not pay for hundreds of thousands of empty workgroups
@@ -434,11 +436,26 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
         if (i >= count) continue;
         slots[k] = queue[i];
         missEntries[k] = i; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there
-        const uint32_t tri = __float_as_uint(ps.hit[i].x); // hit records sit at QUEUE positions (dense)
+        const Vec3     hitRec = SORTED ? load3(ps.hit + i) : vec3(ps.hit[i].x, 0.0f, 0.0f); // hit records sit at QUEUE positions (dense)
+        const uint32_t tri = __float_as_uint(hitRec.x);
         hitTri[k] = tri;
         isMiss[k] = tri == kMiss; // the path ends in the sky: evaluated densely by this bounce's kSky launch
         isHit[k] = tri != kMiss;
+        if constexpr (SORTED)
+        {
+            if (isHit[k])
+            {
+                // what pass 2 needs of this entry, read here in INPUT order (coalesced) and handed over in LDS: pass 2 works in the
+                // tile's sorted order, where the 64 lanes of a wave would gather from ~57 different lines per stream
+                const uint32_t l = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
+                const Vec3     t = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i), z = load3(ps.noise + i);
+                sIn[l] = t.x, sIn[kTile + l] = t.y, sIn[2 * kTile + l] = t.z;
+                sIn[3 * kTile + l] = z.x, sIn[4 * kTile + l] = z.y, sIn[5 * kTile + l] = z.z;
+                sIn[6 * kTile + l] = hitRec.x, sIn[7 * kTile + l] = hitRec.y, sIn[8 * kTile + l] = hitRec.z;
+            }
+        }
     }
+    uint32_t sortedHits = 0, sortedBase = 0; // SORTED: hits of the tile, and where its run starts in the next queue
     if constexpr (SORTED)
     {
         // counting sort of the tile's hits by triangle range: rank inside the bin from an LDS counter, bin starts from a block scan
@@ -481,6 +498,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
         __syncthreads();
         // the thread's work from here on: entries k * 256 + tid of the SORTED order
         const uint32_t tileHits = sScratch[5], base = sScratch[4];
+        sortedHits = tileHits, sortedBase = base;
 #pragma unroll
         for (int k = 0; k < kItems; ++k)
         {
@@ -499,38 +517,76 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
         blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch, &outPos);
     blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
 
-    // Pass 2: shade the hits
-#pragma unroll 1
-    for (int k = 0; k < kItems; ++k)
+    // Pass 2: shade the hits.  An entry is a chain of dependent gathers -- hit record -> shading record -> texture descriptor -> texel --
+    // and four entries one after the other were four such chains end to end: the kernel waited.  Now the hit records of all
+    // four entries are requested up front, and the shading record of entry k + 1 while entry k is shaded (its texel fetch included).
+    // (SORTED only: bounce 1 -- coherent records, no sort -- streams at its memory rate as one entry at a time with fewer registers)
+    constexpr bool kPipelined = SORTED;
+    Vec3           hits[kPipelined ? kItems : 1]; // {triangle, u, v} of the hit records (t is not needed here)
+    const auto     entryIndex = [&](int k) -> uint32_t {
+        return SORTED ? (tile * kItems + hitTri[k] / kBlock) * kBlock + (hitTri[k] % kBlock) : (tile * kItems + static_cast<uint32_t>(k)) * kBlock + threadIdx.x;
+    };
+    if constexpr (kPipelined)
     {
-        if (!isHit[k]) continue;
-        const uint32_t i = SORTED ? (tile * kItems + hitTri[k] / kBlock) * kBlock + (hitTri[k] % kBlock) : (tile * kItems + k) * kBlock + threadIdx.x;
-        const float4   h = ps.hit[i];
-        const uint32_t tri = __float_as_uint(h.x);
-        // everything this stage needs of the triangle sits in ONE 128-byte record (positions + packed attributes): one L2 line
-        // per shaded hit instead of a triangle line and an attribute line (kShade 56.1 -> 53.0 ms per 128 spp)
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) hits[k] = isHit[k] ? vec3(sIn[6 * kTile + hitTri[k]], sIn[7 * kTile + hitTri[k]], sIn[8 * kTile + hitTri[k]]) : Vec3{};
+    }
+    // everything this stage needs of the triangle sits in ONE 128-byte record (positions + packed attributes): one L2 line
+    // per shaded hit instead of a triangle line and an attribute line (kShade 56.1 -> 53.0 ms per 128 spp)
+    struct ShadeRecord
+    {
+        Vec3   p0, p1, p2;
+        float4 a0, a1, a2, a3; // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
+    };
+    const auto fetchRecord = [&](uint32_t tri) {
+        ShadeRecord   r;
         const float4* rec = scene.shadeRecords + 8 * static_cast<size_t>(tri);
+#if defined(RF_EXP_SHADE_ABLATE) && RF_EXP_SHADE_ABLATE >= 3
+        if constexpr (SORTED) rec = scene.shadeRecords + 8 * static_cast<size_t>(tri & 63u); // ablation (timing only): 64 records, all L1 hits
+#endif
+        r.p0 = load3(rec), r.p1 = load3(rec + 1), r.p2 = load3(rec + 2);
+        r.a0 = rec[3], r.a1 = rec[4], r.a2 = rec[5], r.a3 = rec[6];
+        return r;
+    };
+    const auto shade = [&](int k, float hu, float hv, const ShadeRecord& cur, uint32_t out) {
+        const uint32_t i = entryIndex(k);
+        (void)i;
         {
             // hit point pushed off the surface along the geometric normal (wgsl:511-519,523-544): origin of
             // the shadow ray and of the next bounce; same arithmetic as the scalar traversal (rf_device.hpp)
-            const Vec3 p0 = load3(rec), p1 = load3(rec + 1), p2 = load3(rec + 2);
+            const Vec3 p0 = cur.p0, p1 = cur.p1, p2 = cur.p2;
             const Vec3 e1 = p1 - p0, e2 = p2 - p0;
-            const Vec3 hp = offsetRay(p0 + h.y * e1 + h.z * e2, normalize(cross(e1, e2)));
-            store3(ps.rayO + outPos[k], hp); // (this bounce's origins have been consumed by the closest-hit launch)
+            const Vec3 hp = offsetRay(p0 + hu * e1 + hv * e2, normalize(cross(e1, e2)));
+            store3(ps.rayO + out, hp); // (this bounce's origins have been consumed by the closest-hit launch)
         }
-        const Vec3  throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i); // wgsl:184
-        const Vec3  nz = load3(ps.noise + i);
+        // SORTED: this thread's entry is the tile's `local`-th in input order; its throughput and blue-noise triple were read in input
+        // order (coalesced) by pass 1 and wait in LDS -- gathered from memory, the 64 lanes of a wave would touch ~57 different lines of
+        // the tile's 12 KB per stream
+        Vec3 throughput, nz;
+        if constexpr (SORTED)
+        {
+            const uint32_t local = hitTri[k];
+            throughput = vec3(sIn[local], sIn[kTile + local], sIn[2 * kTile + local]);
+            nz = vec3(sIn[3 * kTile + local], sIn[4 * kTile + local], sIn[5 * kTile + local]);
+        }
+        else
+        {
+            throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i); // wgsl:184
+            nz = load3(ps.noise + i);
+        }
         const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
-        store3(ps.noiseOut + outPos[k], nz); // travels with the path: dense for this bounce's shadow launch and for the next kShade
-        // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
-        const float4* va = rec + 3;
-        const float4  a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
+        store3(ps.noiseOut + out, nz); // travels with the path: dense for this bounce's shadow launch and for the next kShade
+        const float4  a0 = cur.a0, a1 = cur.a1, a2 = cur.a2, a3 = cur.a3;
         const Vec3    n0 = vec3(a0.x, a0.y, a0.z), n1 = vec3(a0.w, a1.x, a1.y), n2 = vec3(a1.z, a1.w, a2.x);
-        const float   b0 = 1.0f - h.y - h.z, b1 = h.y, b2 = h.z; // wgsl:515
+        const float   b0 = 1.0f - hu - hv, b1 = hu, b2 = hv; // wgsl:515
         const Vec3    n = (b0 * n0 + b1 * n1) + b2 * n2;         // not normalised, wgsl:396
         const float   uvx = (b0 * a2.y + b1 * a2.w) + b2 * a3.y;
         const float   uvy = (b0 * a2.z + b1 * a3.x) + b2 * a3.z;
+#if defined(RF_EXP_SHADE_ABLATE) && (RF_EXP_SHADE_ABLATE == 1 || RF_EXP_SHADE_ABLATE == 4)
+        const Vec3    albedo = SORTED ? vec3(sLut[__float_as_uint(a3.w) & 255u], uvx - floorf(uvx), uvy - floorf(uvy)) : evalTexture(scene, sLut, __float_as_uint(a3.w), uvx, uvy); // ablation (timing only): no texel fetch
+#else
         const Vec3    albedo = evalTexture(scene, sLut, __float_as_uint(a3.w), uvx, uvy);
+#endif
 
         // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
         const Vec3 lightDirection = sunSample(sky, sunBasis, nx, cosPhi, sinPhi);
@@ -538,7 +594,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
         const Vec3 brdf = albedo * kFrac1Pi;
         const Vec3 reflectance = brdf * dot(n, lightDirection);
         const Vec3 pend = (throughput * lightIntensity) * reflectance;
-        store3(ps.pending + outPos[k], pend); // read by the shadow launch at the same queue position
+        store3(ps.pending + out, pend); // read by the shadow launch at the same queue position
 
         if (!isLastBounce)
         {
@@ -549,10 +605,36 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             pixarOnb(n, bu, bv);
             const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
             const Vec3 t2 = throughput * albedo;
-            store3(ps.rayDOut + outPos[k], wi);
-            store3(ps.thrOut + outPos[k], t2);
+            store3(ps.rayDOut + out, wi);
+            store3(ps.thrOut + out, t2);
+        }
+    };
+    if constexpr (kPipelined)
+    {
+        const uint32_t tileHits = sortedHits, base = sortedBase;
+        ShadeRecord    cur{};
+        if (threadIdx.x < tileHits) cur = fetchRecord(__float_as_uint(hits[0].x));
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+        {
+            const uint32_t p = static_cast<uint32_t>(k) * kBlock + threadIdx.x, pNext = p + kBlock; // positions in the tile's sorted order
+            ShadeRecord    next{};
+            if (k + 1 < kItems && pNext < tileHits) next = fetchRecord(__float_as_uint(hits[k + 1 < kItems ? k + 1 : k].x));
+            if (p < tileHits) shade(k, hits[k].y, hits[k].z, cur, base + p);
+            cur = next;
         }
     }
+    else
+    {
+#pragma unroll 1
+        for (int k = 0; k < kItems; ++k)
+        {
+            if (!isHit[k]) continue;
+            const Vec3 h = load3(ps.hit + entryIndex(k));
+            shade(k, h.y, h.z, fetchRecord(__float_as_uint(h.x)), outPos[k]);
+        }
+    }
+    if constexpr (SORTED) __syncthreads(); // (a block that takes another tile refills sIn)
   }
 }
 

@@ -11,5 +11,5 @@ f = glob.glob('/tmp/kst/**/*kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n = r['Name'].replace('(anonymous namespace)::', '').replace('rf::', '').replace('void ', '').split('(')[0]
     if float(r['Percentage']) < 0.05: continue
-    print(f"{n:36s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:9.3f} avg_us={float(r['AverageNs'])/1e3:9.1f} pct={float(r['Percentage']):6.2f}")
+    print(f"{n:36s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:9.3f} avg_us={float(r['AverageNs'])/1e3:9.1f} max_us={float(r['MaxNs'])/1e3:9.1f} pct={float(r['Percentage']):6.2f}")
 PY
