@@ -409,7 +409,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     __shared__ uint32_t sHist[SORTED ? kSortBins : 1], sStart[SORTED ? kSortBins : 1], sPerm[SORTED ? kItems * kBlock : 1];
     __shared__ float    sLut[256];
     constexpr uint32_t  kTile = kItems * kBlock;
-    __shared__ float    sIn[SORTED ? 9 * kTile : 1]; // SORTED: throughput, blue-noise triple and {triangle, u, v} of the tile's hits, [component][entry of the tile]
+    __shared__ float    sIn[SORTED ? 10 * kTile : 1]; // SORTED: throughput, blue-noise triple, {triangle, u, v} and slot of the tile's hits, [component][entry of the tile]
     const uint32_t      count = *queueCount;
     // grid-stride over tiles of kItems * kBlock queue entries: the grid is capped (kShadeMaxBlocks), so late bounces, whose
     // queues hold a sixth of the paths, do not pay for hundreds of thousands of empty workgroups
@@ -452,6 +452,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
                 sIn[l] = t.x, sIn[kTile + l] = t.y, sIn[2 * kTile + l] = t.z;
                 sIn[3 * kTile + l] = z.x, sIn[4 * kTile + l] = z.y, sIn[5 * kTile + l] = z.z;
                 sIn[6 * kTile + l] = hitRec.x, sIn[7 * kTile + l] = hitRec.y, sIn[8 * kTile + l] = hitRec.z;
+                sIn[9 * kTile + l] = __uint_as_float(slots[k]);
             }
         }
     }
@@ -508,7 +509,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             if (!isHit[k]) continue;
             const uint32_t local = sPerm[p];
             hitTri[k] = local; // (reused: which entry of the tile)
-            slots[k] = queue[(tile * kItems + local / kBlock) * kBlock + (local % kBlock)];
+            slots[k] = __float_as_uint(sIn[9 * kTile + local]);
             hitQueue[outPos[k]] = slots[k];
         }
         __syncthreads(); // LDS is reused by the miss append and the next tile
