@@ -795,6 +795,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     uint32_t  node = kNodeIdle;
     uint32_t  slot = 0;
     uint32_t  resultIndex = 0; // queue position of the lane's ray
+    Vec3      pendingTerm{};   // ANY_HIT: the ray's NEE term (pending[resultIndex])
     // COMPACT: t-values of the x planes of the node the lane is about to visit, in hand when it enters the node straight from its
     // parent's step (rf_wide.hpp, compact-capable records); a lane that arrives from the stack or starts at the root reads them
     float tOuterLo = 0.0f, tOuterHi = 0.0f;
@@ -908,6 +909,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // the closest-hit launch does not read the queue itself at all
                 resultIndex = myPos;
                 if (ANY_HIT) slot = loadQ(queue + resultIndex); // the radiance sum and the blue-noise pair are the path's: by slot
+                // the NEE term this ray decides about: read with the rest of the ray (consecutive queue positions: coalesced) instead of
+                // at write-back, where every finishing lane gathered its own 12 bytes and the wave waited for them
+                if (ANY_HIT) pendingTerm = load3s(ps.pending + resultIndex);
                 const Vec3 o = load3s(ps.rayO + resultIndex);
                 Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
@@ -1534,7 +1538,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             if (ANY_HIT)
             {
                 const float visibility = occluded ? 0.0f : 1.0f;
-                const Vec3  add = (load3s(ps.pending + resultIndex) * visibility) * __uint_as_float(kSolarInvPdfBits);
+                const Vec3  add = (pendingTerm * visibility) * __uint_as_float(kSolarInvPdfBits);
                 // An occluded ray adds pending * 0 = +-0 to a sum that is never -0 (it starts at +0, and x + y = -0 only for two
                 // negative zeros): the sum keeps its bits, so its slot -- a random 16-byte read-modify-write by now -- is left
                 // alone.  Not at bounce 1 (the sum is not in memory yet), and not when the product is NaN (an infinite or NaN
