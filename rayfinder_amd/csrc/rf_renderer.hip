@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(kBlock) void kAccumulate(FrameParams fp, const uint
 // numSamples float4: there kAccumulate's per-thread reads are a 16-byte gather at a stride of numSamples * 16 bytes (8.2 ms per
 // 320 spp of a 1080p frame).  Here one wave takes kAccPixels pixels: their runs are read coalesced (1 KiB per load) into LDS, then
 // one lane per (pixel, channel) adds its samples in sample-index order -- the order is the result (f32, H15), so the
-// additions stay sequential; only the memory traffic changes.  Dynamic LDS: kAccPixels * numSamples * 12 bytes.
+// additions stay sequential; only the memory traffic changes.  Dynamic LDS: kAccPixels * (numSamples + 1) * 12 bytes (rows padded by one float: bank-conflict-free sums).
 #if defined(RF_EXP_ACC_PIXELS)
 constexpr uint32_t kAccPixels = RF_EXP_ACC_PIXELS;
 #else
@@ -1920,23 +1920,23 @@ constexpr uint32_t kAccMaxSamples = 1024;
 
 __global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image)
 {
-    extern __shared__ float sRun[]; // [pixel][channel][position]
-    const uint32_t S = fp.numSamples, lane = threadIdx.x;
+    extern __shared__ float sRun[]; // [pixel][channel][sample], rows of S + 1 floats: the twelve lanes that sum walk twelve different banks
+    const uint32_t S = fp.numSamples, R = S + 1u, lane = threadIdx.x;
     const uint32_t lp0 = blockIdx.x * kAccPixels;
     for (uint32_t px = 0; px < kAccPixels; ++px)
     {
         const uint32_t lp = lp0 + px;
         if (lp >= fp.pixelsPadded) break;
         const float4* run = ps.rad + static_cast<size_t>(lp) * S;
-        float*        dst = sRun + px * 3u * S;
+        float*        dst = sRun + px * 3u * R;
         for (uint32_t p = lane; p < S; p += 64u)
         {
             // position p of the run holds sample samplePerm[p]: stored at ITS index, so that the sums below walk LDS in order
             const Vec3     v = load3(run + p);
             const uint32_t k = fp.samplePerm ? fp.samplePerm[p] : p;
             dst[k] = v.x;
-            dst[S + k] = v.y;
-            dst[2u * S + k] = v.z;
+            dst[R + k] = v.y;
+            dst[2u * R + k] = v.z;
         }
     }
     __syncthreads();
@@ -1947,7 +1947,7 @@ __global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint
     if (!localPixelToXY(fp, tileIds, lp, x, y)) return;
     float*       out = reinterpret_cast<float*>(image + lp) + c;
     float        acc = *out;
-    const float* src = sRun + (px * 3u + c) * S;
+    const float* src = sRun + (px * 3u + c) * R;
 #pragma unroll 8
     for (uint32_t k = 0; k < S; ++k) acc += src[k]; // sample order (wgsl:56-57): one dependent chain of f32 additions per channel
     *out = acc;
@@ -2819,7 +2819,7 @@ struct Renderer::Impl
         hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr);
         launchTimed(4, [&] {
             if (fp.slotGroupShift == 0u && numSamples > 4u && numSamples <= kAccMaxSamples && optAccumulateRuns)
-                hipLaunchKernelGGL(kAccumulateRuns, dim3((fp.pixelsPadded + kAccPixels - 1) / kAccPixels), dim3(64), kAccPixels * 3u * numSamples * sizeof(float), stream, fp,
+                hipLaunchKernelGGL(kAccumulateRuns, dim3((fp.pixelsPadded + kAccPixels - 1) / kAccPixels), dim3(64), kAccPixels * 3u * (numSamples + 1u) * sizeof(float), stream, fp,
                                    tileIds.ptr, ps, image);
             else
                 hipLaunchKernelGGL(kAccumulate, dim3((fp.pixelsPadded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, fp, tileIds.ptr, ps, image);
