@@ -7,7 +7,7 @@ cd $REPO
 F=gpurun_out/r03_final; P=profiles/r03_final
 cp $F/roofline/*.txt $F/roofline/*.csv $F/roofline/*.json $F/roofline/*.jsonl $F/roofline/trace.log $P/
 cp $F/bench_*.json $F/shard_emulation.log $P/
-tail -3 $F/pytest_gpu.log > $P/pytest_gpu.txt
+grep -h "passed\|failed\|error" $F/pytest_gpu.log | tail -3 > $P/pytest_gpu.txt
 cp $F/pmc_per_ray.json profiles/pmc_per_ray.json
 cp $F/pmc_per_ray_x8.json profiles/pmc_per_ray_x8.json
 for f in $(ls gpurun_out/r03_hbm | grep -v bench.err); do cp gpurun_out/r03_hbm/$f profiles/r03_hbm/$f; done
