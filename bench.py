@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 without a launcher's WORLD_SIZE in the
+                                                            environment this process re-launches itself as N ranks under
+                                                            torch.distributed.run --standalone on 127.0.0.1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (the driver's form)
+
+The timed region is run --repeat R times (default 3; each is EXACTLY K steps between barriers); `value` and `ms_per_step`
+are the MEDIAN repeat's, the others are listed under `repeats`.
 
 Workload (BASELINE.json configs[2]/[3]): Sponza stand-in ("synthetic atrium": the real assets/Sponza.glb is absent
 from the reference mount), 1920x1080, 8 bounces, default camera and sky.
@@ -327,6 +332,21 @@ def build_roofline(s, cs, per_bounce, workload):
     return roofline
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become the launcher.  One rank per GPU under
+    torch.distributed.run (standalone rendezvous on 127.0.0.1: the container's hostname may not resolve); rank 0 prints
+    the one JSON line, this process passes the ranks' stdout / stderr through and returns their exit status."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["RF_BENCH_SELF_LAUNCHED"] = "1"
+    log(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,7 +362,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (and with them the parity crop)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-counting", action="store_true", help="skip the untimed counting pass (profiling runs): the algorithmic figures are null then")
+    ap.add_argument("--launch", action="store_true", help="start the rank(s) under torch.distributed.run even for --gpus 1 (with --gpus N > 1 and no "
+                    "launcher environment that happens by itself)")
+    ap.add_argument("--exchange-at-world-1", action="store_true", help="one rank, but through everything N > 1 ranks go through: torch.distributed (RCCL) "
+                    "process group, the product's RCCL communicator, the frame-end exchange (the rank sends its shard to itself) and the device un-tile")
+    ap.add_argument("--repeat", type=int, default=3, help="timed regions of K steps each; the median one is reported (min / max beside it)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if not ("WORLD_SIZE" in os.environ and "RANK" in os.environ) and (args.gpus > 1 or args.launch):     # no launcher around this process
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import rayfinder_amd as rf
@@ -351,16 +381,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU fallback)")
+        # a launcher's world is what exists; a line that says n_gpus = N while M ranks ran would be a wrong scaling point
+        raise SystemExit(f"bench.py: rank {rank}: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; pass --gpus {world} "
+                         f"(or no launcher: `python bench.py --gpus N` starts its own ranks)")
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < max(world, local_rank + 1):
+        raise SystemExit(f"bench.py: rank {rank} of {world}: needs {world} MI355X GPU(s), one per rank, but {visible} are visible "
+                         f"(no GPU visible: the product has no CPU fallback)" if visible == 0 else
+                         f"bench.py: rank {rank} of {world}: needs {world} MI355X GPU(s), one per rank, but only {visible} are visible")
     torch.cuda.set_device(local_rank)
     dist = None
     comm = None
     rccl_ranks = 0
-    if world > 1:
+    multi = world > 1 or args.exchange_at_world_1
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:                   # (only without a launcher: --exchange-at-world-1 run directly)
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         # torch.distributed is the launcher's plumbing (rendezvous, barrier, max over ranks); the data path's one
         # exchange goes through the product's own RCCL communicator, whose id travels over the rendezvous store
@@ -372,7 +413,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"[bench] rank {rank}: RCCL communicator creation FAILED: {e}")
             comm = None
-    exchange = "none" if world == 1 else "C++ RCCL exchange (rf_renderer_gather_frame: grouped ncclSend/ncclRecv + device un-tile)"
+    exchange = "none" if not multi else "C++ RCCL exchange (rf_renderer_gather_frame: grouped ncclSend/ncclRecv + device un-tile)"
 
     def all_ranks_ok(ok):
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -392,7 +433,7 @@ def main():
     r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25), pt.scene(), device_ordinal=local_rank)
     r.set_tile_shard(rank, world)
     accum = None
-    if world > 1:
+    if multi:
         # self-test of the exchange before anything is timed.  The C++ path has only ever run at world size 1 on the
         # builder's single-GPU boxes; should it throw here on any rank, every rank falls back -- loudly, and named in the JSON
         # line -- to the round-1 plumbing (torch.distributed.gather of the compact buffers + host un-tile) so that a
@@ -439,36 +480,43 @@ def main():
         r.render(warm_spp)
     exchange_frame()
     r.synchronize()
-    # restart the accumulation (frameCount keeps counting: the timed frames are warm_spp .. warm_spp + spp - 1, i.e. the
-    # sample indices 0..spp-1 rotated by warm_spp)
-    r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.5))
-    r.set_timing(True)
-    r.reset_stats()
-
-    # Timed region: EXACTLY K steps, barrier + device synchronize on both sides.  The clock stops when THIS rank's
-    # stream is idle (after the exchange, which on rank 0 ends with the un-tile of every rank's shard); the barrier
+    # Timed region, R times over: EXACTLY K steps, barrier + device synchronize on both sides.  The clock stops when THIS
+    # rank's stream is idle (after the exchange, which on rank 0 ends with the un-tile of every rank's shard); the barrier
     # that follows only lines the ranks up again and would add its own latency to every rank's figure, so it sits
-    # after the clock.  The reported time is the max over ranks.
-    barrier()
-    t0 = time.perf_counter()
-    r.render(spp)
-    parts = exchange_frame()
-    r.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-
-    s = r.stats()
-    bs = r.bounce_stats()   # queue occupancy and traversal time per bounce of the timed region (this rank)
+    # after the clock.  The reported time is the max over ranks, and of the R repeats the MEDIAN one is reported.
+    # Every repeat restarts the accumulation (frameCount keeps counting: repeat i traces frames warm_spp + i spp ..
+    # warm_spp + (i + 1) spp - 1, i.e. the sample indices 0..spp-1 rotated by warm_spp -- the same frames every time, so
+    # every repeat produces the same image).
+    R = max(args.repeat, 1)
+    r.set_timing(True)
+    runs = []
+    parts = None
+    for rep in range(R):
+        r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.5 + 0.125 * (rep % 2)))
+        r.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        r.render(spp)
+        parts = exchange_frame()
+        r.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        runs.append((elapsed, r.stats(), r.bounce_stats()))
+    order = sorted(range(R), key=lambda i: runs[i][0])
+    median_run = order[(R - 1) // 2]          # the lower median for even R: a repeat that was actually measured
+    elapsed, s, bs = runs[median_run]         # bs: queue occupancy and traversal time per bounce of that repeat (this rank)
+    last_first_frame = warm_spp + (R - 1) * spp
     per_bounce = [dict(bounce=i + 1, closest_rays=int(bs["closest_rays"][i]), ms_closest=round(float(bs["ms_closest"][i]), 3),
                        shadow_rays=int(bs["shadow_rays"][i]), ms_shadow=round(float(bs["ms_shadow"][i]), 3)) for i in range(len(bs["closest_rays"]))]
     r.set_timing(False)
 
     rays_local = s["closest_rays"] + s["shadow_rays"]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         c = torch.tensor([rays_local, s["closest_rays"], s["shadow_rays"], s["primary_rays"], s["abandoned_rays"]], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         rays_total, closest_total, shadow_total, paths_total, abandoned_total = (float(x) for x in c.tolist())
@@ -491,8 +539,8 @@ def main():
     cs = None
     if not args.no_counting:
         r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.25))
-        # frameCount is now warm_spp + spp: this pass traces frames warm_spp + spp .. warm_spp + 2 spp - 1, the same
-        # sample indices (n = frameCount % spp) as the timed one
+        # frameCount is now warm_spp + R spp: this pass traces the next spp frames, the same sample indices
+        # (n = frameCount % spp) as every timed repeat
         r.set_counting(True)
         r.reset_stats()
         r.render(spp)
@@ -525,8 +573,14 @@ def main():
                                    f"{SPS} spp per step x {K} steps = {spp} spp, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
                        "spp_per_step": SPS, "spp": spp,
                        "scene_triangles": info.get("triangles"), "scene_textures": info.get("textures"), "scene_digest": info.get("digest"),
-                       "sharding": f"32x32 tiles along a Z-order curve dealt round-robin (rotated per block) over {world} rank(s), one exchange at frame end: {exchange}" if world > 1 else "none"},
+                       "sharding": f"32x32 tiles along a Z-order curve dealt round-robin (rotated per block) over {world} rank(s), one exchange at frame end: {exchange}" if multi else "none"},
             "timed_region_s": round(elapsed, 4),
+            "repeats": {"count": R, "reported": "median", "median_index": median_run,
+                        "value": [round(rays_total / t_ * 1e-6, 1) for (t_, _, _) in runs],
+                        "min": round(rays_total / max(t_ for (t_, _, _) in runs) * 1e-6, 1),
+                        "max": round(rays_total / min(t_ for (t_, _, _) in runs) * 1e-6, 1),
+                        "timed_region_s": [round(t_, 4) for (t_, _, _) in runs],
+                        "note": "each repeat is the same K steps (same frames, same image) between barriers; value / ms_per_step / kernel times are the median repeat's"},
             "paths_per_s": round(paths_total / elapsed, 1),
             "rays": {"closest": int(closest_total), "shadow": int(shadow_total), "abandoned": int(abandoned_total)},
             "kernel_ms_rank0": {k: round(s[k], 3) for k in ("ms_raygen", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")},
@@ -538,7 +592,7 @@ def main():
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], out["parity_crop"] = cpu_baseline(pt, W, H, B, warm_spp, spp, args.cpu_seconds, image)
+            out["cpu_baseline"], out["parity_crop"] = cpu_baseline(pt, W, H, B, last_first_frame, spp, args.cpu_seconds, image)
             # scene bake beside it: the reference's recursive builder as restated on the host (one
             # thread, what pt-format-tool does) and the GPU builder that emits the same bytes
             tris = pt.arrays()["bvhPositionAttributes"]

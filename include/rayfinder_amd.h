@@ -100,7 +100,9 @@ typedef struct rf_renderer_descriptor
     rf_render_parameters render_params;
     uint32_t             max_width, max_height; /* maxFramebufferSize; 0 = render_params size */
     int32_t              device_ordinal;
-    uint64_t             max_paths_in_flight;   /* 0 = default (1 Gi paths per batch, less when less device memory is free; path state is allocated on demand: samples x pixels x 140 B) */
+    uint64_t             max_paths_in_flight;   /* batch depth; 0 = default (1 Gi paths).  Default or chosen, a render() call whose batches do not fit the device memory
+                                                   free at that moment traces the same samples in shallower batches (same image; said on stderr; the configured depth is
+                                                   used again once the memory is back).  Path state is allocated on demand: samples x pixels x 140 B */
 } rf_renderer_descriptor;
 
 typedef struct rf_stats
@@ -219,7 +221,11 @@ RF_API int rf_renderer_bind_accumulation_buffer(rf_renderer* r, void* device_ptr
  * ncclSend()s its compact tile buffer to `root`, the root posts all ncclRecv()s in one group (all xGMI ingress
  * links at once; no reduction, no ring) and un-tiles the shards into a row-major width*height float4 image in
  * device memory (*image_device_out on the root, NULL elsewhere; owned by the comm, valid until the next gather).
- * The renderer's tile shard must be (rank, world_size) of the comm.  RF_GATHER_LOOPBACK: the root's own shard also
+ * The renderer's tile shard must be (rank, world_size) of the comm.  SIDE EFFECT: what is sent is the accumulation of the
+ * current parameters; if nothing has been rendered since the accumulation was last restarted (set_render_parameters, a new shard,
+ * a newly bound buffer) the accumulation buffer is ZEROED on the handle's stream first (wgsl:47-49: a restarted frame starts from
+ * zero), and that includes a caller-owned buffer bound with rf_renderer_bind_accumulation_buffer (its first
+ * rf_renderer_accumulation_device_buffer() bytes).  RF_GATHER_LOOPBACK: the root's own shard also
  * goes through ncclSend/ncclRecv instead of being read in place (self-test of the RCCL path at world size 1). */
 typedef struct rf_comm rf_comm;
 #define RF_COMM_ID_BYTES 128

@@ -248,6 +248,22 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
 
     // one group: exactly the operations of gatherPlan() (the list the CPU tests check for every rank of a world)
     const std::vector<GatherOp> plan = gatherPlan(g, m.world, m.rank, root, loopback);
+    // (first exchange only) marks the end of what was queued on the stream BEFORE the exchange -- this rank's frame kernels: the
+    // watchdog below measures the exchange, not the render in front of it
+    hipEvent_t queuedBefore = nullptr;
+    if (!m.firstGatherDone)
+    {
+        RF_HIP(hipEventCreateWithFlags(&queuedBefore, hipEventDisableTiming));
+        RF_HIP(hipEventRecord(queuedBefore, stream));
+    }
+    struct EventGuard
+    {
+        hipEvent_t& e;
+        ~EventGuard()
+        {
+            if (e) (void)hipEventDestroy(e);
+        }
+    } eventGuard{queuedBefore};
     RF_NCCL(ncclGroupStart());
     try
     {
@@ -271,18 +287,32 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
         // disagrees about the frame size or the root) would leave this stream stuck forever.  Watch this one exchange: past the
         // time limit the communicator is aborted and the caller gets an error instead of a hang.  Later gathers are not watched
         // (they stay fully asynchronous).  NOTE: an exception thrown on one rank leaves its peers waiting in their own gather
-        // until THEIR limit expires.
+        // until THEIR limit expires.  The clock starts when the work queued on this stream before the exchange (Renderer::render()
+        // is asynchronous: the whole frame may still be in front of it) has drained, so a long first frame does not abort a healthy
+        // job; what remains inside the limit is the connection set-up, the transfer, and the wait for the slowest peer to finish ITS
+        // frame -- ranks own equal tile counts (+-1), so that wait is a fraction of a frame.
         const double timeout = commTimeoutSeconds();
-        const auto   t0 = std::chrono::steady_clock::now();
+        auto         t0 = std::chrono::steady_clock::now();
+        bool         drained = false;
         for (;;)
         {
             const hipError_t q = hipStreamQuery(stream);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) RF_HIP(q);
+            if (!drained)
+            {
+                const hipError_t e = hipEventQuery(queuedBefore);
+                if (e == hipSuccess)
+                {
+                    drained = true;
+                    t0 = std::chrono::steady_clock::now();
+                }
+                else if (e != hipErrorNotReady) RF_HIP(e);
+            }
             ncclResult_t async = ncclSuccess;
             RF_NCCL(ncclCommGetAsyncError(m.comm, &async));
             if (async != ncclSuccess && async != ncclInProgress) throw std::runtime_error(std::string("RCCL error during the first frame exchange: ") + ncclGetErrorString(async));
-            if (timeout > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout)
+            if (drained && timeout > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout)
             {
                 (void)ncclCommAbort(m.comm);
                 m.comm = nullptr;

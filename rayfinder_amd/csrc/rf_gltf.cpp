@@ -59,7 +59,13 @@ struct Json
     }
     bool        has(std::string_view key) const { return find(key) != nullptr; }
     std::size_t size() const { return kind == Kind::Array ? array.size() : object.size(); }
-    std::size_t index() const { return static_cast<std::size_t>(number); }
+    // an index / count / offset / stride: a non-negative integer a double holds exactly (anything else in a file is hostile or
+    // corrupt, and converting it would be undefined behaviour)
+    std::size_t index() const
+    {
+        if (!(number >= 0.0) || number > 9007199254740992.0) throw std::runtime_error("glTF: a size or index is negative or beyond 2^53");
+        return static_cast<std::size_t>(number);
+    }
     float       f32() const { return static_cast<float>(number); } // cgltf: (float)atof(token)
 };
 
@@ -531,6 +537,16 @@ struct BufferViewSpan
     std::size_t    size = 0, byteStride = 0;
 };
 
+// `count` elements of `elem` bytes, `stride` bytes apart, inside `avail` bytes -- without forming count * stride, which a hostile
+// file can make wrap (byteStride and count are whatever the JSON says)
+bool strideFits(std::size_t count, std::size_t stride, std::size_t elem, std::size_t avail)
+{
+    if (count == 0) return true;
+    if (elem > avail) return false;
+    if (count == 1) return true;
+    return stride != 0 && count - 1 <= (avail - elem) / stride;
+}
+
 BufferViewSpan bufferViewSpan(const Document& doc, std::size_t index)
 {
     const Json&                 bv = doc.json.at("bufferViews").array.at(index);
@@ -542,6 +558,8 @@ BufferViewSpan bufferViewSpan(const Document& doc, std::size_t index)
     s.data = buffer.data() + offset;
     s.size = length;
     s.byteStride = bv.has("byteStride") ? bv.at("byteStride").index() : 0;
+    // glTF 2.0 (bufferView.byteStride): 4 .. 252; 0 = "not given" = tightly packed
+    if (s.byteStride != 0 && (s.byteStride < 4 || s.byteStride > 252)) throw std::runtime_error("glTF: buffer view byteStride outside 4..252");
     return s;
 }
 
@@ -560,9 +578,13 @@ AccessorView accessorView(const Document& doc, std::size_t index)
     v.stride = elem;
     if (!acc.has("bufferView")) return v;
     const BufferViewSpan bv = bufferViewSpan(doc, acc.at("bufferView").index());
-    if (bv.byteStride != 0) v.stride = bv.byteStride;
+    if (bv.byteStride != 0)
+    {
+        if (bv.byteStride < elem) throw std::runtime_error("glTF: buffer view byteStride smaller than the accessor's element");
+        v.stride = bv.byteStride;
+    }
     const std::size_t offset = acc.has("byteOffset") ? acc.at("byteOffset").index() : 0;
-    if (v.count && (offset > bv.size || (v.count - 1) * v.stride + elem > bv.size - offset)) throw std::runtime_error("glTF: accessor exceeds its buffer view");
+    if (v.count && (offset > bv.size || !strideFits(v.count, v.stride, elem, bv.size - offset))) throw std::runtime_error("glTF: accessor exceeds its buffer view");
     v.base = bv.data + offset;
     return v;
 }
@@ -636,6 +658,8 @@ std::vector<float> unpackFloats(const Document& doc, std::size_t accessorIndex, 
 {
     const AccessorView v = accessorView(doc, accessorIndex);
     if (v.components != comps) throw std::runtime_error(std::string("glTF: ") + what + " has the wrong accessor type");
+    // (an accessor over a buffer view is bounded by that view; one with sparse data only is bounded by nothing but this)
+    if (v.count > (std::size_t(1) << 32)) throw std::runtime_error(std::string("glTF: ") + what + " accessor count is implausible");
     std::vector<float> out(v.count * static_cast<std::size_t>(comps), 0.0f);
     const std::size_t  cs = static_cast<std::size_t>(componentSize(v.componentType));
     if (v.base != nullptr)
@@ -654,8 +678,8 @@ std::vector<float> unpackFloats(const Document& doc, std::size_t accessorIndex, 
         const BufferViewSpan ib = bufferViewSpan(doc, si.at("bufferView").index()), vb = bufferViewSpan(doc, sv.at("bufferView").index());
         const std::size_t    io = si.has("byteOffset") ? si.at("byteOffset").index() : 0, vo = sv.has("byteOffset") ? sv.at("byteOffset").index() : 0;
         const std::size_t    is = static_cast<std::size_t>(componentSize(indexType)), elem = cs * static_cast<std::size_t>(comps);
-        if (n && (io > ib.size || n * is > ib.size - io)) throw std::runtime_error("glTF: sparse indices exceed their buffer view");
-        if (n && (vo > vb.size || (n - 1) * v.stride + elem > vb.size - vo)) throw std::runtime_error("glTF: sparse values exceed their buffer view");
+        if (n && (io > ib.size || !strideFits(n, is, is, ib.size - io))) throw std::runtime_error("glTF: sparse indices exceed their buffer view");
+        if (n && (vo > vb.size || !strideFits(n, v.stride, elem, vb.size - vo))) throw std::runtime_error("glTF: sparse values exceed their buffer view");
         for (std::size_t k = 0; k < n; ++k)
         {
             const std::size_t at = componentAsUint(ib.data + io + k * is, indexType);

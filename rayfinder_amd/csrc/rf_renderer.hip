@@ -2398,7 +2398,7 @@ struct Renderer::Impl
     }
 
     uint64_t allocatedPaths = 0;
-    bool     maxPathsIsDefault = true; // no caller-chosen batch depth: clamp it by the memory that is free (render())
+    uint64_t effectivePaths = 0;       // batch depth the last render() call ended up with (<= maxPaths: less when less memory was free THEN)
 
     // bytes of path state + queues per path slot (eight packed xyz streams, two float4 streams, three u32 queues)
     static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 3 * sizeof(uint32_t);
@@ -2931,7 +2931,14 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             padded[kTriStride * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
         }
         // ... and the exact box of every leaf in the spare floats of its first triangle (read by the half-precision quad kernels)
-        leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n);
+        if (!leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n))
+        {
+            // leaves that share a first triangle (hand-made tree): one slot cannot hold two exact boxes, so the layouts that cull a leaf by
+            // the box in that slot stay off and the exact records (which carry every box themselves) are used
+            m.wide.quadHalf = m.wide.quadLocal = nullptr;
+            m.wideQuadHalf.release(), m.wideQuadLocal.release();
+            m.optQuadHalfFromBounce = m.optQuadHalfShadowFromBounce = m.optQuadLocalFromBounce = m.optQuadLocalShadowFromBounce = 0u;
+        }
         m.triangles.upload(padded.data(), padded.size());
     }
     {
@@ -3024,7 +3031,6 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     // wave (FrameParams::samplePerm).  Measured on the atrium, 1080p, Mrays/s: 64 Mi 5125, 128 Mi 5171, 256 Mi 5224 (before
     // the sample sort); 256 Mi 5692, 512 Mi 5826 / 5796, 1 Gi 5983 (with it).
     const uint64_t want = desc.maxPathsInFlight ? desc.maxPathsInFlight : (1024ull << 20);
-    m.maxPathsIsDefault = desc.maxPathsInFlight == 0;
     // path slots and queue indices are 32-bit: at most 2^31 paths per batch, and one sample of the whole
     // (padded) frame must fit in a batch
     constexpr uint64_t kMaxPathsPerBatch = 1ull << 31;
@@ -3110,11 +3116,14 @@ void Renderer::render(uint32_t numFrames)
         }
         // equal batches (320 samples with room for 256 per batch -> 160 + 160, not 256 + 64): a small trailing batch has
         // short launches and, with few samples per pixel, less coherent waves
+        // m.maxPaths is the CONFIGURED depth (the default or the caller's) and is never changed here: what a call has to give up
+        // because memory is short at that moment (another handle alive, a shared GPU) is given up for that call only.
         const uint32_t todo = std::min(remaining, spp - m.accumulated);
         uint32_t       n = 0;
+        uint64_t       depth = m.maxPaths;
         for (;;)
         {
-            const uint32_t perBatch = static_cast<uint32_t>(std::max<uint64_t>(1, m.maxPaths / pixelsPadded));
+            const uint32_t perBatch = static_cast<uint32_t>(std::max<uint64_t>(1, depth / pixelsPadded));
             const uint32_t numBatches = (todo + perBatch - 1) / perBatch;
             n = (todo + numBatches - 1) / numBatches;
             const uint64_t need = static_cast<uint64_t>(n) * pixelsPadded;
@@ -3125,12 +3134,22 @@ void Renderer::render(uint32_t numFrames)
             const uint64_t fit = m.pathsThatFit();
             if (need > fit && n > 1)
             {
-                m.maxPaths = std::max<uint64_t>(pixelsPadded, std::min(m.maxPaths / 2, fit));
+                depth = std::max<uint64_t>(pixelsPadded, std::min(depth / 2, fit));
                 continue;
             }
             if (m.ensurePathState(need)) break;
             if (n == 1) throw std::runtime_error("out of device memory: one sample of the frame (" + std::to_string(need * Impl::kBytesPerPath >> 20) + " MiB of path state) does not fit");
-            m.maxPaths = std::max<uint64_t>(pixelsPadded, m.maxPaths / 2);
+            depth = std::max<uint64_t>(pixelsPadded, depth / 2);
+        }
+        if (depth != m.effectivePaths)
+        {
+            // said once per change, not per batch: shallower batches are a silent loss of speed otherwise
+            if (depth < m.maxPaths)
+                std::fprintf(stderr, "[rf] device memory is short: batches of %llu paths instead of the configured %llu (%u samples per batch); same image, shorter launches\n",
+                             static_cast<unsigned long long>(depth), static_cast<unsigned long long>(m.maxPaths), n);
+            else if (m.effectivePaths != 0 && m.effectivePaths < m.maxPaths)
+                std::fprintf(stderr, "[rf] device memory is back: batches of the configured %llu paths again\n", static_cast<unsigned long long>(m.maxPaths));
+            m.effectivePaths = depth;
         }
         m.traceBatch(m.frameCount, n);
         m.frameCount += n;
@@ -3189,7 +3208,9 @@ void Renderer::clearAccumulationIfStale()
     Impl& m = *mImpl;
     if (!m.imageDirty || m.image == nullptr) return;
     RF_HIP(hipSetDevice(m.device));
-    RF_HIP(hipMemsetAsync(m.image, 0, static_cast<size_t>(m.tiles.size()) * 1024 * sizeof(float4), m.stream)); // wgsl:47-49
+    // (this shard's part of the buffer; a bound buffer is never written past the size its owner gave in bindAccumulationBuffer --
+    // configureShard refuses a shard that needs more)
+    RF_HIP(hipMemsetAsync(m.image, 0, std::min<uint64_t>(accumulationBytes(), m.imageBytes), m.stream)); // wgsl:47-49
     m.imageDirty = false;
 }
 
@@ -3198,7 +3219,7 @@ void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, ui
     const Impl& m = *mImpl;
     pathsAllocated = m.allocatedPaths;
     pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
-    maxPathsPerBatch = m.maxPaths;
+    maxPathsPerBatch = m.effectivePaths ? std::min(m.effectivePaths, m.maxPaths) : m.maxPaths;
     sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.wideQuadLocal.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
                  m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2);
 }

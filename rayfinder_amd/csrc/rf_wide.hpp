@@ -176,16 +176,24 @@ inline uint16_t halfDirected(float v, bool down, bool& ok)
 
 // The EXACT box of every leaf, written into the spare floats of the leaf's FIRST device triangle record (64 bytes: {p0 .} {p1 .} {p2 .}
 // {. . . .}):  lo = (record[0].w, record[1].w, record[2].w),  hi = record[3].xyz.  Read by the half-precision quad kernels only.
-inline void leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles)
+// Returns false when two leaves claim the same first-triangle slot (a hand-made tree: validateScene only checks that leaf ranges lie inside the
+// triangle array, not that they are disjoint): the later leaf's box would overwrite the earlier one's, the half-precision / local-grid kernels
+// would cull with a box that is not the leaf's, and the image would depend on the record layout.  The caller keeps those layouts off then.
+inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles)
 {
+    std::vector<bool> claimed(numTriangles, false);
+    bool              distinct = true;
     for (size_t i = 0; i < count; ++i)
     {
         const BvhNode& n = nodes[i];
         if (n.triangleCount == 0 || n.trianglesOffset >= numTriangles) continue;
+        if (claimed[n.trianglesOffset]) distinct = false;
+        claimed[n.trianglesOffset] = true;
         float4* t = triangles + 4 * static_cast<size_t>(n.trianglesOffset);
         t[0].w = n.aabb.min.x, t[1].w = n.aabb.min.y, t[2].w = n.aabb.min.z;
         t[3] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, 0.0f);
     }
+    return distinct;
 }
 
 inline WideBuild buildWide(const BvhNode* nodes, size_t count)

@@ -173,3 +173,41 @@ def test_gloo_plan_exchange_of_product_rendered_shards(tmp_path):
     mp.spawn(_gpu_worker, args=(world, _free_port(), w, h, str(tmp_path)), nprocs=world, join=True)
     got, want = np.load(tmp_path / "product_gathered.npy"), np.load(tmp_path / "product_whole.npy")
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ------------------------------------------------------------------ round 4: bench.py --gpus N is a launcher by itself
+def _run_bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def _no_gpu_here():
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu_here(), reason="checks the no-GPU exit of every self-launched rank")
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` (the shape of the driver's command, no WORLD_SIZE around it) must not run one rank and print
+    n_gpus: 1: it re-launches itself as two ranks under torch.distributed.run --standalone on 127.0.0.1.  In this container
+    both ranks get as far as the device check and exit non-zero, each naming itself; no JSON line is printed."""
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert rc != 0
+    assert "launching 2 ranks" in err and "torch.distributed.run" in err and "--nproc-per-node=2" in err
+    assert "rank 0 of 2: needs 2 MI355X GPU(s)" in err and "rank 1 of 2: needs 2 MI355X GPU(s)" in err
+    assert "n_gpus" not in out
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    """Under a launcher, WORLD_SIZE ranks exist whatever --gpus says: a line claiming another n_gpus would be a wrong scaling
+    point, so the rank exits non-zero and says which of the two to change."""
+    rc, out, err = _run_bench(["--gpus", "4"], env_extra=dict(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), drop=())
+    assert rc != 0 and "--gpus 4 but the launcher started WORLD_SIZE=2" in err and out.strip() == ""
+
+
+@pytest.mark.skipif(not _no_gpu_here(), reason="checks the no-GPU exit")
+def test_bench_single_rank_exits_loudly_without_a_gpu():
+    rc, out, err = _run_bench(["--gpus", "1"])
+    assert rc != 0 and "no GPU visible" in err and "launching" not in err and out.strip() == ""

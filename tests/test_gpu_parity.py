@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import rayfinder_amd as rf
-from conftest import GOLDEN, bits, oracle_scene_from_pt
+from conftest import DUCK, GOLDEN, DuckOracle, bits, oracle_scene_from_pt
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
@@ -1146,3 +1146,89 @@ def test_bvh_visualizer_tool_png_is_the_grey_map_of_the_node_visit_pass(duck_pt,
             grey = rf.bvh_visualizer_grey(gpu["nodesVisited"]).reshape(h, w)
             assert np.array_equal(img[..., 0], grey) and np.array_equal(img[..., 1], grey) and np.array_equal(img[..., 2], grey)
         assert files[0] == files[1]
+
+
+# ------------------------------------------------------------------ round 4: bench.py as its own launcher; product inputs of the checker
+def _bench_line(extra, tmp_path):
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    duck = str(tmp_path / "Duck.pt")
+    if not os.path.exists(duck):
+        rf.PtFormat.from_gltf(DUCK).save(duck)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", duck, "--width", "320", "--height", "192", "--steps", "2", "--warmup", "1",
+                        "--bounces", "4", "--cpu-seconds", "1", "--repeat", "3"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line on stdout"
+    return json.loads(lines[0]), p.stderr.decode()
+
+
+def test_bench_line_shape_is_the_same_however_the_rank_was_started(tmp_path):
+    """`python bench.py --gpus 1`, the same through bench.py's own launcher (torch.distributed.run --standalone, what
+    `--gpus N > 1` does by itself), and one rank through the whole N > 1 plumbing (RCCL process group, the product's
+    communicator, frame-end exchange to itself, device un-tile): one JSON line each, same keys, n_gpus = 1, the same rays,
+    and the median-of-3 bookkeeping."""
+    plain, _ = _bench_line(["--gpus", "1"], tmp_path)
+    launched, err = _bench_line(["--gpus", "1", "--launch"], tmp_path)
+    assert "launching 1 ranks" in err
+    looped, _ = _bench_line(["--gpus", "1", "--launch", "--exchange-at-world-1"], tmp_path)
+    for line in (plain, launched, looped):
+        assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "Mrays/s" and line["nan_pixels"] == 0
+        rep = line["repeats"]
+        assert rep["count"] == 3 and len(rep["value"]) == 3 and rep["min"] <= line["value"] <= rep["max"]
+        assert abs(line["value"] - sorted(rep["value"])[1]) <= 0.11
+        assert abs(line["ms_per_step"] * 2 - sorted(rep["timed_region_s"])[1] * 1e3) < 1e-2
+        assert line["parity_crop"]["verdict"] == "bit-identical"            # the LAST repeat's frame against the oracle
+    assert set(plain) == set(launched) == set(looped)
+    assert plain["rays"] == launched["rays"] == looped["rays"]
+    assert plain["rccl_ranks"] == 0 and plain["exchange"] == "none"
+    assert looped["rccl_ranks"] == 1 and "C++ RCCL exchange" in looped["exchange"] and "FALLBACK" not in looped["exchange"]
+
+
+def test_product_computed_checker_inputs_equal_the_oracles_own():
+    """The parity tests above give the oracle sky states, cameras and baked arrays the PRODUCT computed (rf.aligned_sky_state,
+    rf.fly_camera / create_camera, oracle_scene_from_pt): here each of them is compared with the oracle's own computation -- and the
+    sky with the reference-compiled vectors -- inside the driver-run suite (tests/checker_inputs.py; the CPU suite runs the same)."""
+    import checker_inputs
+    assert checker_inputs.check_sky_states() == (30, 144)
+    assert checker_inputs.check_cameras() >= 50
+    nodes, info = checker_inputs.check_atrium_bake()
+    assert nodes == 459645 and info["triangles"] == 265024
+    # the other scenes the GPU tests bake with the product and hand to the oracle: Duck (glTF ingest + builder) and the courtyard asset
+    d = DuckOracle()
+    a = rf.PtFormat.from_gltf(DUCK).arrays()
+    assert a["bvhNodes"].tobytes() == d.nodes.tobytes() and a["trianglePositionAttributes"].tobytes() == d.pos48.tobytes()
+    assert a["triangleVertexAttributes"].tobytes() == np.ascontiguousarray(d.attr80).tobytes()
+    px, w, h = a["baseColorTextures"][0]
+    assert (w, h) == tuple(int(x) for x in d.descs[0][:2]) and np.array_equal(px, d.texels[:px.size])
+
+
+def test_leaves_that_share_a_first_triangle_keep_the_exact_record_layouts(duck_pt, duck_oracle):
+    """A hand-made .pt may point two leaves at the same triangle (validateScene checks ranges, not disjointness).  The
+    half-precision / local-grid kernels cull a leaf by the exact box kept in its FIRST triangle's record, which can hold only one
+    box: for such a scene those layouts stay off (rf_wide.hpp, leafBoxesIntoTriangles), whatever the options say, and the image is
+    the reference-ordered oracle's on every layout that is left."""
+    a = duck_pt.arrays()
+    nodes = a["bvhNodes"].copy()
+    leaves = np.nonzero(nodes["triangleCount"] == 1)[0]
+    rng = np.random.default_rng(3)
+    for k in rng.choice(len(leaves) - 1, 400, replace=False):       # 400 leaves now test a triangle that lies in ANOTHER leaf's box
+        nodes[leaves[k + 1]]["trianglesOffset"] = nodes[leaves[k]]["trianglesOffset"]
+    tex = [(px, w, h) for (px, w, h) in a["baseColorTextures"]]
+    sc = rf.scene_from_arrays(nodes, a["trianglePositionAttributes"], a["triangleVertexAttributes"], tex)
+    W, H, spp, bounces = 160, 120, 3, 4
+    cam = rf.fly_camera(W, H)
+    osc = orc.OracleScene(nodes, a["trianglePositionAttributes"], a["triangleVertexAttributes"], duck_oracle.descs, duck_oracle.texels)
+    ref, _ = orc.render(osc, orc.make_render_params(W, H, orc.default_pt_camera(W, H), spp, bounces, 0.25, orc.aligned_sky_state()), 0, spp)
+    for opts in (dict(), dict(quad_half_from_bounce=1, quad_half_shadow_from_bounce=1), dict(quad_local_from_bounce=1, quad_local_shadow_from_bounce=1),
+                 dict(quad_from_bounce=0, quad_shadow_from_bounce=0)):
+        r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, bounces, rf.make_sky(), 0.25), sc)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        r.render(spp)
+        img, _ = r.read_accumulation()
+        r.close()
+        assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3])), opts

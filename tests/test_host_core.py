@@ -818,3 +818,57 @@ def test_gltf_sparse_accessors_and_normalized_integer_attributes(tmp_path):
         q.write_text(json.dumps(bad))
         with pytest.raises(rf.RayfinderError):
             rf.PtFormat.from_gltf(q)
+
+
+def test_gltf_strides_and_counts_whose_product_wraps_are_rejected(tmp_path):
+    """byteStride and count come straight from the JSON.  (count - 1) * stride formed in size_t wraps for byteStride = 2^54 and
+    count = 1025 (advisor, round 3: the bounds check passed and the bake read base + i * 2^54).  Every such file must be an
+    error with a message -- in a child process, so that a crash is a test failure and not the end of the test run."""
+    import base64
+    import subprocess
+    blob = np.arange(6 * 3, dtype="<f4").tobytes() + np.arange(6 * 2, dtype="<f4").tobytes() + np.array([0, 1, 2, 3, 4, 5], "<u2").tobytes()
+
+    def doc(stride=None, count=6, sparse_count=None, idx_count=6):
+        views = [{"buffer": 0, "byteOffset": 0, "byteLength": 72}, {"buffer": 0, "byteOffset": 72, "byteLength": 48}, {"buffer": 0, "byteOffset": 120, "byteLength": 12}]
+        if stride is not None:
+            views[0]["byteStride"] = stride
+            views[1]["byteStride"] = stride
+        acc = [{"bufferView": 0, "componentType": 5126, "count": count, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": count, "type": "VEC2"},
+               {"bufferView": 2, "componentType": 5123, "count": idx_count, "type": "SCALAR"}]
+        if sparse_count is not None:
+            acc[0] = {"componentType": 5126, "count": 6, "type": "VEC3",
+                      "sparse": {"count": sparse_count, "indices": {"bufferView": 2, "componentType": 5123}, "values": {"bufferView": 0}}}
+        return {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+                "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 0, "TEXCOORD_0": 1}, "indices": 2, "material": 0}]}],
+                "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [1.0, 1.0, 1.0, 1.0]}}], "accessors": acc, "bufferViews": views,
+                "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}]}
+
+    cases = {"ok": doc(), "stride_2p54": doc(stride=2 ** 54, count=1025), "stride_2p61": doc(stride=2 ** 61, count=9), "stride_2p63": doc(stride=2 ** 63, count=3),
+             "stride_3": doc(stride=3), "stride_256": doc(stride=256, count=1), "stride_below_element": doc(stride=8),
+             "count_2p60": doc(count=2 ** 60), "count_negative": doc(count=-6), "count_1e300": doc(count=1e300),
+             "sparse_2p62": doc(sparse_count=2 ** 62), "sparse_2p63_plus": doc(sparse_count=2 ** 63 + 1), "index_count_2p63": doc(idx_count=3 * 2 ** 61)}
+    for name, js in cases.items():
+        (tmp_path / f"{name}.gltf").write_text(json.dumps(js))
+    code = ("import sys; sys.path.insert(0, %r); import rayfinder_amd as rf\n"
+            "for p in sys.argv[1:]:\n"
+            "    try:\n"
+            "        pt = rf.PtFormat.from_gltf(p); print('OK', p, pt.view().num_triangle_position_attributes)\n"
+            "    except Exception as e:\n"
+            "        print('ERR', p, str(e)[:120])\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code] + [str(tmp_path / f"{n}.gltf") for n in cases], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"the bake crashed (exit {r.returncode}): {r.stdout[-2000:]} {r.stderr[-2000:]}"
+    lines = {os.path.basename(l.split()[1])[:-5]: l for l in r.stdout.splitlines() if l.startswith(("OK", "ERR"))}
+    assert set(lines) == set(cases)
+    assert lines["ok"].startswith("OK") and lines["ok"].rstrip().endswith(" 2")
+    for name in cases:
+        if name != "ok":
+            assert lines[name].startswith("ERR") and "glTF" in lines[name], lines[name]
+
+
+# ---------------------------------------------------------------- round 4: what the GPU tests hand to the checker (also run under -m gpu)
+def test_product_sky_states_cameras_and_atrium_bake_equal_the_oracles():
+    import checker_inputs
+    checker_inputs.check_sky_states()
+    checker_inputs.check_cameras()
+    nodes, info = checker_inputs.check_atrium_bake()
+    assert nodes == 459645 and info["triangles"] == 265024

@@ -148,3 +148,17 @@ for i in range(400):
         for k in path[:-1]: o = o[k]
         o[path[-1]] = int(rng.choice([0, 1, 2, 3, 5, 7, 8, 255, 4096, 2**31, 2**32 - 1, 5120, 5121, 5123, 5125, 5126, int(rng.integers(0, 200))]))
     open(f"{out}/ingest/s{i}.gltf", "w").write(json.dumps(j2))
+# strides and counts whose PRODUCT wraps size_t (round 4: byteStride 2^54 with count 1025 passed a (count-1)*stride check),
+# negative and non-integral sizes, one or two slots at a time
+huge = [2**54, 2**53, 2**53 + 2, 2**61, 2**63, 2**64 - 1, 2**64, 1025, -1, -2**40, 1e300, 0.5, 2**32, 2**32 + 1, 2**44]
+for i in range(300):
+    j2 = json.loads(json.dumps(sp_js))
+    for _ in range(1 + i % 2):
+        path = slots[int(rng.integers(0, len(slots)))]
+        o = j2
+        for k in path[:-1]: o = o[k]
+        o[path[-1]] = huge[int(rng.integers(0, len(huge)))]
+    if i % 3 == 0:      # the reported case: a stride on every attribute view + a count that multiplies it past 2^64
+        for v in j2["bufferViews"]: v["byteStride"] = huge[i // 3 % 5]
+        for a in j2["accessors"][:5]: a["count"] = 1025
+    open(f"{out}/ingest/u{i}.gltf", "w").write(json.dumps(j2))
