@@ -810,18 +810,35 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
     float     rayTMax = tMax;
-    int       stackSize = 0;
+    // Closest-hit launches keep the stack top as a BYTE offset into sStack (lane * 8 + depth * kBlock * 8): a push is one ds_write + one add, no
+    // shift-or for the address, and -- in the quad steps -- one bound check per step instead of one per push: closest-hit launches -1.5 % (round 4,
+    // gpurun_out A/B in profiles/r04_lanes).  The any-hit launches measured +2.5 % with it and keep the plain depth, as do the counting builds
+    // (they report it).
+    constexpr bool kPtrStack = !COUNT && !ANY_HIT;
+    const int     spBase = kPtrStack ? static_cast<int>(threadIdx.x * sizeof(uint2)) : 0;
+    constexpr int kSpStep = kPtrStack ? static_cast<int>(kBlock * sizeof(uint2)) : 1;
+    constexpr int kSpLimit = kPtrStack ? kDepth * static_cast<int>(kBlock * sizeof(uint2)) : kDepth; // (depth == kDepth <=> offset >= this: lane * 8 < kBlock * 8)
+    int       stackSize = spBase;
+    const auto stackAt = [&](int s) -> uint2& {
+        if constexpr (kPtrStack) return *reinterpret_cast<uint2*>(reinterpret_cast<char*>(sStack) + s);
+        else return sStack[s * kBlock + threadIdx.x];
+    };
     bool      needScalar = false; // irregular ray or stack overflow: redo with the scalar traversal
     // An any-hit ray's rayTMax never changes, so an entry that passed `tmin < rayTMax` when it was pushed passes it when it is popped: such a
     // kernel keeps only the words on its stack (no tmin to select, store and compare) -- except the reference-bookkeeping build, which
     // pushes missed children with tmin = +inf to count them.
     constexpr bool kStackWordsOnly = ANY_HIT && !kRefCount;
     auto      push = [&](uint32_t word, float tmin) -> bool {
-        if (stackSize >= kDepth) return false;
-        if constexpr (kStackWordsOnly) sStack[stackSize * kBlock + threadIdx.x].x = word;
-        else sStack[stackSize * kBlock + threadIdx.x] = make_uint2(word, __float_as_uint(tmin));
-        ++stackSize;
+        if (stackSize >= kSpLimit) return false;
+        if constexpr (kStackWordsOnly) stackAt(stackSize).x = word;
+        else stackAt(stackSize) = make_uint2(word, __float_as_uint(tmin));
+        stackSize += kSpStep;
         return true;
+    };
+    auto      pushUnchecked = [&](uint32_t word, float tmin) {
+        if constexpr (kStackWordsOnly) stackAt(stackSize).x = word;
+        else stackAt(stackSize) = make_uint2(word, __float_as_uint(tmin));
+        stackSize += kSpStep;
     };
     ClosestHit        best{};
     bool              occluded = false;
@@ -842,18 +859,18 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         node = kNodeDone;
         if constexpr (kStackWordsOnly)
         {
-            if (stackSize > 0)
+            if (stackSize > spBase)
             {
-                --stackSize;
-                node = sStack[stackSize * kBlock + threadIdx.x].x;
+                stackSize -= kSpStep;
+                node = stackAt(stackSize).x;
                 if (COUNT) ++wPop;
             }
             return;
         }
-        while (stackSize > 0)
+        while (stackSize > spBase)
         {
-            --stackSize;
-            uint2 e = sStack[stackSize * kBlock + threadIdx.x];
+            stackSize -= kSpStep;
+            uint2 e = stackAt(stackSize);
             asm volatile("" : "+v"(e.x), "+v"(e.y)); // one ds_read_b64 (not tmin first, word after the loop)
             if (COUNT) ++wPop;
             if (kRefCount) ++rayNodes;
@@ -926,7 +943,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 const uint32_t rayClass = classifyRay(ray);
                 negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u);
                 rayTMax = tMax;
-                stackSize = 0;
+                stackSize = spBase;
                 best.triangle = kMiss;
                 occluded = false;
                 if (COMPACT == 1) haveOuter = false;
@@ -1081,7 +1098,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                             halfEntryBounds<true>(a.s3, a.s4, a.s5, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
                             halfEntryBounds<true>(a.s6, a.s7, a.s8, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
                             halfEntryBounds<true>(a.s9, a.sa, a.sb, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
-                            w0 = a.sc, w1 = a.sd, w2 = a.se, w3 = a.sf;
+                            // (the four words reach the lanes HERE: left to the compiler, the SGPR -> VGPR copies sit in the join block and the per-lane
+                            // path pays for them on every step too: closest-hit launches -1 %)
+                            asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7" : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3) : "s"(a.sc), "s"(a.sd), "s"(a.se), "s"(a.sf));
                         }
                         else
                         {
@@ -1103,7 +1122,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                         // class B ray: a 0 * inf product means the packed test is not the reference's here
                         needScalar = true;
                         okq0 = okq1 = okq2 = okq3 = false;
-                        stackSize = 0; // -> popNext() ends the ray; it is redone below
+                        stackSize = spBase; // -> popNext() ends the ray; it is redone below
                     }
                     const uint32_t axN = (w0 >> kWideAxisShift) & 3u, axA = (w1 >> kWideAxisShift) & 3u, axB = (w3 >> kWideAxisShift) & 3u;
                     // (an any-hit ray on the conservative layouts leaves `tmin < rayTMax` to the exact leaf test: its rayTMax is the constant
@@ -1142,9 +1161,24 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     {
                         // enter the first entry that can be hit; the later ones wait on the stack with their tmin, last first
                         bool pushed = true;
-                        if (x3 && (x0 || x1 || x2)) pushed = push(s3w, s3t);
-                        if (x2 && (x0 || x1)) pushed = push(s2w, s2t) && pushed;
-                        if (x1 && x0) pushed = push(s1w, s1t) && pushed;
+                        if constexpr (kPtrStack)
+                        {
+                            // one bound check per step: room for the three entries a step can leave behind (a ray this deep that does not
+                            // need all three is redone by the scalar traversal a little earlier than necessary: same result)
+                            pushed = stackSize < kSpLimit - 2 * kSpStep;
+                            if (pushed)
+                            {
+                                if (x3 && (x0 || x1 || x2)) pushUnchecked(s3w, s3t);
+                                if (x2 && (x0 || x1)) pushUnchecked(s2w, s2t);
+                                if (x1 && x0) pushUnchecked(s1w, s1t);
+                            }
+                        }
+                        else
+                        {
+                            if (x3 && (x0 || x1 || x2)) pushed = push(s3w, s3t);
+                            if (x2 && (x0 || x1)) pushed = push(s2w, s2t) && pushed;
+                            if (x1 && x0) pushed = push(s1w, s1t) && pushed;
+                        }
                         node = x0 ? s0w : (x1 ? s1w : (x2 ? s2w : s3w));
                         if (!pushed)
                         {
@@ -1333,7 +1367,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     // class B ray: a 0 * inf product means the packed test is not the reference's here
                     needScalar = true;
                     ok0 = ok1 = false;
-                    stackSize = 0; // -> popNext() ends the ray; it is redone below
+                    stackSize = spBase; // -> popNext() ends the ray; it is redone below
                 }
 #if defined(RF_ABLATE) && RF_ABLATE == 1
                 {   // ablation: the slab arithmetic twice more (result kept alive, never different)
@@ -1363,7 +1397,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
                     const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
                     const bool     pushed = push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
-                    rayStackHigh = max(rayStackHigh, static_cast<uint32_t>(stackSize));
+                    rayStackHigh = max(rayStackHigh, static_cast<uint32_t>(stackSize)); // (kRefCount => COUNT => plain depth)
                     ++rayNodes; // the near child
                     if (!pushed)
                     {
@@ -1453,7 +1487,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     // class B ray with a 0 * inf product at this box: the reference's NaN rules apply -- the whole ray is redone by
                     // the scalar traversal (as the exact-record kernels do for any step with such a product)
                     needScalar = true;
-                    stackSize = 0;
+                    stackSize = spBase;
                     n = 0;
                 }
                 else if (!(bn <= bf && bf > 0.0f && bn < rayTMax)) n = 0; // the reference rejects this leaf: no triangle is tested

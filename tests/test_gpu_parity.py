@@ -1180,7 +1180,7 @@ def test_bench_line_shape_is_the_same_however_the_rank_was_started(tmp_path):
         rep = line["repeats"]
         assert rep["count"] == 3 and len(rep["value"]) == 3 and rep["min"] <= line["value"] <= rep["max"]
         assert abs(line["value"] - sorted(rep["value"])[1]) <= 0.11
-        assert abs(line["ms_per_step"] * 2 - sorted(rep["timed_region_s"])[1] * 1e3) < 1e-2
+        assert abs(line["ms_per_step"] * 2 - sorted(rep["timed_region_s"])[1] * 1e3) < 0.11      # (the list is rounded to 0.1 ms)
         assert line["parity_crop"]["verdict"] == "bit-identical"            # the LAST repeat's frame against the oracle
     assert set(plain) == set(launched) == set(looped)
     assert plain["rays"] == launched["rays"] == looped["rays"]
