@@ -79,6 +79,24 @@ enum Class : int
     kMixNoSel,     // the step mix with its 12 v_cndmask replaced by v_fma_mix
     kMixBfi,       // the step mix with its 12 v_cndmask replaced by v_bfi_b32
     kMixSel24,     // the step mix with 24 v_cndmask (12 fewer v_fma_mix)
+    kAddF,  // v_add_f32
+    kSubF,  // v_sub_f32
+    kMinF,  // v_min_f32
+    kMovB,  // v_mov_b32
+    kAndB,  // v_and_b32
+    kOrB,  // v_or_b32
+    kLshl,  // v_lshlrev_b32
+    kLshr,  // v_lshrrev_b32
+    kSubU,  // v_sub_u32
+    kFmac,  // v_fmac_f32
+    kMulS,  // v_mul_f32(sgpr)
+    kAlignS,  // v_alignbit_b32(sgpr)
+    kFmaMixS,  // v_fma_mix_f32(vvv,sgpr_free)
+    kCvt,  // v_cvt_f32_u32
+    kLshlAdd,  // v_lshl_add_u32
+    kMulLo,  // v_mul_lo_u32
+    kDivFix,  // v_div_fixup_f32
+    kCmpClass,  // v_cmp_class_f32
     kStepMix,      // the half-precision quad step's multiset: 12 alignbit, 24 fma_mix, 4 max3, 4 min3, 8 cmp, 12 cndmask  (64 instructions)
     kNumClasses
 };
@@ -86,7 +104,7 @@ enum Class : int
 static const char* kNames[kNumClasses] = {"v_fma_f32", "v_mul_f32", "v_add_u32", "v_fma_mix_f32", "v_perm_b32", "v_alignbit_b32", "v_pk_add_f32", "v_pk_mul_f32",
                                           "v_pk_fma_f32", "v_min3_f32", "v_max3_f32", "v_max_f32", "v_cmp_lt_f32(vcc)", "v_cmp_lt_f32(sgpr)", "v_cndmask_b32", "v_bfe_u32",
                                           "v_mov_b32_dpp", "v_fma_f64", "v_rcp_f32", "v_readlane_b32", "s_mov_b32", "ds_read_b64", "ds_write_b64", "v_cndmask_b32(sgpr)",
-                                          "v_cmp+v_cndmask", "v_bfi_b32", "v_bfe_i32", "mix_no_cndmask", "mix_bfi_for_cndmask", "mix_24_cndmask", "half_quad_step_mix"};
+                                          "v_cmp+v_cndmask", "v_bfi_b32", "v_bfe_i32", "mix_no_cndmask", "mix_bfi_for_cndmask", "mix_24_cndmask", "v_add_f32", "v_sub_f32", "v_min_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_sub_u32", "v_fmac_f32", "v_mul_f32(sgpr)", "v_alignbit_b32(sgpr)", "v_fma_mix_f32(vvv,sgpr_free)", "v_cvt_f32_u32", "v_lshl_add_u32", "v_mul_lo_u32", "v_div_fixup_f32", "v_cmp_class_f32", "half_quad_step_mix"};
 
 template<int CLASS>
 __global__ __launch_bounds__(256) void kIssue(int iters, unsigned long long execMask, Out* out)
@@ -106,6 +124,8 @@ __global__ __launch_bounds__(256) void kIssue(int iters, unsigned long long exec
     f2       pa = f2{a, b}, pb = f2{b, a};
     double   da = 1.0000001, db = 1e-12;
     uint32_t ldsAddr = threadIdx.x * 8u;
+    const float    sb = __builtin_amdgcn_readfirstlane(0x3f7ffffe) == 0 ? 1.0f : __uint_as_float(__builtin_amdgcn_readfirstlane(0x3f7ffffe));
+    const uint32_t sa = __builtin_amdgcn_readfirstlane(0x3c003c00);
     asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(ua), "+v"(ub), "+v"(uc), "+v"(pa), "+v"(pb), "+v"(da), "+v"(db), "+v"(ldsAddr));
     __syncthreads();
     unsigned long long savedExec;
@@ -279,6 +299,114 @@ __global__ __launch_bounds__(256) void kIssue(int iters, unsigned long long exec
         else if constexpr (CLASS == kBfeI)
         {
 #define OP(i) asm volatile("v_bfe_i32 %0, %0, 3, 29" : "+v"(R(i)));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kAddF)
+        {
+#define OP(i) asm volatile("v_add_f32 %0, %1, %0" : "+v"(R(i)) : "v"(c));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kSubF)
+        {
+#define OP(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(R(i)) : "v"(c));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kMinF)
+        {
+#define OP(i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(R(i)) : "v"(a));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kMovB)
+        {
+#define OP(i) asm volatile("v_mov_b32 %0, %1" : "=v"(R(i)) : "v"(R(((i) + 1) & 15)));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kAndB)
+        {
+#define OP(i) asm volatile("v_and_b32 %0, %1, %0" : "+v"(R(i)) : "v"(ua));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kOrB)
+        {
+#define OP(i) asm volatile("v_or_b32 %0, %1, %0" : "+v"(R(i)) : "v"(ub));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kLshl)
+        {
+#define OP(i) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(R(i)));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kLshr)
+        {
+#define OP(i) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(R(i)));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kSubU)
+        {
+#define OP(i) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(R(i)) : "v"(uc));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kFmac)
+        {
+#define OP(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(R(i)) : "v"(b), "v"(c));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kMulS)
+        {
+#define OP(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(R(i)) : "s"(sb));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kAlignS)
+        {
+#define OP(i) asm volatile("v_alignbit_b32 %0, %1, %1, %2" : "=v"(R(i)) : "s"(sa), "v"(R(((i) + 1) & 15)));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kFmaMixS)
+        {
+#define OP(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(R(i)) : "v"(R(((i) + 1) & 15)), "v"(a), "v"(c));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kCvt)
+        {
+#define OP(i) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(R(i)));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kLshlAdd)
+        {
+#define OP(i) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(R(i)) : "v"(uc));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kMulLo)
+        {
+#define OP(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(R(i)) : "v"(uc));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kDivFix)
+        {
+#define OP(i) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(R(i)) : "v"(a), "v"(b));
+            REP64(OP)
+#undef OP
+        }
+        else if constexpr (CLASS == kCmpClass)
+        {
+#define OP(i) asm volatile("v_cmp_class_f32 vcc, %0, %1" : : "v"(a), "v"(uc) : "vcc");
             REP64(OP)
 #undef OP
         }
