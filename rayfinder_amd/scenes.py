@@ -121,6 +121,9 @@ def _texture_sizes():
 # triangles (265 k at 1; 17 M at 8 -- 2.2 GB of BVH records + triangles, an order of magnitude past the 256 MiB Infinity Cache:
 # the out-of-cache regime of bench.py --scene-scale).  Same shapes, textures and camera; the surfaces' small bumps are re-sampled.
 _SCALE = 1
+# atrium(detail="clutter"): the architecture's flat grids at half the density in both directions and the columns at half the height
+# segments, so that the props below make up most of the triangles at about the same total (see _clutter)
+_THIN = 1
 
 
 class _Mesh:
@@ -156,7 +159,7 @@ def _bump(u, v, seed, amp):
 
 
 def _plane(mesh, origin, eu, ev, nu, nv, tex, uv_scale, bump_seed=0, bump=0.0):
-    nu, nv = nu * _SCALE, nv * _SCALE
+    nu, nv = max(nu * _SCALE // _THIN, 1), max(nv * _SCALE // _THIN, 1)
     origin, eu, ev = (np.asarray(a, np.float64) for a in (origin, eu, ev))
     s, t = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1), indexing="ij")
     n = _normalize(np.cross(eu, ev))
@@ -170,7 +173,7 @@ def _plane(mesh, origin, eu, ev, nu, nv, tex, uv_scale, bump_seed=0, bump=0.0):
 
 
 def _column(mesh, cx, cz, y0, y1, radius, sides, segs, tex, flutes=12):
-    sides, segs = sides * _SCALE, segs * _SCALE
+    sides, segs = sides * _SCALE, max(segs * _SCALE // _THIN, 2)
     ang = np.arange(sides + 1, dtype=np.float64) * (6.283185307179586 / sides)
     sn, cs = _sincos(ang)
     fl, _ = _sincos(ang * flutes)
@@ -232,17 +235,168 @@ def _curtain(mesh, p0, p1, y_top, y_bot, waves, nu, nv, tex, amp, seed):
     mesh.add_grid(pos, nrm, uv, tex)
 
 
-def atrium_triangles(scale=1):
+# ----------------------------------------------------------------------------- clutter (atrium(detail="clutter"))
+def _add_grid_facing(mesh, pos, nrm, uv, tex):
+    """add_grid with the winding that makes the GEOMETRIC normal agree with the shading normal: the reference offsets ray origins along the
+    geometric normal whichever side a ray came from (ray_intersection.cpp:17-35), so a closed surface wound inside out shadows itself."""
+    geo = np.cross(pos[1:, :-1] - pos[:-1, :-1], pos[1:, 1:] - pos[:-1, :-1])
+    if float((geo * nrm[:-1, :-1]).sum()) < 0.0:
+        pos, nrm, uv = pos[:, ::-1], nrm[:, ::-1], uv[:, ::-1]
+    mesh.add_grid(np.ascontiguousarray(pos), np.ascontiguousarray(nrm), np.ascontiguousarray(uv), tex)
+
+
+
+def _rand01(n, seed):
+    """n deterministic uniforms in [0, 1) (integer hash of the index)."""
+    return (_hash32(np.arange(n, dtype=np.uint32) * np.uint32(2654435761) + np.uint32(seed)) >> np.uint32(8)).astype(np.float64) / 16777216.0
+
+
+def _displaced_sphere(mesh, centre, radius, nu, nv, tex, seed, amp):
+    """A 'lion head': a latitude / longitude sphere whose radius carries three octaves of lattice noise -- curved, densely tessellated,
+    with small concavities (what the heads, vases and capitals of a real asset look like to a BVH builder)."""
+    lat = np.linspace(0.02, 3.141592653589793 - 0.02, nv + 1)
+    lon = np.arange(nu + 1, dtype=np.float64) * (6.283185307179586 / nu)
+    sl, cl = _sincos(lat); so, co = _sincos(lon)
+    iu = (np.arange(nu + 1) % nu).astype(np.uint32)          # the seam closes: vertex nu == vertex 0
+    disp = np.zeros((nv + 1, nu + 1))
+    for octave, (cells, a) in enumerate(((6, 1.0), (13, 0.5), (29, 0.25))):
+        gu = (iu[None, :].astype(np.float64) * cells / nu); gv = (np.arange(nv + 1)[:, None].astype(np.float64) * cells / nv)
+        u0 = np.floor(gu).astype(np.uint32); v0 = np.floor(gv).astype(np.uint32); fu = gu - u0; fv = gv - v0
+
+        def lattice(a_, b_):
+            return (_hash32((a_ % np.uint32(cells)) * np.uint32(73856093) ^ b_ * np.uint32(19349663) ^ np.uint32(seed + 17 * octave)) & np.uint32(1023)).astype(np.float64) / 1023.0 - 0.5
+
+        top = lattice(u0, v0) * (1 - fu) + lattice(u0 + 1, v0) * fu
+        bot = lattice(u0, v0 + 1) * (1 - fu) + lattice(u0 + 1, v0 + 1) * fu
+        disp = disp + a * (top * (1 - fv) + bot * fv)
+    r = radius * (1.0 + amp * disp)
+    c = np.asarray(centre, np.float64)
+    pos = np.stack([c[0] + r * sl[:, None] * co[None, :], c[1] + r * cl[:, None] * np.ones_like(co)[None, :], c[2] + r * sl[:, None] * so[None, :]], axis=-1)
+    du = np.gradient(pos, axis=1); dv = np.gradient(pos, axis=0)
+    nrm = _normalize(np.cross(du, dv))          # outward
+    uv = np.stack([np.broadcast_to((lon / 6.283185307179586 * 3.0)[None, :], r.shape), np.broadcast_to((lat / 3.141592653589793 * 2.0)[:, None], r.shape)], axis=-1)
+    _add_grid_facing(mesh, pos, nrm, uv, tex)
+
+
+def _foliage(mesh, centre, radii, count, size, tex, seed):
+    """A plant: `count` small leaf triangles with random positions and orientations inside an ellipsoid.  Overlapping triangles in one
+    volume are what a binned-SAH builder cannot separate: this is where multi-triangle leaves and triangle tests per ray come from."""
+    c = np.asarray(centre, np.float64); rr = np.asarray(radii, np.float64)
+    u = [_rand01(count, seed + 101 * k) for k in range(9)]
+    # position: cube root of a uniform for the radius, direction from two uniforms
+    rad = u[0] ** (1.0 / 3.0)
+    cz = 2.0 * u[1] - 1.0; sz = np.sqrt(np.maximum(1.0 - cz * cz, 0.0))
+    sp, cp = _sincos(6.283185307179586 * u[2])
+    p = c + rad[:, None] * np.stack([sz * cp, cz, sz * sp], axis=-1) * rr
+    # a random frame per leaf
+    cz2 = 2.0 * u[3] - 1.0; sz2 = np.sqrt(np.maximum(1.0 - cz2 * cz2, 0.0))
+    sp2, cp2 = _sincos(6.283185307179586 * u[4])
+    n = np.stack([sz2 * cp2, cz2, sz2 * sp2], axis=-1)
+    helper = np.where(np.abs(n[:, 1:2]) < 0.9, np.array([[0.0, 1.0, 0.0]]), np.array([[1.0, 0.0, 0.0]]))
+    t1 = _normalize(np.cross(n, helper)); t2 = np.cross(n, t1)
+    s1 = size * (0.5 + u[5]); s2 = size * (0.25 + 0.5 * u[6])
+    a = p - 0.5 * s1[:, None] * t1; b = p + 0.5 * s1[:, None] * t1 + 0.3 * s2[:, None] * t2; d = p + s2[:, None] * t2 * (1.0 + u[7][:, None])
+    mesh.P.append(np.stack([a, b, d], axis=1))
+    mesh.N.append(np.stack([n, n, n], axis=1))
+    uv0 = np.stack([u[7], u[8]], axis=-1)
+    mesh.UV.append(np.stack([uv0, uv0 + np.array([0.2, 0.0]), uv0 + np.array([0.1, 0.25])], axis=1))
+    mesh.T.append(np.full(count, tex, np.uint32))
+
+
+def _chain(mesh, top, links, link_r, tube_r, tex, seed):
+    """A hanging chain: `links` tori, alternately turned by 90 degrees (thin, curved, many small triangles in a tall thin box)."""
+    nu, nv = 10, 6
+    a = np.arange(nu + 1, dtype=np.float64) * (6.283185307179586 / nu); b = np.arange(nv + 1, dtype=np.float64) * (6.283185307179586 / nv)
+    sa, ca = _sincos(a); sb, cb = _sincos(b)
+    for k in range(links):
+        c = np.asarray(top, np.float64) - np.array([0.0, 1.55 * link_r * k, 0.0])
+        ring = (link_r + tube_r * cb[None, :]); y = tube_r * sb[None, :] * np.ones_like(sa)[:, None]
+        x = ring * ca[:, None] * 0.62; z = ring * sa[:, None]          # an oval link, long axis vertical after the swap below
+        if k % 2 == 0:
+            pos = np.stack([c[0] + x, c[1] + z, c[2] + y], axis=-1)
+        else:
+            pos = np.stack([c[0] + y, c[1] + z, c[2] + x], axis=-1)
+        du = np.gradient(pos, axis=0); dv = np.gradient(pos, axis=1)
+        nrm = _normalize(np.cross(du, dv))
+        uv = np.stack([np.broadcast_to((a / 6.283185307179586)[:, None], x.shape), np.broadcast_to((b / 6.283185307179586)[None, :], x.shape)], axis=-1)
+        # (shading normal: away from the tube's centre line, the ring of radius link_r)
+        ring0 = link_r * ca[:, None] * 0.62 * np.ones_like(cb)[None, :]; ring1 = link_r * sa[:, None] * np.ones_like(cb)[None, :]; zero = np.zeros_like(x)
+        core = np.stack([c[0] + ring0, c[1] + ring1, c[2] + zero], axis=-1) if k % 2 == 0 else np.stack([c[0] + zero, c[1] + ring1, c[2] + ring0], axis=-1)
+        out = _normalize(pos - core)
+        _add_grid_facing(mesh, pos, out, uv, tex)
+
+
+def _cable(mesh, p0, p1, segments, radius, sag, tex):
+    """A sagging cable between two points as a three-sided tube of LONG segments: skinny triangles that run diagonally through space have
+    bounding boxes thousands of times their own area -- the classic BVH stressor (rails, rods, stems, the chains' hangers), and what puts
+    triangle tests per ray up in a real asset."""
+    p0, p1 = np.asarray(p0, np.float64), np.asarray(p1, np.float64)
+    t = np.linspace(0.0, 1.0, segments + 1)
+    centre = p0[None, :] + t[:, None] * (p1 - p0)[None, :]
+    centre[:, 1] -= sag * 4.0 * t * (1.0 - t)
+    axis = _normalize((p1 - p0)[None, :])[0]
+    helper = np.array([0.0, 1.0, 0.0]) if abs(axis[1]) < 0.9 else np.array([1.0, 0.0, 0.0])
+    e1 = _normalize(np.cross(axis, helper)[None, :])[0]; e2 = np.cross(axis, e1)
+    ang = np.arange(4, dtype=np.float64) * (6.283185307179586 / 3.0)
+    sa, ca = _sincos(ang)
+    ring = radius * (ca[:, None] * e1[None, :] + sa[:, None] * e2[None, :])          # (4, 3): three sides, closed
+    pos = centre[:, None, :] + ring[None, :, :]
+    nrm = np.broadcast_to(_normalize(ring)[None, :, :], pos.shape)
+    uv = np.stack([np.broadcast_to((t * 8.0)[:, None], pos.shape[:2]), np.broadcast_to((ang / 6.283185307179586)[None, :], pos.shape[:2])], axis=-1)
+    _add_grid_facing(mesh, pos, nrm, uv, tex)
+
+
+def _clutter(m):
+    """The props of atrium(detail="clutter"): draped cloth, displaced spheres, chains and plants -- the curved, densely tessellated and
+    overlapping detail the plain stand-in lacks.  Same 25 textures."""
+    H1, H2 = 4.2, 8.4
+    CZ0, CZ1 = -3.4, 3.4
+    # cloth: finely folded sheets hung across the court and along the lower arcades
+    for i, (x, wv) in enumerate(((-9.5, 7), (-4.5, 9), (0.5, 6), (5.0, 8), (9.5, 7))):
+        _curtain(m, (x, 0, CZ0 + 0.3), (x, 0, CZ1 - 0.3), H1 + 2.4, H1 - 1.0, wv, 88, 56, 4 + i % 6, 0.16, 0.9 * i + 0.3)
+    for i, x in enumerate((-10.0, -6.0, -2.0, 2.0, 6.0, 10.0)):
+        _curtain(m, (x - 0.9, 0, CZ0 - 0.5), (x + 0.9, 0, CZ0 - 0.5), H1 - 0.8, 0.4, 5, 36, 42, 4 + (i + 3) % 6, 0.09, 0.5 * i)
+    # heads / vases: displaced spheres on the plinths and on the parapet
+    for i, (x, y, z, r) in enumerate(((-3.0, 1.35, 1.2, 0.42), (-5.5, 1.0, -1.5, 0.38), (3.5, 1.65, -0.8, 0.40), (6.5, 1.1, 1.6, 0.36), (-8.5, 0.95, 0.4, 0.45), (0.2, 1.9, 2.2, 0.33),
+                                      (-7.0, H1 + 1.3, CZ0, 0.3), (-1.0, H1 + 1.3, CZ0, 0.3), (5.0, H1 + 1.3, CZ1, 0.3), (9.0, H1 + 1.3, CZ1, 0.3))):
+        _displaced_sphere(m, (x, y, z), r, 56, 36, 20 + i % 5, 700 + 13 * i, 0.35)
+    # chains hanging from the upper slab into the court
+    for i, (x, z) in enumerate(((-6.5, -1.2), (-1.5, 1.4), (3.0, -1.6), (7.5, 0.9), (1.0, 0.2), (-9.0, 1.0))):
+        _chain(m, (x, H2 - 0.1, z), 28, 0.09, 0.02, 3 if i % 2 else 1, 40 + i)
+    # cables strung across the court between the galleries and down to the floor, at all sorts of angles
+    for i in range(96):
+        h = _rand01(6, 500 + 7 * i)
+        x0 = -11.0 + 22.0 * h[0]; x1 = min(max(x0 + (h[1] - 0.5) * 14.0, -11.2), 11.2)
+        ya = (H1 + 0.9) if i % 3 else (H2 + 1.4); yb = (0.05 if i % 5 == 0 else (H1 + 0.9 if i % 2 else H2 + 1.4))
+        _cable(m, (x0, ya, CZ0 + 0.05 if i % 2 else CZ1 - 0.05), (x1, yb, CZ1 - 0.05 if i % 2 else CZ0 + 0.05), 4, 0.012, 0.25 + 0.5 * h[2], 3)
+    # plants: clusters of overlapping leaves in planters on the court floor and on the first-floor gallery ...
+    for i, (x, y, z, rr, n) in enumerate(((-3.0, 2.3, 1.2, (0.55, 0.75, 0.55), 4000), (3.5, 2.6, -0.8, (0.5, 0.8, 0.5), 4000), (6.5, 2.0, 1.6, (0.6, 0.7, 0.6), 4000),
+                                          (-8.5, 1.9, 0.4, (0.7, 0.8, 0.7), 5000), (-11.0, H1 + 1.2, -5.0, (0.9, 0.9, 0.9), 5000), (11.0, H1 + 1.2, 5.0, (0.9, 0.9, 0.9), 5000),
+                                          (0.0, H1 + 1.1, 5.3, (1.4, 0.8, 0.6), 6000))):
+        _foliage(m, (x, y, z), rr, n, 0.13, 5 if i % 3 else 8, 9000 + 31 * i)
+    # ... and trees in the court: wide, sparse canopies of larger leaves that a good part of the rays has to cross (a ray through a canopy
+    # meets some tens of overlapping leaf boxes: the triangle tests per ray of a real asset's plants and drapes)
+    for i, (x, z, y, r) in enumerate(((-9.5, -1.0, 3.6, 1.35), (-6.2, 1.3, 4.3, 1.5), (-2.6, -1.2, 3.9, 1.4), (1.2, 1.2, 4.6, 1.6), (4.6, -1.1, 3.8, 1.4), (8.4, 1.0, 4.2, 1.5),
+                                      (10.4, -1.4, 3.4, 1.2), (-0.6, 0.3, 6.6, 1.7))):
+        _foliage(m, (x, y, z), (r, 0.8 * r, r), 6500, 0.24, 5 if i % 2 else 8, 12000 + 57 * i)
+        _plane(m, (x - 0.07, 0.0, z - 0.07), (0.14, 0, 0), (0, y - 0.5 * r, 0), 2, 24, 3, (0.2, 3.0), 71 + i, 0.0)      # the trunk: two crossed strips
+        _plane(m, (x, 0.0, z - 0.07), (0, 0, 0.14), (0, y - 0.5 * r, 0), 2, 24, 3, (0.2, 3.0), 81 + i, 0.0)
+
+
+def atrium_triangles(scale=1, detail="plain"):
     """-> positions (N,9), normals (N,9), uvs (N,6), texture index (N,) in source order."""
-    global _SCALE
+    global _SCALE, _THIN
+    assert detail in ("plain", "clutter")
     _SCALE = int(scale)
+    _THIN = 2 if detail == "clutter" else 1
     try:
-        return _atrium_triangles()
+        return _atrium_triangles(detail == "clutter")
     finally:
         _SCALE = 1
+        _THIN = 1
 
 
-def _atrium_triangles():
+def _atrium_triangles(clutter=False):
     m = _Mesh()
     X0, X1, Z0, Z1 = -15.0, 15.0, -7.0, 7.0   # outer walls
     CX0, CX1, CZ0, CZ1 = -11.5, 11.5, -3.4, 3.4  # open court
@@ -304,6 +458,8 @@ def _atrium_triangles():
                             ((x - s, 0, z + s), (0, 0, -2 * s), (0, h, 0)), ((x + s, 0, z - s), (0, 0, 2 * s), (0, h, 0)),
                             ((x - s, h, z - s), (2 * s, 0, 0), (0, 0, 2 * s))):
             _plane(m, o, eu, ev, 10, 10, tex, (1.0, 1.0), 61 + i, 0.002)
+    if clutter:
+        _clutter(m)
     return m.arrays()
 
 
@@ -314,12 +470,14 @@ def atrium_textures():
 _CACHE = {}
 
 
-def atrium(scale=1):
+def atrium(scale=1, detail="plain"):
     """-> (PtFormat, info dict).  The BVH is built by the product's builder (host by default: rf.set_bake_bvh_builder).
-    scale > 1: every surface grid tessellated scale x finer in both directions (scale^2 x the triangles)."""
-    key = "atrium" if scale == 1 else f"atrium{scale}"
+    scale > 1: every surface grid tessellated scale x finer in both directions (scale^2 x the triangles).
+    detail = "clutter": the harder stand-in -- the flat grids thinned, plus draped cloth, displaced spheres, chains and plants of
+    overlapping leaves (curved, densely tessellated, not separable by a SAH split: multi-triangle leaves, several triangle tests per ray)."""
+    key = ("atrium" if scale == 1 else f"atrium{scale}") + ("" if detail == "plain" else "_" + detail)
     if key not in _CACHE:
-        P, N, UV, T = atrium_triangles(scale)
+        P, N, UV, T = atrium_triangles(scale, detail)
         tex = atrium_textures()
         pt = PtFormat.from_triangles(P, N, UV, T, tex)
         h = hashlib.sha256()
@@ -328,6 +486,8 @@ def atrium(scale=1):
         for px, w, hh in tex:
             h.update(px.tobytes())
         name = "synthetic atrium (Sponza stand-in)" if scale == 1 else f"synthetic atrium x{scale} tessellation (out-of-cache variant of the Sponza stand-in)"
+        if detail != "plain":
+            name = name.replace("synthetic atrium", "synthetic atrium with clutter")
         info = dict(name=name, triangles=int(P.shape[0]), textures=len(tex),
                     texture_mib=sum(px.size for px, _, _ in tex) * 4 / 2 ** 20, digest=h.hexdigest()[:16])
         _CACHE[key] = (pt, info)

@@ -1232,3 +1232,39 @@ def test_leaves_that_share_a_first_triangle_keep_the_exact_record_layouts(duck_p
         img, _ = r.read_accumulation()
         r.close()
         assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3])), opts
+
+
+def test_clutter_atrium_crops_vs_oracle_and_its_traversal_statistics():
+    """The harder stand-in (scenes.atrium(detail="clutter"): cloth, displaced spheres, chains, diagonal cables, plants of overlapping leaves) under every
+    record layout the renderer may pick for it: crops bit-identical to the oracle, and the counting build reproduces the oracle's node visits and triangle
+    tests -- 78 visits and 7.5 triangle tests per closest-hit ray against the plain atrium's 62 / 3.0."""
+    from rayfinder_amd import scenes
+    pt, info = scenes.atrium(1, "clutter")
+    sc, _ = oracle_scene_from_pt(pt)
+    W, H, spp, bounces = 480, 270, 4, 8
+    crops = [(200, 100, 264, 148), (0, 0, 64, 32), (400, 200, 480, 270)]
+    rp = orc.make_render_params(W, H, orc.default_pt_camera(W, H), spp, bounces, 0.25, orc.aligned_sky_state())
+    for opts in (dict(), dict(quad_half_from_bounce=0, quad_half_shadow_from_bounce=0, quad_local_from_bounce=1, quad_local_shadow_from_bounce=1),
+                 dict(quad_half_from_bounce=0, quad_half_shadow_from_bounce=0, quad_local_from_bounce=0, quad_local_shadow_from_bounce=0)):
+        r, _ = _renderer(pt, W, H, spp, bounces)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        r.render(spp)
+        img, _ = r.read_accumulation()
+        s = r.stats()
+        r.close()
+        assert s["abandoned_rays"] == 0
+        for (x0, y0, x1, y1) in crops:
+            ref, _ = orc.render(sc, rp, 0, spp, x0, y0, x1, y1)
+            assert np.array_equal(bits(img[y0:y1, x0:x1, :3]), bits(ref[y0:y1, x0:x1, :3])), (opts, x0, y0)
+    # the reference's visit counts on a frame small enough for the oracle: counting build == oracle
+    w2, h2 = 160, 90
+    r, _ = _renderer(pt, w2, h2, 2, bounces)
+    r.set_counting(True)
+    r.render(2)
+    s = r.stats()
+    r.close()
+    _, st = orc.render(sc, orc.make_render_params(w2, h2, orc.default_pt_camera(w2, h2), 2, bounces, 0.25, orc.aligned_sky_state()), 0, 2)
+    assert s["closest_rays"] == st.closestRays and s["closest_node_visits"] == st.closestNodeVisits and s["closest_triangle_tests"] == st.closestTriTests
+    assert s["shadow_rays"] == st.shadowRays
+    assert st.closestNodeVisits / st.closestRays > 70 and st.closestTriTests / st.closestRays > 5.0

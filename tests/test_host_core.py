@@ -872,3 +872,19 @@ def test_product_sky_states_cameras_and_atrium_bake_equal_the_oracles():
     checker_inputs.check_cameras()
     nodes, info = checker_inputs.check_atrium_bake()
     assert nodes == 459645 and info["triangles"] == 265024
+
+
+def test_clutter_atrium_is_the_harder_stand_in_and_leaves_the_plain_one_alone():
+    """scenes.atrium(detail="clutter"): deterministic, bakes to the oracle builder's bytes like the plain atrium, closed props wound
+    so that the reference's geometric-normal ray offset leaves them lit, and the plain atrium's digest -- the BENCH series' workload -- is unchanged."""
+    import checker_inputs
+    from rayfinder_amd import scenes
+    pt, info = scenes.atrium(1, "clutter")
+    assert info["triangles"] == 358504 and info["textures"] == 25 and info["digest"] == "da326758c181ba04" and "clutter" in info["name"]
+    P, N, UV, T = scenes.atrium_triangles(1, "clutter")
+    assert np.isfinite(P).all() and np.isfinite(N).all() and np.isfinite(UV).all() and int(T.max()) < 25
+    assert checker_inputs.check_bake_against_oracle_builder(P, N, UV, T, pt) == 644457
+    geo = np.cross(P[:, 3:6] - P[:, 0:3], P[:, 6:9] - P[:, 0:3])
+    facing = (geo * (N[:, 0:3] + N[:, 3:6] + N[:, 6:9])).sum(axis=1)
+    assert (facing[-200000:] > 0).mean() > 0.995               # the props (the last ~214 k triangles): geometric and shading normals on the same side
+    assert scenes.atrium(1)[1]["digest"] == "206d06350b4893c2" and scenes.atrium(1)[1]["triangles"] == 265024
