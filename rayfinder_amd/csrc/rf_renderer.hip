@@ -38,6 +38,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 namespace rf
 {
@@ -828,8 +829,52 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // kernel keeps only the words on its stack (no tmin to select, store and compare) -- except the reference-bookkeeping build, which
     // pushes missed children with tmin = +inf to count them.
     constexpr bool kStackWordsOnly = ANY_HIT && !kRefCount;
+    // ---- Rays that need more than the LDS stack holds.  Until round 4 such a ray was redone whole by the scalar traversal (one lane, the
+    // reference-ordered kernel over the 32-byte nodes): fine at 0.01 % of the rays (the plain atrium), a cliff at 2.6 % (the atrium with clutter, whose
+    // long diagonal boxes keep many candidates alive: closest-hit launches 3.2 x longer than with the binary records, which push at most one entry per
+    // step).  Now a full LDS stack EVICTS its kEvict oldest entries -- the ones needed last -- to a per-lane scratch array and moves the rest down; when the
+    // LDS stack runs empty the youngest evicted block comes back.  Same entries, same order, nothing recomputed; only a ray that would need more than
+    // kDepth + kEvict * kSpillBlocks pending entries still takes the scalar traversal.  The number of evicted entries rides in bits 8.. of negMask.
+    constexpr bool kSpill = !kRefCount;
+    constexpr int  kEvict = 6, kSpillBlocks = 6;
+    static_assert(kEvict <= kDepth - 3, "after an eviction a quad step's three pushes must fit");
+    using SpillEntry = std::conditional_t<kStackWordsOnly, uint32_t, uint2>;
+    SpillEntry spillBuf[kSpill ? kEvict * kSpillBlocks : 1];
+    const auto slotS = [&](int i) -> int { return kPtrStack ? spBase + i * kSpStep : i; };
+    const auto evict = [&]() -> bool {
+        if constexpr (!kSpill) return false;
+        const uint32_t spilled = negMask >> 8;
+        if (spilled + kEvict > static_cast<uint32_t>(kEvict * kSpillBlocks)) return false;
+        for (int i = 0; i < kEvict; ++i)
+        {
+            if constexpr (kStackWordsOnly) spillBuf[spilled + i] = stackAt(slotS(i)).x;
+            else spillBuf[spilled + i] = stackAt(slotS(i));
+        }
+        const int depth = kPtrStack ? (stackSize - spBase) / kSpStep : stackSize;
+        for (int i = kEvict; i < depth; ++i)
+        {
+            if constexpr (kStackWordsOnly) stackAt(slotS(i - kEvict)).x = stackAt(slotS(i)).x;
+            else stackAt(slotS(i - kEvict)) = stackAt(slotS(i));
+        }
+        stackSize -= kEvict * kSpStep;
+        negMask += static_cast<uint32_t>(kEvict) << 8;
+        return true;
+    };
+    // (the LDS stack is empty and entries are waiting in scratch: the youngest block comes back.  popNext() does not look at the scratch area -- it is the
+    // hot path -- so a lane whose LDS stack ran dry reports "done"; the write-back block below, which every finished lane passes once, sends a lane with
+    // evicted entries back to work instead)
+    const auto unspill = [&]() {
+        negMask -= static_cast<uint32_t>(kEvict) << 8;
+        const uint32_t spilled = negMask >> 8;
+        for (int i = 0; i < kEvict; ++i)
+        {
+            if constexpr (kStackWordsOnly) stackAt(slotS(i)).x = spillBuf[spilled + i];
+            else stackAt(slotS(i)) = spillBuf[spilled + i];
+        }
+        stackSize = slotS(kEvict);
+    };
     auto      push = [&](uint32_t word, float tmin) -> bool {
-        if (stackSize >= kSpLimit) return false;
+        if (stackSize >= kSpLimit && !evict()) return false;
         if constexpr (kStackWordsOnly) stackAt(stackSize).x = word;
         else stackAt(stackSize) = make_uint2(word, __float_as_uint(tmin));
         stackSize += kSpStep;
@@ -1122,7 +1167,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                         // class B ray: a 0 * inf product means the packed test is not the reference's here
                         needScalar = true;
                         okq0 = okq1 = okq2 = okq3 = false;
-                        stackSize = spBase; // -> popNext() ends the ray; it is redone below
+                        stackSize = spBase, negMask &= 0xFFu; // -> popNext() ends the ray; it is redone below
                     }
                     const uint32_t axN = (w0 >> kWideAxisShift) & 3u, axA = (w1 >> kWideAxisShift) & 3u, axB = (w3 >> kWideAxisShift) & 3u;
                     // (an any-hit ray on the conservative layouts leaves `tmin < rayTMax` to the exact leaf test: its rayTMax is the constant
@@ -1161,11 +1206,12 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     {
                         // enter the first entry that can be hit; the later ones wait on the stack with their tmin, last first
                         bool pushed = true;
-                        if constexpr (kPtrStack)
+                        if constexpr (kPtrStack || kSpill)
                         {
-                            // one bound check per step: room for the three entries a step can leave behind (a ray this deep that does not
-                            // need all three is redone by the scalar traversal a little earlier than necessary: same result)
+                            // one bound check per step: room for the three entries a step can leave behind (a stack this full that does not
+                            // need all three evicts its oldest entries a little earlier than necessary: same entries, same order)
                             pushed = stackSize < kSpLimit - 2 * kSpStep;
+                            if (__builtin_expect(!pushed, 0)) pushed = evict();
                             if (pushed)
                             {
                                 if (x3 && (x0 || x1 || x2)) pushUnchecked(s3w, s3t);
@@ -1367,7 +1413,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     // class B ray: a 0 * inf product means the packed test is not the reference's here
                     needScalar = true;
                     ok0 = ok1 = false;
-                    stackSize = spBase; // -> popNext() ends the ray; it is redone below
+                    stackSize = spBase, negMask &= 0xFFu; // -> popNext() ends the ray; it is redone below
                 }
 #if defined(RF_ABLATE) && RF_ABLATE == 1
                 {   // ablation: the slab arithmetic twice more (result kept alive, never different)
@@ -1487,7 +1533,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     // class B ray with a 0 * inf product at this box: the reference's NaN rules apply -- the whole ray is redone by
                     // the scalar traversal (as the exact-record kernels do for any step with such a product)
                     needScalar = true;
-                    stackSize = spBase;
+                    stackSize = spBase, negMask &= 0xFFu;
                     n = 0;
                 }
                 else if (!(bn <= bf && bf > 0.0f && bn < rayTMax)) n = 0; // the reference rejects this leaf: no triangle is tested
@@ -1547,6 +1593,14 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         }
 
         // ---- write back finished rays
+        if (kSpill && node == kNodeDone && !needScalar && !occluded)
+        {
+            while (node == kNodeDone && (negMask >> 8) != 0u) // evicted entries pending: not finished after all (rare: see evict())
+            {
+                unspill();
+                popNext();
+            }
+        }
         if (node == kNodeDone)
         {
             if (needScalar)
