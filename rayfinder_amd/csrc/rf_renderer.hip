@@ -836,7 +836,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // LDS stack runs empty the youngest evicted block comes back.  Same entries, same order, nothing recomputed; only a ray that would need more than
     // kDepth + kEvict * kSpillBlocks pending entries still takes the scalar traversal.  The number of evicted entries rides in bits 8.. of negMask.
     constexpr bool kSpill = !kRefCount;
-    constexpr int  kEvict = 6, kSpillBlocks = 6;
+    constexpr int  kEvict = kDepth >= 9 ? 6 : (kDepth > 4 ? kDepth - 3 : 1), kSpillBlocks = 36 / kEvict; // (6 x 6 by default; the stress build with a 6-entry LDS stack -- make EXP=RF_EXP_STACK=6 -- evicts 3 at a time, all the time)
     static_assert(kEvict <= kDepth - 3, "after an eviction a quad step's three pushes must fit");
     using SpillEntry = std::conditional_t<kStackWordsOnly, uint32_t, uint2>;
     SpillEntry spillBuf[kSpill ? kEvict * kSpillBlocks : 1];
