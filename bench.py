@@ -282,7 +282,13 @@ def build_roofline(s, cs, per_bounce, workload):
             cl = [r for r in rows if r["kernel"] == "closest" and "valu" in r["fractions"]]
             if cl:
                 share = sum(r["fractions"]["valu"] * r["ms"] for r in cl) / sum(r["ms"] for r in cl)
-                ceilings["valu"] = dict(issue_share=round(share, 4), peak=1.0, frac=round(share, 4), counter="SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x cycles)")
+                cpi = ceil.get("valu_issue_peak_cycles_per_instruction")
+                ceilings["valu"] = dict(issue_share=round(share, 4), peak=1.0, frac=round(share, 4),
+                                        counter=f"SQ_INSTS_VALU x {cpi if cpi else 4} cycles / (1024 SIMDs x cycles)",
+                                        peak_cycles_per_instruction=cpi if cpi else 4.0,
+                                        peak_source=("tools/microbench/valu_calib: the fastest mixed instruction stream measured at 6 waves per SIMD (" + str(ceil.get("valu_issue_peak_source")) + "); "
+                                                     "the traversal step's own mix issues at " + str(ceil.get("valu_step_mix_cycles_per_instruction")) + " cycles per instruction; EXEC masks with half of the "
+                                                     "lanes off issue " + str(ceil.get("valu_half_empty_exec_speedup")) + " x as fast (no faster)") if cpi else "uncalibrated 4-cycle model")
         roofline["ceilings"] = ceilings
         binding = max(ceilings, key=lambda k: ceilings[k]["frac"])
         roofline["bound"] = binding

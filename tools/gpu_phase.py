@@ -13,7 +13,7 @@ from rayfinder_amd import scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 scale = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 opts = sys.argv[3:]
-pt, info = scenes.atrium(scale) if scale > 1 else scenes.atrium()
+pt, info = scenes.atrium(scale, os.environ.get("RF_SCENE_DETAIL", "plain"))          # RF_SCENE_DETAIL=clutter: the harder stand-in
 W, H = 1920, 1080
 cam = rf.fly_camera(W, H)
 for b in (1, 2, 3, 4, 8):

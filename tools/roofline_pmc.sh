@@ -14,9 +14,11 @@ cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-4}; WARMUP=${WARMUP:-2}
 # BENCH_ARGS: extra bench.py arguments (e.g. "--scene-scale 8 --spp-per-step 8"); CALIB_FROM: a committed profile directory whose
 # calibration files are reused instead of re-running the microbenchmark (same chip, same rocprofv3)
-BENCH="python $REPO/bench.py --steps $STEPS --warmup $WARMUP --no-cpu-baseline --no-counting ${BENCH_ARGS:-}"
+BENCH="python $REPO/bench.py --steps $STEPS --warmup $WARMUP --repeat 1 --no-cpu-baseline --no-counting ${BENCH_ARGS:-}"   # (--repeat 1: the counters are divided by the rays of ONE timed region + warm-up)
 CALIB=$REPO/tools/microbench/fetch_calib
 [ -x $CALIB ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $CALIB $REPO/tools/microbench/fetch_calib.hip
+VCALIB=$REPO/tools/microbench/valu_calib
+[ -x $VCALIB ] || /opt/rocm/bin/hipcc -std=c++20 -O3 --offload-arch=gfx950 -o $VCALIB $REPO/tools/microbench/valu_calib.hip
 
 summarize() {   # csv, counters -> per-kernel per-dispatch averages
 python3 - "$1" "$2" <<'PY'
@@ -42,9 +44,12 @@ pmc() {   # tag, command, counters
 # ---- 1. calibration microbenchmark
 if [ -n "${CALIB_FROM:-}" ]; then
   cp $REPO/$CALIB_FROM/calib_plain.jsonl $REPO/$CALIB_FROM/calib_pmc*_summary.txt $OUT/
+  cp $REPO/$CALIB_FROM/valu_calib_w*.jsonl $OUT/ 2> /dev/null
   echo "$CALIB_FROM" > $OUT/calibration_reused_from.txt
 else
 $CALIB > $OUT/calib_plain.jsonl 2> $OUT/calib_plain.err
+# (round 4) VALU issue rates per instruction class, at the traversal kernel's occupancy (6 waves per SIMD) and at 8; EXEC masks full .. one lane
+for w in 6 8; do $VCALIB $w 1500 > $OUT/valu_calib_w$w.jsonl 2>> $OUT/calib_plain.err; done
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1)); pmc calib_pmc$i "$CALIB" "$ctrs"

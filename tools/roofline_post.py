@@ -87,8 +87,46 @@ factors = dict(fetch_calibration=(1.0 / fr) if fr else None, write_calibration=(
                write_pattern="fill16<33>: coalesced 16 B/lane stores of 8 GiB: known = bytes written",
                streaming_read_ratio=ratio("stream16<33>", "fetch_ratio"),
                note="ratio = counter bytes / known bytes; MI355X_MICROARCH.md predicts 0.5 for wide coalesced streaming reads on gfx950")
-json.dump(dict(factors=factors, kernels=calibration), open(os.path.join(out, "calibration.json"), "w"), indent=1)
+# ---------------------------------------------------------------- VALU issue calibration (tools/microbench/valu_calib.hip, round 4)
+# cycles per wave-instruction per SIMD = wall time of a launch that keeps `waves_per_simd` waves on every SIMD x the shader clock the launch ran at
+# (s_memtime / s_memrealtime inside the kernel) / instructions issued per SIMD.  `valu_issue_peak` is what the roofline's VALU ceiling uses: the FASTEST
+# MIXED instruction stream measured (streams of a single class reach 2.3 cycles for plain VOP1 / VOP2 arithmetic on VGPRs, but the traversal kernel
+# did not get faster when 15 of its selects per step were moved into that class: profiles/r04_lanes) -- so a launch at fraction 1 issues as fast as
+# any mixed stream this chip was seen to issue.
+valu = {}
+for w in (6, 8):
+    path = os.path.join(out, f"valu_calib_w{w}.jsonl")
+    if not os.path.exists(path):
+        continue
+    for line in open(path):
+        line = line.strip()
+        if not line.startswith("{"):
+            continue
+        j = json.loads(line)
+        if "class" not in j:
+            continue
+        cyc = j["ns_per_simd_inst"] * j["memtime_mhz"] * 1e-3
+        valu.setdefault(j["class"], {}).setdefault(j["exec"], {})[f"w{w}"] = round(cyc, 3)
+valu_issue = None
+if valu:
+    def cyc_of(cls, mask="full", w="w6"):
+        return valu.get(cls, {}).get(mask, {}).get(w)
+    mixed = {c: cyc_of(c) for c in valu if (c.startswith("mix_") or c in ("half_quad_step_mix", "v_cmp+v_cndmask")) and cyc_of(c)}
+    fastest = min(mixed, key=mixed.get) if mixed else None
+    step = cyc_of("half_quad_step_mix")
+    valu_issue = dict(
+        cycles_per_instruction_at_6_waves_per_simd={c: cyc_of(c) for c in sorted(valu) if cyc_of(c)},
+        half_quad_step_mix_by_exec_mask={m: v.get("w6") for m, v in valu.get("half_quad_step_mix", {}).items()},
+        v_fma_mix_f32_by_exec_mask={m: v.get("w6") for m, v in valu.get("v_fma_mix_f32", {}).items()},
+        step_mix_cycles_per_instruction=step,
+        fastest_mixed_stream=fastest, valu_issue_peak_cycles_per_instruction=mixed.get(fastest) if fastest else None,
+        valu_issue_peak_instructions_per_simd_clk=round(1.0 / mixed[fastest], 4) if fastest else None,
+        half_empty_exec_speedup=round(step / valu["half_quad_step_mix"]["low32"]["w6"], 3) if step and valu.get("half_quad_step_mix", {}).get("low32", {}).get("w6") else None,
+        note="cycles per wave64 instruction per SIMD, wall-clock based, every SIMD of the chip loaded with 6 waves; half_empty_exec_speedup ~ 1: a VALU instruction "
+             "whose EXEC mask has half (or three quarters) of its lanes off issues no faster on gfx950 -- idle lanes are lost issue slots")
+json.dump(dict(factors=factors, kernels=calibration, valu_issue=valu_issue), open(os.path.join(out, "calibration.json"), "w"), indent=1)
 print(json.dumps(factors, indent=1))
+VALU_CPI = (valu_issue or {}).get("valu_issue_peak_cycles_per_instruction") or 4.0      # cycles per instruction at the calibrated issue peak (4: the uncalibrated round-3 model)
 
 # ---------------------------------------------------------------- the bench command
 bench = json.loads(open(os.path.join(out, "bench_under_trace.json")).read().strip().splitlines()[-1])
@@ -174,6 +212,8 @@ per_ray["ceilings"] = dict(
     hbm_random_64B_gather_GBps=round(max(hbm_gather.values()), 1) if hbm_gather else None,
     hbm_random_64B_gather_source={k2: round(v, 1) for k2, v in hbm_gather.items()},
     hbm_stream_read_GBps=calibration.get("stream16<33>", {}).get("rate"), hbm_stream_write_GBps=calibration.get("fill16<33>", {}).get("rate"),
+    valu_issue_peak_cycles_per_instruction=VALU_CPI, valu_issue_peak_source=(valu_issue or {}).get("fastest_mixed_stream") or "uncalibrated: 4 cycles per wave64 instruction",
+    valu_step_mix_cycles_per_instruction=(valu_issue or {}).get("step_mix_cycles_per_instruction"), valu_half_empty_exec_speedup=(valu_issue or {}).get("half_empty_exec_speedup"),
     note="measured on this chip by tools/microbench/fetch_calib.hip: G L1->L2 read requests/s of a random 64-byte record gather over a 32 MiB table "
          "(cache resident) = records/s x requests per record; bytes/s of the same gather over an 8 GiB table (every record from HBM)")
 json.dump(per_ray, open(os.path.join(out, "pmc_per_ray.json"), "w"), indent=1)
@@ -220,7 +260,10 @@ for kind in ("closest", "shadow"):
             e["l1_to_l2_requests_per_ray"] = round(c.get("TCP_TCC_READ_REQ_sum", 0.0) / rays, 2)
             if "SQ_INSTS_VALU" in c:
                 e["valu_instructions_per_ray"] = round(c["SQ_INSTS_VALU"] / rays, 1)
-                e["valu_issue_share"] = round(c["SQ_INSTS_VALU"] * 4.0 / SIMDS / cyc, 3)     # 4 cycles per wave64 instruction per SIMD
+                e["valu_issue_share"] = round(c["SQ_INSTS_VALU"] * VALU_CPI / SIMDS / cyc, 3)     # against the calibrated issue peak (valu_calib: fastest mixed stream)
+                e["valu_issue_share_4_cycle_model"] = round(c["SQ_INSTS_VALU"] * 4.0 / SIMDS / cyc, 3)     # rounds 2-3: 4 cycles per wave64 instruction per SIMD (uncalibrated: > 1 at bounce 1)
+                if "SQ_THREAD_CYCLES_VALU" in c:
+                    e["valu_active_lanes_per_instruction"] = round(c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_INSTS_VALU"] * 64.0, 1.0), 3)
                 e["salu_instructions_per_ray"] = round(c.get("SQ_INSTS_SALU", 0.0) / rays, 1)
             if "TCC_HIT_sum" in c:
                 e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 3)
@@ -234,8 +277,10 @@ if table:
     per_ray["per_bounce"] = table
     json.dump(per_ray, open(os.path.join(out, "pmc_per_ray.json"), "w"), indent=1)
     json.dump(dict(profile=os.path.basename(os.path.abspath(out)), spp_of_the_batch=bench["config"]["spp"],
+                   valu_issue_peak_cycles_per_instruction=VALU_CPI,
                    note="one row per launch of the timed batch; l1_accesses_per_clk_per_cu is against the ceiling of 1 (one vector-L1 tag access per clock "
-                        "per CU); valu_issue_share = wave instructions x 4 cycles / SIMD-cycles available", rows=table),
+                        "per CU); valu_issue_share = wave instructions x the calibrated cycles per instruction (calibration.json: valu_issue, the fastest mixed "
+                        "stream of tools/microbench/valu_calib) / SIMD-cycles available", rows=table),
               open(os.path.join(out, "per_bounce.json"), "w"), indent=1)
     for e in table:
         print(e)
