@@ -2795,8 +2795,15 @@ struct Renderer::Impl
             // wave-wide stall: bounce 1 -4 % at 256 entries, the deep bounces +0.5 %)
             const uint32_t chunkNow = bounce <= optChunkEarlyBounces ? optChunkEarly : optChunk;
             const bool     quadNow = wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
-            const bool     halfNow = quadNow && ((wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce) ||
-                                                 (wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce));
+            // A camera that stands outside the conservative records' origin bound (4 R + 1 for a root box within +-R: a turntable shot from far away) would
+            // send EVERY primary ray to the scalar traversal (2 x the launch, tools/gpu_far_camera.py): that launch reads the exact quad records, which have
+            // no such bound.  Later bounces start on surfaces, inside the bound.
+            const float    camReach = std::max({std::fabs(params.camera.origin.x), std::fabs(params.camera.origin.y), std::fabs(params.camera.origin.z)}) +
+                                   (std::fabs(params.camera.lensRadius) * 2.0f);
+            const bool     primaryOutside = bounce == 1u && !(camReach <= wide.originBound);
+            const bool     halfOk = wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce && !primaryOutside;
+            const bool     localOk = wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce && !primaryOutside;
+            const bool     halfNow = quadNow && (halfOk || localOk);
             const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (quadNow && !halfNow ? optRefillMinDeepQuad : optRefillMinDeep) : optRefillMin;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
@@ -2811,11 +2818,10 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (bounce <= optPacketBounces)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
-                else if (wide.quadHalf != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
-                         optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce)
+                else if (quadNow && halfOk)
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
-                else if (quadNow && wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce)
+                else if (quadNow && localOk)
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u))

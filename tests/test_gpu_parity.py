@@ -1268,3 +1268,25 @@ def test_clutter_atrium_crops_vs_oracle_and_its_traversal_statistics():
     assert s["closest_rays"] == st.closestRays and s["closest_node_visits"] == st.closestNodeVisits and s["closest_triangle_tests"] == st.closestTriTests
     assert s["shadow_rays"] == st.shadowRays
     assert st.closestNodeVisits / st.closestRays > 70 and st.closestTriTests / st.closestRays > 5.0
+
+
+@pytest.mark.parametrize("distance", [10.0, 1000.0])
+def test_camera_far_outside_the_scene_keeps_primary_rays_off_the_scalar_path(duck_pt, duck_oracle, distance):
+    """A camera beyond the conservative records' origin bound (4 R + 1): its primary launch reads the exact quad records instead of sending every ray to
+    the scalar traversal (round 4: that launch took twice as long); later bounces start on surfaces and keep the 64-byte records.  Bit-identical either way."""
+    a = duck_pt.arrays()
+    lo, hi = np.array(a["bvhNodes"][0]["min"][:3]), np.array(a["bvhNodes"][0]["max"][:3])
+    centre, size = 0.5 * (lo + hi), float(np.max(hi - lo))
+    W, H, spp, bounces = 320, 240, 4, 4
+    eye = centre + np.array([0.6, 0.4, 0.7]) / np.linalg.norm([0.6, 0.4, 0.7]) * distance * size
+    cam = rf.create_camera(eye, centre, 0.0, 1.0, float(2.0 * np.arctan(0.75 / distance)), W / H)
+    r, _ = _renderer(duck_pt, W, H, spp, bounces, cam=cam)
+    r.render(spp)
+    img, _ = r.read_accumulation()
+    s = r.stats()
+    r.close()
+    assert s["scalar_redo_rays"] < 0.01 * s["primary_rays"]
+    ref, st = orc.render(duck_oracle.scene, orc.make_render_params(W, H, orc.create_camera(eye, centre, 0.0, 1.0, float(2.0 * np.arctan(0.75 / distance)), W / H), spp, bounces, 0.25,
+                                                                   orc.aligned_sky_state()), 0, spp)
+    assert s["closest_rays"] == st.closestRays and st.closestRays > W * H * spp      # the duck is in frame: paths bounce
+    assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
