@@ -266,6 +266,10 @@ def build_roofline(s, cs, per_bounce, workload):
                     # instructions per ray are a property of the rays; the share scales with this run's time against the profiled run's
                     share = r["valu_issue_share"] * (r["ms"] / ms) * (rays / max(r["rays"], 1)) if r.get("ms") else r["valu_issue_share"]
                     fr["valu"] = share
+                    if r.get("valu_issue_share_exec_adjusted") and r["valu_issue_share"]:
+                        # informative: the same share with valu_calib's penalty for partly empty EXEC masks at this launch's active-lane fraction (not a ceiling)
+                        row["valu_exec_adjusted"] = round(share * r["valu_issue_share_exec_adjusted"] / r["valu_issue_share"], 3)
+                        row["valu_active_lanes_per_instruction"] = r.get("valu_active_lanes_per_instruction")
                 if "l2_hit_rate" in r:
                     row["l2_hit_rate"] = r["l2_hit_rate"]
                 if "hbm_side_bytes_per_ray" in r:

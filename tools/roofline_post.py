@@ -264,6 +264,12 @@ for kind in ("closest", "shadow"):
                 e["valu_issue_share_4_cycle_model"] = round(c["SQ_INSTS_VALU"] * 4.0 / SIMDS / cyc, 3)     # rounds 2-3: 4 cycles per wave64 instruction per SIMD (uncalibrated: > 1 at bounce 1)
                 if "SQ_THREAD_CYCLES_VALU" in c:
                     e["valu_active_lanes_per_instruction"] = round(c["SQ_THREAD_CYCLES_VALU"] / max(c["SQ_INSTS_VALU"] * 64.0, 1.0), 3)
+                    # informative, NOT the ceiling: valu_calib's step mix issues 1 / half_empty_exec_speedup x slower under a half-empty EXEC mask; scaled linearly
+                    # with the idle-lane share of this launch's instructions, that is how busy the VALU is AT THAT OCCUPANCY (may exceed 1 by the noise of the model)
+                    hs = (valu_issue or {}).get("half_empty_exec_speedup")
+                    if hs:
+                        penalty = 1.0 + min(max(1.0 - e["valu_active_lanes_per_instruction"], 0.0), 0.75) / 0.5 * (1.0 / hs - 1.0)
+                        e["valu_issue_share_exec_adjusted"] = round(e["valu_issue_share"] * penalty, 3)
                 e["salu_instructions_per_ray"] = round(c.get("SQ_INSTS_SALU", 0.0) / rays, 1)
             if "TCC_HIT_sum" in c:
                 e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 3)
