@@ -399,9 +399,11 @@ def main():
                          f"(or no launcher: `python bench.py --gpus N` starts its own ranks)")
     visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if visible < max(world, local_rank + 1):
-        raise SystemExit(f"bench.py: rank {rank} of {world}: needs {world} MI355X GPU(s), one per rank, but {visible} are visible "
-                         f"(no GPU visible: the product has no CPU fallback)" if visible == 0 else
-                         f"bench.py: rank {rank} of {world}: needs {world} MI355X GPU(s), one per rank, but only {visible} are visible")
+        log(f"bench.py: rank {rank} of {world}: needs {world} MI355X GPU(s), one per rank, but " + ("0 are visible (no GPU visible: the product has no CPU fallback)" if visible == 0
+            else f"only {visible} are visible"))
+        if world > 1:
+            time.sleep(1.0)     # the launcher ends the other ranks as soon as one exits: give each the time to say which rank it was
+        sys.exit(1)
     torch.cuda.set_device(local_rank)
     dist = None
     comm = None
