@@ -118,7 +118,8 @@ typedef struct rf_stats
     /* Always counted.  abandoned_rays: traversals that needed more than 96 stack entries and were cut short (the
      * reference's 32-entry stack, ray_intersection.cpp:148,194 / wgsl:327,375, is overrun long before: undefined
      * there); 0 on every scene tested.  scalar_redo_rays: rays the packed traversal handed to the reference-ordered
-     * scalar one (axis-parallel / non-finite rays, more than 12 pending far children) -- results are identical. */
+     * scalar one (axis-parallel / non-finite rays, origins outside the conservative records' bound, more than 48 pending
+     * entries: a full 12-entry LDS stack first evicts its oldest entries to scratch) -- results are identical. */
     uint64_t abandoned_rays, scalar_redo_rays;
 } rf_stats;
 

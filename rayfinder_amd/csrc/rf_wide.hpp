@@ -65,7 +65,8 @@ constexpr int      kWideLdsStack = RF_EXP_STACK; // experiment builds: a shallow
 constexpr int      kWideLdsStack = 12;
 #endif
 #endif
-// kWideLdsStack: (child word, tmin) pairs per lane, all in LDS; deeper rays are redone by the scalar traversal
+// kWideLdsStack: (child word, tmin) pairs per lane in LDS; a full stack evicts its oldest entries to a per-lane scratch array (kTraceWide, rf_renderer.hip);
+// only a ray with more than kWideLdsStack + 36 pending entries is redone by the scalar traversal
 
 struct WideScene
 {
