@@ -549,3 +549,14 @@ def test_wgsl_builtins_are_the_specified_f64_evaluations():
     assert math.isnan(L.orc_d_acos(1.5)) and math.isnan(L.orc_d_acos(float("nan"))) and math.isnan(L.orc_d_sin(float("inf")))
     assert L.orc_d_exp(-800.0) == 0.0 and L.orc_d_exp(800.0) == float("inf") and L.orc_d_exp(0.0) == 1.0
     assert L.orc_d_acos(1.0) == 0.0 and L.orc_d_cos(0.0) == 1.0 and L.orc_d_sin(0.0) == 0.0
+
+
+def test_reference_angle_test_vectors():
+    """src/tests/angle.cpp:8-29 replayed on the oracle's degrees -> radians (the conversion behind the camera's vfov / yaw / pitch and the sky's zenith / azimuth):
+    90 degrees == 0.5 pi, 90 + 90 == pi, within Catch::Approx's default tolerance (100 float epsilons, relative)."""
+    eps = 100.0 * float(np.finfo(np.float32).eps)
+    half_pi, pi = np.float32(0.5) * np.float32(np.pi), np.float32(np.pi)
+    assert abs(float(orc.degrees_to_radians(90.0)) - float(half_pi)) <= eps * float(half_pi)
+    assert abs(float(orc.degrees_to_radians(90.0 + 90.0)) - float(pi)) <= eps * float(pi)
+    # and the round trip the reference checks (asDegrees of what was given in radians)
+    assert abs(float(orc.degrees_to_radians(90.0)) * 180.0 / float(pi) - 90.0) <= eps * 90.0
