@@ -8,7 +8,7 @@ import rayfinder_amd as rf
 from rayfinder_amd import scenes
 spp = int(sys.argv[1]); v = sys.argv[2] if len(sys.argv) > 2 else "-"
 if int(os.environ.get("RF_SCENE_SCALE", 1)) > 1: rf.set_bake_bvh_builder(0)      # GPU builder: same node bytes, 40x faster at that size
-pt, info = scenes.atrium(scale=int(os.environ.get("RF_SCENE_SCALE", 1)))
+pt, info = scenes.atrium(int(os.environ.get("RF_SCENE_SCALE", 1)), os.environ.get("RF_SCENE_DETAIL", "plain"))      # RF_SCENE_DETAIL=clutter: the harder stand-in
 W, H, b = 1920, 1080, int(os.environ.get("RF_B", 8))
 cam = rf.fly_camera(W, H)
 r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, b, rf.make_sky(), 0.25), pt.scene())
