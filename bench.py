@@ -23,10 +23,11 @@ exchange (rf_renderer_gather_frame: grouped ncclSend/ncclRecv + device un-tile),
 
 The JSON line also carries
   roofline     the closest-hit traversal kernel against the HBM roofline, in MEASURED bytes: `traffic` = fabric-side
-               bytes per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE (separate --pmc passes of this command,
-               calibrated on known byte counts in the same access pattern: profiles/pmc_per_ray.json, per ray,
-               scaled by the rays one launch traces), `achieved` = traffic / average launch duration (HIP events on
-               the renderer's stream inside the timed region), frac = achieved / 8 TB/s.  SURVEY.md 8(d)'s
+               bytes per launch from rocprofv3 FETCH_SIZE / WRITE_SIZE -- two child passes of this workload under
+               `rocprofv3 --pmc <one counter> --kernel-trace` after the timed region (`traffic_live`; the committed
+               per-ray profile profiles/pmc_per_ray.json serves when rocprofv3 is missing or --no-live-counters is
+               given), calibrated on known byte counts in the same access pattern --, `achieved` = traffic / average
+               launch duration (HIP events on the renderer's stream inside the timed region), frac = achieved / 8 TB/s.  SURVEY.md 8(d)'s
                algorithmic figure (48 B per reference node visit ...) is reported beside it under `algorithmic`
                and is NOT divided by the HBM peak: the 34 MB of BVH + triangles live in L2 / Infinity Cache, so it is
                a cache rate.  `l1` is the ceiling that binds: vector-L1 line accesses per second against
@@ -202,7 +203,48 @@ def find_pmc_profile(workload):
     return None, None
 
 
-def build_roofline(s, cs, per_bounce, workload):
+def live_traffic(argv_scene, steps, sps, width, height, bounces, timeout_s=240):
+    """`traffic` measured in THIS run: two more passes of the same workload, each as a child process under
+    `rocprofv3 --pmc <one counter> --kernel-trace` (FETCH_SIZE, then WRITE_SIZE: separate passes, counters with --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes), summed over the closest-hit launches of the child's one timed batch.
+    -> dict(fetch_kb, write_kb, launches, closest_rays) or None (rocprofv3 missing, a pass failed or timed out: the committed per-ray profile serves then)."""
+    import csv, glob, shutil, subprocess, tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rocprof is None:
+        log("[bench] live counters: rocprofv3 not found")
+        return None
+    out = {}
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "0", "--repeat", "1", "--spp-per-step", str(sps), "--width", str(width),
+             "--height", str(height), "--bounces", str(bounces), "--no-cpu-baseline", "--no-counting", "--no-live-counters"] + argv_scene
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rf_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "r", "--"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not files or not lines:
+                log(f"[bench] live counters: the {counter} pass failed (rc {p.returncode}): {p.stderr.decode(errors='replace')[-300:]}")
+                return None
+            line = json.loads(lines[-1])
+            total, dispatches = 0.0, set()
+            for r in csv.DictReader(open(files[0])):
+                if "kTraceWide<false" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                    total += float(r["Counter_Value"]); dispatches.add(r.get("Dispatch_Id"))
+            out[counter] = total
+            out["launches"] = len(dispatches)
+            out["closest_rays"] = line["rays"]["closest"]
+        except Exception as e:  # noqa: BLE001  (a profiler that is absent, hangs or changes its output must not take the bench line down)
+            log(f"[bench] live counters: the {counter} pass failed: {e}")
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return dict(fetch_kb=out["FETCH_SIZE"], write_kb=out["WRITE_SIZE"], launches=out["launches"], closest_rays=out["closest_rays"])
+
+
+def build_roofline(s, cs, per_bounce, workload, live=None):
     """The roofline block of the JSON line.
 
     Top level (the driver's contract): the closest-hit traversal kernel against HBM in MEASURED fabric-side bytes --
@@ -218,12 +260,40 @@ def build_roofline(s, cs, per_bounce, workload):
                     avg_launch_ms=round(avg_ms, 4), launches=launches, rays_per_launch=int(rays_per_launch),
                     compulsory_hbm_bytes_per_ray=40)   # 12 B origin + 12 B direction in (packed, at the ray's queue position: no queue read), 16 B hit record out
     pmc, pmc_file = find_pmc_profile(workload)
+    if pmc is None and live and live.get("closest_rays") and avg_ms > 0:
+        # no committed counter profile for this workload (another scene / frame size): the HBM figures come from this run's own counter passes, with the
+        # calibration factors of the access pattern (they belong to the pattern, not to the scene)
+        fc, wc = 0.9304, 1.0
+        try:
+            cal = json.load(open(os.path.join(ROOT, "profiles", "pmc_per_ray.json")))
+            fc, wc = float(cal.get("fetch_calibration") or fc), float(cal.get("write_calibration") or wc)
+        except Exception:  # noqa: BLE001
+            pass
+        per_ray = (live["fetch_kb"] * 1024.0 * fc + live["write_kb"] * 1024.0 * wc) / live["closest_rays"]
+        traffic = per_ray * rays_per_launch
+        achieved = traffic / (avg_ms * 1e-3) / 1e9
+        roofline.update(traffic=int(traffic), achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBPS, 4),
+                        traffic_live=dict(live=True, fetch_size_kb=live["fetch_kb"], write_size_kb=live["write_kb"], launches_profiled=live["launches"],
+                                          closest_rays_profiled=live["closest_rays"], fetch_calibration=fc, write_calibration=wc, hbm_side_bytes_per_ray=round(per_ray, 2),
+                                          note="two child passes of this workload under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace`; no committed per-ray profile for this "
+                                               "workload, so the other ceilings (L1 tag, L1->L2 requests, VALU) are not priced"))
     if pmc is not None and avg_ms > 0:
         sec = avg_ms * 1e-3
         per_ray = float(pmc["hbm_side_bytes_per_ray"])
+        live_info = dict(live=False, note="committed per-ray counter profile x the live ray count (no live counter pass in this run)")
+        if live and live.get("closest_rays"):
+            # FETCH_SIZE / WRITE_SIZE of the closest-hit launches measured in THIS run (two child passes under rocprofv3 --pmc), corrected with the committed
+            # calibration factors of the access pattern (tools/microbench/fetch_calib: random 64-byte gathers 1 / 1.07, coalesced stores 1.0)
+            fc, wc = float(pmc.get("fetch_calibration") or 1.0), float(pmc.get("write_calibration") or 1.0)
+            committed = per_ray
+            per_ray = (live["fetch_kb"] * 1024.0 * fc + live["write_kb"] * 1024.0 * wc) / live["closest_rays"]
+            live_info = dict(live=True, fetch_size_kb=live["fetch_kb"], write_size_kb=live["write_kb"], launches_profiled=live["launches"], closest_rays_profiled=live["closest_rays"],
+                             fetch_calibration=fc, write_calibration=wc, hbm_side_bytes_per_ray_committed_profile=committed,
+                             note="two child passes of this workload under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (one counter per pass), summed over the closest-hit "
+                                  "launches of the child's timed batch, x the calibration factors, / the rays those launches traced")
         traffic = per_ray * rays_per_launch
         achieved = traffic / sec / 1e9
-        roofline.update(traffic=int(traffic), achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBPS, 4),
+        roofline.update(traffic=int(traffic), achieved=round(achieved, 1), frac=round(achieved / HBM_PEAK_GBPS, 4), traffic_live=live_info,
                         traffic_source=dict(file=pmc_file, profile=pmc.get("profile"), hbm_side_bytes_per_ray=per_ray,
                                             fetch_size_bytes_per_ray=pmc.get("fetch_size_bytes_per_ray"), fetch_calibration=pmc.get("fetch_calibration"),
                                             write_size_bytes_per_ray=pmc.get("write_size_bytes_per_ray"), write_calibration=pmc.get("write_calibration"),
@@ -379,6 +449,8 @@ def main():
                     "launcher environment that happens by itself)")
     ap.add_argument("--exchange-at-world-1", action="store_true", help="one rank, but through everything N > 1 ranks go through: torch.distributed (RCCL) "
                     "process group, the product's RCCL communicator, the frame-end exchange (the rank sends its shard to itself) and the device un-tile")
+    ap.add_argument("--no-live-counters", action="store_true", help="skip the two extra passes under `rocprofv3 --pmc` that measure the roofline's `traffic` in this run "
+                    "(the committed per-ray profile x the live ray count is used then)")
     ap.add_argument("--repeat", type=int, default=3, help="timed regions of K steps each; the median one is reported (min / max beside it)")
     args = ap.parse_args()
 
@@ -565,7 +637,14 @@ def main():
         assert cs["closest_rays"] == s["closest_rays"] and cs["shadow_rays"] == s["shadow_rays"], "counting pass traced different rays"
 
     # ---- roofline of the dominant kernel (closest-hit traversal) + one-line entries for the shadow traversal and kShade
-    roofline = build_roofline(s, cs, per_bounce, f"{info['name']} {W}x{H}x{B}")
+    live = None
+    if rank == 0 and world == 1 and not multi and not args.no_live_counters and "ROCPROFILER_REGISTER_ROOT" not in os.environ and "ROCP_TOOL_LIBRARIES" not in os.environ:
+        r.synchronize()
+        scene_args = (["--scene", scene_path] if scene_path else []) + ["--scene-scale", str(max(args.scene_scale, 1)), "--scene-detail", args.scene_detail]
+        t_live = time.time()
+        live = live_traffic(scene_args, K, SPS, W, H, B)
+        log(f"[bench] live counter passes: {'ok' if live else 'unavailable'} in {time.time() - t_live:.1f} s")
+    roofline = build_roofline(s, cs, per_bounce, f"{info['name']} {W}x{H}x{B}", live)
 
     cfg_label = {(1920, 1080, 8): "BASELINE.json config 3" if world == 1 else "BASELINE.json config 4", (3840, 2160, 16): "BASELINE.json config 5",
                  (800, 600, 4): "BASELINE.json config 2"}.get((W, H, B), "custom configuration")

@@ -1011,7 +1011,7 @@ def test_courtyard_asset_bake_render_and_bench(tmp_path):
     assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
     assert s["closest_rays"] == st.closestRays and s["shadow_rays"] == st.shadowRays > 0
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--scene", path.replace(".gltf", ".pt"), "--width", "320", "--height", "192",
-                                   "--steps", "1", "--warmup", "1", "--bounces", "4", "--cpu-seconds", "1"], stderr=subprocess.DEVNULL)
+                                   "--steps", "1", "--warmup", "1", "--bounces", "4", "--cpu-seconds", "1", "--no-live-counters"], stderr=subprocess.DEVNULL)
     line = json.loads(out.decode().strip().splitlines()[-1])
     assert line["value"] > 0 and line["nan_pixels"] == 0 and line["parity_crop"]["verdict"] == "bit-identical"
     assert "courtyard.pt" in line["config"]["workload"]
@@ -1171,10 +1171,14 @@ def test_bench_line_shape_is_the_same_however_the_rank_was_started(tmp_path):
     `--gpus N > 1` does by itself), and one rank through the whole N > 1 plumbing (RCCL process group, the product's
     communicator, frame-end exchange to itself, device un-tile): one JSON line each, same keys, n_gpus = 1, the same rays,
     and the median-of-3 bookkeeping."""
-    plain, _ = _bench_line(["--gpus", "1"], tmp_path)
-    launched, err = _bench_line(["--gpus", "1", "--launch"], tmp_path)
+    plain, _ = _bench_line(["--gpus", "1"], tmp_path)                         # (with the live counter passes: the default)
+    launched, err = _bench_line(["--gpus", "1", "--launch", "--no-live-counters"], tmp_path)
     assert "launching 1 ranks" in err
     looped, _ = _bench_line(["--gpus", "1", "--launch", "--exchange-at-world-1"], tmp_path)
+    # the HBM figures of a workload without a committed counter profile come from this run's own rocprofv3 passes (8 = 2 steps' one batch... bounces = 4 launches)
+    tl = plain["roofline"].get("traffic_live")
+    assert tl and tl["live"] and tl["launches_profiled"] == 4 and plain["roofline"]["traffic"] > 0 and 0 < plain["roofline"]["frac"] < 1
+    assert "traffic_live" not in launched["roofline"] and launched["roofline"]["traffic"] is None
     for line in (plain, launched, looped):
         assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["unit"] == "Mrays/s" and line["nan_pixels"] == 0
         rep = line["repeats"]
@@ -1182,7 +1186,7 @@ def test_bench_line_shape_is_the_same_however_the_rank_was_started(tmp_path):
         assert abs(line["value"] - sorted(rep["value"])[1]) <= 0.11
         assert abs(line["ms_per_step"] * 2 - sorted(rep["timed_region_s"])[1] * 1e3) < 0.11      # (the list is rounded to 0.1 ms)
         assert line["parity_crop"]["verdict"] == "bit-identical"            # the LAST repeat's frame against the oracle
-    assert set(plain) == set(launched) == set(looped)
+    assert set(plain) == set(launched) == set(looped)            # (top-level keys; the roofline block differs by `traffic_live`)
     assert plain["rays"] == launched["rays"] == looped["rays"]
     assert plain["rccl_ranks"] == 0 and plain["exchange"] == "none"
     assert looped["rccl_ranks"] == 1 and "C++ RCCL exchange" in looped["exchange"] and "FALLBACK" not in looped["exchange"]
