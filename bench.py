@@ -203,7 +203,7 @@ def find_pmc_profile(workload):
     return None, None
 
 
-def live_traffic(argv_scene, steps, sps, width, height, bounces, timeout_s=240):
+def live_traffic(argv_scene, steps, sps, width, height, bounces, timeout_s=90):
     """`traffic` measured in THIS run: two more passes of the same workload, each as a child process under
     `rocprofv3 --pmc <one counter> --kernel-trace` (FETCH_SIZE, then WRITE_SIZE: separate passes, counters with --kernel-trace only, as
     MI355X_MICROARCH.md prescribes), summed over the closest-hit launches of the child's one timed batch.
