@@ -721,10 +721,8 @@ constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.
 constexpr uint32_t kFlagUniformTri = 8u;          // the same for the triangles of a leaf phase
 constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path for records that every descending lane shares
 constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
-constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaf in which the wave last found an occluder (see kTraceWide)
-constexpr uint32_t kFlagOccluderUpdate = 32u;     // any-hit: finished rays record what stopped them in the occluder grid (WideScene::occGrid) -- the launch runs behind kShadowHint
-constexpr uint32_t kFlagOccluderLeafFirst = 128u;  // ... and the wave goes straight to the leaf phase after a refill whose hints are all leaves
-constexpr uint32_t kFlagNoRayCount = 64u;         // the launch's rays are counted elsewhere (kShadowHint counted the whole queue)
+constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaf that stopped the last ray from its cell of the scene (see kTraceWide)
+constexpr uint32_t kFlagOccluderWave = 32u;       // ... and, where the cell has no entry, the leaf in which this wave last found an occluder
 
 // Lane state of kTraceWide lives in ONE register, the next thing to visit: a child word of
 // rf_wide.hpp (bit 31 clear: interior record index; set: leaf descriptor) or one of two sentinels
@@ -791,9 +789,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // done after one leaf visit instead of a walk from the root.  The visibility bit is the same by the argument that lets an any-hit ray choose its order
     // (NEAREST_FIRST above): the set of leaves the reference reaches does not depend on the order, a leaf whose own box passes the reference's test is
     // reached by the reference (its ancestors' boxes contain it: rf_wide.hpp), and a leaf visited twice answers twice the same.
-    constexpr bool kOccluderCache = ANY_HIT && !COUNT;
+    constexpr bool kOccluderCache = ANY_HIT && !COUNT && (COMPACT == 4 || COMPACT == 5);
     const bool     occluderCache = kOccluderCache && (flags & kFlagOccluderCache) != 0u;
-    const bool     occluderUpdate = kOccluderCache && (flags & (kFlagOccluderCache | kFlagOccluderUpdate)) != 0u && wide.occGrid != nullptr;
     uint32_t       waveOccluder = 0u; // child word of that leaf (bit 31 set); 0: none yet
     // ... and, where the launch has an occluder grid (WideScene::occGrid), the entry of the cell the ray starts in comes first: what stopped the last ray
     // that left this part of the scene, whichever wave traced it.  A ray that finds its occluder writes it to its cell; a ray that tried a hint and reached
@@ -955,7 +952,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     for (;;)
     {
         if (kPhase) ++wOuter;
-        bool freshHint = false; // kOccluderCache: the lane has just been given a ray that starts at a hint
         // ---- refill idle lanes from the wave's chunk
         const unsigned long long idleMask = __ballot(node == kNodeIdle);
         const uint32_t           idleCount = __popcll(idleMask);
@@ -996,16 +992,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // the ray's state sits at its QUEUE position: the lanes of a refill read consecutive elements (coalesced), and
                 // the closest-hit launch does not read the queue itself at all
                 resultIndex = myPos;
-                bool triedHint = false;
-                if constexpr (kOccluderCache)
-                {
-                    if (wide.rayList != nullptr)
-                    {
-                        const uint32_t e = wide.rayList[myPos]; // behind kShadowHint: the rays it could not answer, by queue position
-                        resultIndex = e & 0x7FFFFFFFu;
-                        triedHint = (e >> 31) != 0u;
-                    }
-                }
                 if (ANY_HIT) slot = loadQ(queue + resultIndex); // the radiance sum and the blue-noise pair are the path's: by slot
                 // the NEE term this ray decides about: read with the rest of the ray (consecutive queue positions: coalesced) instead of
                 // at write-back, where every finishing lane gathered its own 12 bytes and the wave waited for them
@@ -1022,7 +1008,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 pr = packRay(ray);
                 rayDir = dir;
                 const uint32_t rayClass = classifyRay(ray);
-                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u) | (triedHint ? 16u : 0u);
+                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u);
                 rayTMax = tMax;
                 stackSize = spBase;
 #if defined(RF_EXP_PHASE)
@@ -1069,18 +1055,17 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
                 if constexpr (kOccluderCache)
                 {
-                    uint32_t hint = waveOccluder;
+                    uint32_t hint = (flags & kFlagOccluderWave) != 0u ? waveOccluder : 0u;
                     if (occluderCache && wide.occGrid != nullptr)
                     {
                         const uint32_t g = wide.occGrid[occluderCell(o.x, o.y, o.z)];
                         if (g != 0u) hint = g;
                     }
-                    if (occluderCache && hint != 0u && node == 0u) // (a hint is never record 0, the root)
+                    if (occluderCache && hint != 0u && node == 0u)
                     {
                         push(0u, 0.0f); // the root waits (an empty stack: always room)
                         node = hint;
                         negMask |= kNegTriedHint;
-                        freshHint = true;
 #if defined(RF_EXP_PHASE)
                         ++phaseOccTried, phaseFromCache = true;
 #endif
@@ -1094,12 +1079,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             continue;
         }
 
-        // (occluder cache: right after a refill whose rays all start at a LEAF the wave looks at those leaves first -- half of the new rays end
-        // there, and their lanes are refilled again before the survivors join the descent)
-        bool skipDescend = false;
-        if constexpr (kOccluderCache) skipDescend = occluderCache && (flags & kFlagOccluderLeafFirst) != 0u && __ballot(freshHint) != 0ull && __ballot(freshHint && static_cast<int32_t>(node) >= 0) == 0ull;
         // ---- descend: one 64-byte record = both children of an accepted interior node
-        if (!skipDescend) do
+        do
         {
             if (kPhase) ++wDescend;
             if (static_cast<int32_t>(node) >= 0)
@@ -1571,7 +1552,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             bool finished = false;
             if (kPhase) ++wLeafPhase;
             float4 firstA{}, firstB{}, firstC{};
-            uint32_t leafHint = 0u;
             if constexpr (COMPACT == 4 || COMPACT == 5)
             {
                 // The half-precision / local-grid quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
@@ -1579,14 +1559,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // rides in the spare floats of its first triangle record (leafBoxesIntoTriangles): the same 64-byte line.
                 const float4* t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
                 firstA = t0[0], firstB = t0[1], firstC = t0[2];
-                float4 hi;
-                if constexpr (kOccluderCache) hi = t0[3]; // .w: the leaf's occluder-cache hint (leafBoxesIntoTriangles)
-                else
-                {
-                    const v3f h3 = *reinterpret_cast<const v3f*>(t0 + 3);
-                    hi = make_float4(h3.x, h3.y, h3.z, 0.0f);
-                }
-                if constexpr (kOccluderCache) leafHint = __float_as_uint(hi.w);
+                const v3f hi = *reinterpret_cast<const v3f*>(t0 + 3);
                 float     bn, bf;
                 bool      boxNaN;
                 PackedRay exact = pr;
@@ -1661,7 +1634,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             if (finished)
             {
-                if (kOccluderCache) occluderWord = leafHint != 0u ? leafHint : node;
+                if (kOccluderCache) occluderWord = node;
 #if defined(RF_EXP_PHASE)
                 if (ANY_HIT) { ++phaseOccluded; if (phaseFromCache && stackSize == spBase + kSpStep) ++phaseOccHit; }
 #endif
@@ -1709,7 +1682,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             if constexpr (kOccluderCache)
             {
-                if (occluderUpdate && (occluderWord != 0u || (!occluded && (negMask & kNegTriedHint) != 0u)))
+                if (occluderCache && wide.occGrid != nullptr && (occluderWord != 0u || (!occluded && (negMask & kNegTriedHint) != 0u)))
                     wide.occGrid[occluderCell(pr.oXY.x, pr.oXY.y, pr.oZ)] = occluderWord; // (0: the hint failed and the ray reached the sun)
             }
             if (ANY_HIT)
@@ -1783,85 +1756,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         if (lane == 0 && ANY_HIT) atomicAdd(&counters->occluderTried, ot), atomicAdd(&counters->occluderHit, oh), atomicAdd(&counters->occludedRays, oc);
     }
 #endif
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !(flags & kFlagNoRayCount)) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// kShadowHint: the any-hit launch's first look.  A shadow ray is answered as soon as ONE triangle stops it, and where the last ray from
-// this part of the scene was stopped is known: the occluder grid (WideScene::occGrid, filled by the any-hit kTraceWide launches at
-// write-back) names a leaf per cell of the scene's space.  This kernel walks the bounce's shadow queue densely, one ray per lane with no
-// traversal state at all: cell of the origin -> leaf -> the leaf's exact box with the reference's formula (its bounds ride in the leaf's
-// first triangle record: leafBoxesIntoTriangles) -> the leaf's triangles.  A ray stopped there is finished (its NEE term times 0, exactly as
-// the traversal's write-back adds it); every other ray's queue position goes onto a list that the traversal launch works through.
-//
-// Same visibility as the reference's shadowRay (wgsl:321-368): a triangle is tested there iff the traversal reaches its leaf, i.e. iff
-// the boxes of the leaf and of all its ancestors pass `slab test && tmin < rayTMax`; an ancestor's box contains the leaf's, the slab
-// arithmetic is monotone in the planes (rf_wide.hpp), so a ray that passes the leaf's own test passes every ancestor's -- the reference either
-// reaches this leaf and finds the same triangle, or has found another one before: occluded either way.  Rays that are not class A
-// (rf_wide.hpp: an infinite 1/direction component, a non-finite origin), big leaves and cells without a hint are simply passed on.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void kShadowHint(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
-                                                       const uint32_t* queueCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax, uint32_t firstBounce)
-{
-    __shared__ uint32_t sScratch[8];
-    const uint32_t      count = *queueCount;
-    const uint32_t      tiles = (count + kItems * kBlock - 1) / (kItems * kBlock);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
-    {
-        bool     keep[kItems];
-        uint32_t entry[kItems];
-#pragma unroll
-        for (int k = 0; k < kItems; ++k)
-        {
-            const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
-            keep[k] = i < count;
-            entry[k] = i;
-            if (i >= count) continue;
-            const Vec3     o = load3(ps.rayO + i);
-            const uint32_t cx = static_cast<uint32_t>(__float2int_rd((o.x - wide.rootLo.x) * wide.occScale)), cy = static_cast<uint32_t>(__float2int_rd((o.y - wide.rootLo.y) * wide.occScale)),
-                           cz = static_cast<uint32_t>(__float2int_rd((o.z - wide.rootLo.z) * wide.occScale));
-            const uint32_t hint = wide.occGrid[((cx * 73856093u) ^ (cy * 19349663u) ^ (cz * 83492791u)) & wide.occMask];
-            // a leaf word with its triangle count in the word (not the big-leaf table)
-            if ((hint & kWideLeafBit) == 0u || ((hint >> kWideIndexBits) & 7u) == 7u) continue;
-            const Vec3    nz = load3(ps.noiseOut + i);
-            const Vec3    dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
-            const RayPrep ray = prepareRay(o, dir);
-            if (classifyRay(ray) != kRayPlain) continue;
-            entry[k] = i | 0x80000000u; // tried
-            const PackedRay pr = packRay(ray);
-            const uint32_t  first = hint & ((1u << kWideIndexBits) - 1u), n = ((hint >> kWideIndexBits) & 7u) + 1u;
-            const float4*   t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
-            const float4    a = t0[0], b = t0[1], c = t0[2], hi = t0[3];
-            float           bn, bf;
-            bool            boxNaN;
-            slabSingleBounds(pr, a.w, b.w, c.w, hi.x, hi.y, hi.z, bn, bf, boxNaN);
-            if (!(bn <= bf && bf > 0.0f && bn < tMax)) continue; // the reference rejects this leaf
-            bool        occluded = false;
-            TriangleHit th;
-            if (intersectTriangle(o, dir, vec3(a.x, a.y, a.z), vec3(b.x, b.y, b.z), vec3(c.x, c.y, c.z), tMax, th)) occluded = true;
-            for (uint32_t j = 1; j < n && !occluded; ++j)
-            {
-                const v3f q0 = *reinterpret_cast<const v3f*>(t0 + kTriStride * j), q1 = *reinterpret_cast<const v3f*>(t0 + kTriStride * j + 1),
-                          q2 = *reinterpret_cast<const v3f*>(t0 + kTriStride * j + 2);
-                occluded = intersectTriangle(o, dir, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), tMax, th);
-            }
-            if (!occluded) continue;
-            keep[k] = false;
-            // the traversal's write-back for an occluded ray (kTraceWide): radiance += (pending * 0) * invPdf -- a sum that keeps its bits unless the
-            // product is NaN, or the sum is not in memory yet (bounce 1)
-            const Vec3 add = (load3(ps.pending + i) * 0.0f) * __uint_as_float(kSolarInvPdfBits);
-            const bool unchanged = firstBounce == 0u && add.x == 0.0f && add.y == 0.0f && add.z == 0.0f;
-            if (!unchanged)
-            {
-                const uint32_t slot = queue[i];
-                const Vec3     radiance = (firstBounce != 0u ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot)) + add;
-                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            }
-        }
-        blockAppend<kItems>(keep, entry, list, listCount, sScratch);
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
 }
 
 
@@ -2135,16 +2030,13 @@ __global__ void kHitPoints(DeviceScene scene, const float4* hit, P3* rayO, uint3
 
 // Queue occupancy per bounce: Q[b-1] paths enter bounce b (closest-hit rays), Q[b] of them hit
 // something (shadow rays).  Folded into running totals at the end of every batch.
-// `listCounts` / `hintMask`: bounces whose any-hit launch ran behind kShadowHint (bit b) -- Q[b] minus the length of its list is what kShadowHint answered.
-__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals, const uint32_t* listCounts, unsigned long long hintMask)
+__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals)
 {
     const uint32_t b = threadIdx.x;
     if (b >= numBounces) return;
     const uint32_t k = min(b, RenderStats::kMaxBounceStats - 1);
     atomicAdd(&totals[k], static_cast<unsigned long long>(queueCounts[kLineWords * b]));
     atomicAdd(&totals[RenderStats::kMaxBounceStats + k], static_cast<unsigned long long>(queueCounts[kLineWords * (b + 1)]));
-    if ((hintMask >> b) & 1ull)
-        atomicAdd(&totals[2 * RenderStats::kMaxBounceStats + k], static_cast<unsigned long long>(queueCounts[kLineWords * (b + 1)] - listCounts[kLineWords * b]));
 }
 
 // image[lp] += radiance of samples 0..numSamples-1 in order (f32, wgsl:55); image is the compact
@@ -2586,7 +2478,7 @@ struct Renderer::Impl
     DeviceBuffer<float4>    sRad, sHit;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
-    DeviceBuffer<unsigned long long> bounceTotals; // 3 x kMaxBounceStats: closest-hit rays, shadow rays, shadow rays answered by kShadowHint
+    DeviceBuffer<unsigned long long> bounceTotals; // 2 x kMaxBounceStats
 
     // deferred-lighting variant: its own frame counter and buffers (array<array<f32, 3>>)
     uint32_t               deferredFrameCount = 0;
@@ -2600,12 +2492,11 @@ struct Renderer::Impl
     bool     wideUsable = true;
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
-    uint32_t optOccluderLeafFirst = 0, optRefillMinOccluder = 0, optLeafVoteOccluder = 0; // any-hit launches with the occluder cache: leaf phase first after a hinted refill; their own refill threshold / leaf vote (0: the common ones)
-    uint32_t optShadowHintBounces = 0; // the any-hit launches of bounces 1..n run behind kShadowHint (needs the occluder grid)
-    bool     leafBoxesValid = false;   // every leaf's exact box sits in its first triangle record (leafBoxesIntoTriangles)
-    uint32_t optOccluderGridCells = 0; // occluder grid: cells along the longest axis of the root box (0: no grid, the wave's last occluder only)
+    uint32_t optRefillMinOccluder = 24;      // refill threshold of the cached any-hit launches from bounce 2 on (0: the common one)
+    uint32_t optOccluderWaveBounces = 1;     // bounces 1..n: a cell without an entry falls back to the wave's last occluder
+    uint32_t optOccluderGridCells = 1024; // occluder grid: cells along the longest axis of the root box (0: no grid, the wave's last occluder only)
     DeviceBuffer<uint32_t> occluderGrid;
-    uint32_t optOccluderCacheBounces = 0; // the any-hit launches of bounces 1..n try the wave's last occluder leaf first (kFlagOccluderCache)
+    uint32_t optOccluderCacheBounces = 64; // the any-hit launches of bounces 1..n try the wave's last occluder leaf first (kFlagOccluderCache)
     bool     optShadowSignOrder = true; // the half-precision / local-grid shadow launches (VALU bound) visit entries in record order: a cheaper step beats the shorter walks of nearest-first there
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
@@ -2939,8 +2830,7 @@ struct Renderer::Impl
         const uint32_t numBounces = fp.numBounces;
 
         wide.occGrid = nullptr;
-        wide.rayList = nullptr;
-        if ((optOccluderCacheBounces != 0u || optShadowHintBounces != 0u) && optOccluderGridCells != 0u)
+        if (optOccluderCacheBounces != 0u && optOccluderGridCells != 0u)
         {
             constexpr size_t kOccluderGridEntries = size_t{1} << 22; // 16 MB
             if (occluderGrid.count != kOccluderGridEntries)
@@ -2959,12 +2849,10 @@ struct Renderer::Impl
         // device words, one per 64-byte line (they are all hot atomics): [0, B]: queue lengths per
         // bounce; [B+1, 2B]: miss-list length per bounce; then two work cursors per bounce for the traversal launches
         constexpr uint32_t kLine = kLineWords;
-        const uint32_t words = kLine * (2 * numBounces + 1) + kLine * kShards * 2 * numBounces + kLine * numBounces;
+        const uint32_t words = kLine * (2 * numBounces + 1) + kLine * kShards * 2 * numBounces;
         if (queueCounts.count < words) queueCounts.alloc(words);
         uint32_t* const missCounts = queueCounts.ptr + kLine * (numBounces + 1);
         uint32_t* const cursors = queueCounts.ptr + kLine * (2 * numBounces + 1);
-        uint32_t* const listCounts = cursors + kLine * kShards * 2 * numBounces; // lengths of the lists kShadowHint leaves to the any-hit launches, per bounce
-        unsigned long long hintMask = 0ull;
         const uint32_t  itemBlocks = static_cast<uint32_t>((paths + kBlock * kItems - 1) / (kBlock * kItems));
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
 
@@ -3043,23 +2931,15 @@ struct Renderer::Impl
                 // the paths that left the scene at this bounce, while its direction / throughput arrays and queue are intact
                 hipLaunchKernelGGL(kSky, dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, qIn, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
             });
-            // kShadowHint first (see there): the rays the occluder grid answers at once never enter the traversal; the rest are traced from a list
-            // (the bounce's input queue is free by now: kShade and kSky have consumed it)
-            const bool      hintPass = traversalVariant != 0 && !counting && bounce > optPacketBounces && bounce <= optShadowHintBounces && bounce <= 64u && wide.occGrid != nullptr && leafBoxesValid;
-            uint32_t* const listCount = listCounts + kLine * (bounce - 1);
-            uint32_t* const countShadow = hintPass ? listCount : countOut;
-            if (hintPass) hintMask |= 1ull << (bounce - 1);
-            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (hintPass ? (kFlagOccluderUpdate | kFlagNoRayCount) : (bounce <= optOccluderCacheBounces ? (kFlagOccluderCache | (optOccluderLeafFirst ? kFlagOccluderLeafFirst : 0u)) : 0u));
-            const bool     cachedShadow = !hintPass && bounce <= optOccluderCacheBounces;
-            const uint32_t refillShadow = cachedShadow && optRefillMinOccluder != 0u ? optRefillMinOccluder : optRefillMin, leafVoteShadow = cachedShadow && optLeafVoteOccluder != 0u ? optLeafVoteOccluder : optLeafVote;
+            // occluder cache (kTraceWide, kFlagOccluderCache): the conservative-record any-hit launches of bounces 1..optOccluderCacheBounces; their rays are
+            // short (a third of the steps), so the deep launches refill earlier
+            const bool     quadShadowNow = optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
+            const bool     conservativeShadowNow = quadShadowNow && ((wide.quadLocal != nullptr && optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce) ||
+                                                                      (wide.quadHalf != nullptr && optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce));
+            const bool     cachedShadow = traversalVariant != 0 && !counting && bounce > optPacketBounces && shadowNearestFirst && conservativeShadowNow && bounce <= optOccluderCacheBounces;
+            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (cachedShadow ? kFlagOccluderCache : 0u) | (cachedShadow && bounce <= optOccluderWaveBounces ? kFlagOccluderWave : 0u);
+            const uint32_t refillShadow = cachedShadow && bounce >= 2 && optRefillMinOccluder != 0u ? optRefillMinOccluder : optRefillMin;
             launchTimed(3, [&] {
-                WideScene wide = this->wide; // (the launches below name `wide`)
-                if (hintPass)
-                {
-                    const dim3 hintGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
-                    hipLaunchKernelGGL(kShadowHint, hintGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, qIn, listCount, counters.ptr, kTMax, bounce == 1 ? 1u : 0u);
-                    wide.rayList = qIn;
-                }
                 if (traversalVariant == 0)
                 {
                     if (counting)
@@ -3073,54 +2953,54 @@ struct Renderer::Impl
                 else if (shadowNearestFirst)
                 {
                     if (counting)
-                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.quadLocal != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                              optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce)
                     {
                         if (optShadowSignOrder)
-                            hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                            hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
-                            hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                            hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quadHalf != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                              optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce)
                     {
                         if (optShadowSignOrder)
-                            hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                            hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
-                            hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                            hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce)
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce)
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else
-                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                 }
                 else if (counting)
-                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow, cursorShadow,
-                                       counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
+                                       counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
                 else
-                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow, cursorShadow,
-                                       counters.ptr, refillShadow, leafVoteShadow, chunkNow, kTMax, shadowFlags);
+                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
+                                       counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
             }, bounce - 1);
             std::swap(qIn, qOut);
             std::swap(ps.rayD, ps.rayDOut);
             std::swap(ps.thr, ps.thrOut);
             std::swap(ps.noise, ps.noiseOut);
         }
-        hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr, listCounts, hintMask);
+        hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr);
         launchTimed(4, [&] {
             if (fp.slotGroupShift == 0u && numSamples > 4u && numSamples <= kAccMaxSamples && optAccumulateRuns)
                 hipLaunchKernelGGL(kAccumulateRuns, dim3((fp.pixelsPadded + kAccPixels - 1) / kAccPixels), dim3(64), kAccPixels * 3u * (numSamples + 1u) * sizeof(float), stream, fp,
@@ -3235,10 +3115,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             padded[kTriStride * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
         }
         // ... and the exact box of every leaf in the spare floats of its first triangle (read by the half-precision quad kernels)
-        uint32_t hintLevels = 0; // experiments: RF_OCCLUDER_HINT_LEVELS
-        if (const char* v = std::getenv("RF_OCCLUDER_HINT_LEVELS")) hintLevels = static_cast<uint32_t>(std::max(std::atoi(v), 0));
-        m.leafBoxesValid = leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n, hintLevels);
-        if (!m.leafBoxesValid)
+        if (!leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n))
         {
             // leaves that share a first triangle (hand-made tree): one slot cannot hold two exact boxes, so the layouts that cull a leaf by
             // the box in that slot stay off and the exact records (which carry every box themselves) are used
@@ -3313,7 +3190,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     DeviceCounters zero{};
     m.counters.upload(&zero, 1);
     {
-        const std::vector<unsigned long long> z(3 * RenderStats::kMaxBounceStats, 0ull);
+        const std::vector<unsigned long long> z(2 * RenderStats::kMaxBounceStats, 0ull);
         m.bounceTotals.upload(z.data(), z.size());
     }
     {
@@ -3675,10 +3552,8 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;
-    else if (name == "occluder_leaf_first") mImpl->optOccluderLeafFirst = value != 0;
+    else if (name == "occluder_wave_bounces") mImpl->optOccluderWaveBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "refill_min_occluder") mImpl->optRefillMinOccluder = static_cast<uint32_t>(std::max<int64_t>(value, 0));
-    else if (name == "leaf_vote_occluder") mImpl->optLeafVoteOccluder = static_cast<uint32_t>(std::max<int64_t>(value, 0));
-    else if (name == "shadow_hint_bounces") mImpl->optShadowHintBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "occluder_grid_cells") mImpl->optOccluderGridCells = static_cast<uint32_t>(std::clamp<int64_t>(value, 0, 1 << 16));
     else if (name == "occluder_cache_bounces") mImpl->optOccluderCacheBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "reserve_samples")
@@ -3717,7 +3592,7 @@ void Renderer::resetStats()
     m.collectTimings();
     DeviceCounters zero{};
     RF_HIP(hipMemcpy(m.counters.ptr, &zero, sizeof zero, hipMemcpyHostToDevice));
-    RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 3 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
+    RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 2 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
     m.hostStats = RenderStats{};
     m.primaryRaysHost = 0;
 }
@@ -3775,13 +3650,12 @@ RenderStats Renderer::stats()
                          steps / (64.0 * c.descendTrips[k]), tris / (64.0 * c.leafTrips[k]));
         }
     }
-    unsigned long long totals[3 * RenderStats::kMaxBounceStats];
+    unsigned long long totals[2 * RenderStats::kMaxBounceStats];
     RF_HIP(hipMemcpy(totals, m.bounceTotals.ptr, sizeof totals, hipMemcpyDeviceToHost));
     for (uint32_t b = 0; b < RenderStats::kMaxBounceStats; ++b)
     {
         s.closestRaysByBounce[b] = totals[b];
         s.shadowRaysByBounce[b] = totals[RenderStats::kMaxBounceStats + b];
-        s.shadowRaysHintAnswered += totals[2 * RenderStats::kMaxBounceStats + b];
     }
     return s;
 }

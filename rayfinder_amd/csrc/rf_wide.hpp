@@ -83,14 +83,11 @@ struct WideScene
     float4        rootHi;
     uint32_t      rootLeaf;  // child word of the root if the whole tree is one leaf, else kWideNone
     uint32_t      numRecords;
-    // occluder grid of the any-hit launches (kTraceWide, kFlagOccluderCache): a hash table over cells of the scene's space -- entry = where the last shadow
-    // ray that left that cell found its occluder (a child word / record index, 0: nothing known).  Hints only: any value a kernel wrote is a valid start.
+    // occluder grid of the any-hit launches (kTraceWide, kFlagOccluderCache): a hash table over cells of the scene's space -- entry = the leaf (child word) in
+    // which the last shadow ray that left that cell found its occluder, 0: nothing known.  Hints only: any leaf word a kernel wrote is a valid first visit.
     uint32_t*     occGrid;   // or nullptr
     float         occScale;  // cells per unit length
     uint32_t      occMask;   // entries - 1 (a power of two)
-    // any-hit launches behind kShadowHint: the queue POSITIONS of the rays still to trace (bit 31: the ray has already tried a hint), or nullptr = every
-    // position of the queue; the launch's count argument is then the length of this list
-    const uint32_t* rayList;
 };
 
 struct WideBuild
@@ -188,25 +185,8 @@ inline uint16_t halfDirected(float v, bool down, bool& ok)
 // Returns false when two leaves claim the same first-triangle slot (a hand-made tree: validateScene only checks that leaf ranges lie inside the
 // triangle array, not that they are disjoint): the later leaf's box would overwrite the earlier one's, the half-precision / local-grid kernels
 // would cull with a box that is not the leaf's, and the image would depend on the record layout.  The caller keeps those layouts off then.
-inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles, uint32_t hintLevels = 0)
+inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles)
 {
-    // record[3].w: the occluder-cache hint of the leaf (kTraceWide, any-hit): the QUAD record index (numbering of buildWide: the interior nodes at even
-    // depth, in node order) of the record `hintLevels` quad levels above the leaf -- 1: the record that has the leaf among its entries -- where a wave that
-    // found an occluder in this leaf lets its next rays START (root on the stack); 0 = "the leaf's own child word" (hintLevels 0, or the record would be the
-    // root, where a ray starts anyway).  Any record is a valid place to start: the hint only decides what is looked at first.
-    std::vector<uint32_t> parent, quadIndex, depth;
-    if (hintLevels != 0)
-    {
-        parent.assign(count, 0u), quadIndex.assign(count, 0u), depth.assign(count, 0u);
-        uint32_t numQuad = 0;
-        for (size_t i = 0; i < count; ++i) // (a node's parent precedes it: depth-first order)
-        {
-            if (nodes[i].triangleCount != 0) continue;
-            if ((depth[i] & 1u) == 0u) quadIndex[i] = numQuad++;
-            for (const size_t c : {i + 1, static_cast<size_t>(nodes[i].secondChildOffset)})
-                if (c < count && c > i) parent[c] = static_cast<uint32_t>(i), depth[c] = depth[i] + 1u;
-        }
-    }
     std::vector<bool> claimed(numTriangles, false);
     bool              distinct = true;
     for (size_t i = 0; i < count; ++i)
@@ -216,16 +196,8 @@ inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* t
         if (claimed[n.trianglesOffset]) distinct = false;
         claimed[n.trianglesOffset] = true;
         float4* t = triangles + 4 * static_cast<size_t>(n.trianglesOffset);
-        uint32_t hint = 0u; // 0: "use the leaf's own word"
-        if (hintLevels != 0 && i != 0)
-        {
-            size_t a = parent[i];
-            if (depth[a] & 1u) a = parent[a]; // the record that holds the leaf as an entry
-            for (uint32_t l = 1; l < hintLevels && a != 0; ++l) a = parent[parent[a]];
-            if (a != 0 && quadIndex[a] < (1u << kWideIndexBits)) hint = quadIndex[a];
-        }
         t[0].w = n.aabb.min.x, t[1].w = n.aabb.min.y, t[2].w = n.aabb.min.z;
-        t[3] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, bitsFloat(hint));
+        t[3] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, 0.0f);
     }
     return distinct;
 }
