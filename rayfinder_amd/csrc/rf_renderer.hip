@@ -721,8 +721,33 @@ constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.
 constexpr uint32_t kFlagUniformTri = 8u;          // the same for the triangles of a leaf phase
 constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path for records that every descending lane shares
 constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
-constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaf that stopped the last ray from its cell of the scene (see kTraceWide)
-constexpr uint32_t kFlagOccluderWave = 32u;       // ... and, where the cell has no entry, the leaf in which this wave last found an occluder
+constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaves that stopped the last rays from its cell of the scene (see kTraceWide)
+#if defined(RF_EXP_OCC_SLOTS)
+constexpr int kOccSlots = RF_EXP_OCC_SLOTS;
+#else
+constexpr int kOccSlots = 4; // entries per cell of the occluder grid (1, 2 or 4: shadow launches of the atrium -19 / -29 / -34 %, profiles/r04_occluder)
+#endif
+static_assert(kOccSlots == 1 || kOccSlots == 2 || kOccSlots == 4, "one aligned load per cell");
+__device__ __forceinline__ void loadOccluderCell(const uint32_t* cell, uint32_t (&e)[kOccSlots])
+{
+    if constexpr (kOccSlots == 1) e[0] = *cell;
+    else if constexpr (kOccSlots == 2)
+    {
+        const uint2 v = *reinterpret_cast<const uint2*>(cell);
+        e[0] = v.x, e[1] = v.y;
+    }
+    else
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(cell);
+        e[0] = v.x, e[1] = v.y, e[kOccSlots > 2 ? 2 : 0] = v.z, e[kOccSlots > 3 ? 3 : 0] = v.w;
+    }
+}
+__device__ __forceinline__ void storeOccluderCell(uint32_t* cell, const uint32_t (&e)[kOccSlots])
+{
+    if constexpr (kOccSlots == 1) *cell = e[0];
+    else if constexpr (kOccSlots == 2) *reinterpret_cast<uint2*>(cell) = make_uint2(e[0], e[1]);
+    else *reinterpret_cast<uint4*>(cell) = make_uint4(e[0], e[1], e[kOccSlots > 2 ? 2 : 0], e[kOccSlots > 3 ? 3 : 0]);
+}
 
 // Lane state of kTraceWide lives in ONE register, the next thing to visit: a child word of
 // rf_wide.hpp (bit 31 clear: interior record index; set: leaf descriptor) or one of two sentinels
@@ -783,18 +808,23 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     const bool       shadowDirFromStream = flags & kFlagShadowDirFromStream;
     const bool       firstBounce = flags & kFlagFirstBounce;
     const bool       uniformFetch = flags & kFlagUniformFetch, uniformTri = flags & kFlagUniformTri;
-    // Occluder cache (any-hit launches).  The shadow rays a wave picks up one after the other leave neighbouring surface points towards the same 0.27-degree
-    // sun disc, so what blocked the last ray very likely blocks the next one.  A new ray therefore visits FIRST the leaf in which a lane of this wave last
-    // found an occluder (a wave-uniform child word), with the root waiting on its stack: if that leaf's exact box and one of its triangles stop the ray, it is
-    // done after one leaf visit instead of a walk from the root.  The visibility bit is the same by the argument that lets an any-hit ray choose its order
-    // (NEAREST_FIRST above): the set of leaves the reference reaches does not depend on the order, a leaf whose own box passes the reference's test is
-    // reached by the reference (its ancestors' boxes contain it: rf_wide.hpp), and a leaf visited twice answers twice the same.
-    constexpr bool kOccluderCache = ANY_HIT && !COUNT && (COMPACT == 4 || COMPACT == 5);
-    const bool     occluderCache = kOccluderCache && (flags & kFlagOccluderCache) != 0u;
-    uint32_t       waveOccluder = 0u; // child word of that leaf (bit 31 set); 0: none yet
-    // ... and, where the launch has an occluder grid (WideScene::occGrid), the entry of the cell the ray starts in comes first: what stopped the last ray
-    // that left this part of the scene, whichever wave traced it.  A ray that finds its occluder writes it to its cell; a ray that tried a hint and reached
-    // the sun clears the cell (lit and penumbra regions stop paying for stale hints).  Racing writes are harmless: every value written is a valid start.
+    // Occluder cache (any-hit launches on the conservative records).  A shadow ray is answered as soon as ONE triangle stops it, and the rays that leave the
+    // same few centimetres of the scene towards the 0.27-degree sun disc are stopped by the same few triangles.  The launch therefore keeps a hash grid over
+    // cells of the scene's space (WideScene::occGrid; kOccSlots leaf words per cell, most recent first): a finished ray records the leaf in which it found its
+    // occluder, and a NEW ray visits the leaves of its origin's cell FIRST, with the root waiting below them on its stack -- if one of them stops it, it is done
+    // after a leaf visit or two instead of a walk from the root (atrium: 11 -> 3.5 steps per shadow ray).  A ray that tried its cell's leaves and reached the sun
+    // drops the cell's first entry, so lit regions stop paying for stale entries.
+    // The visibility bit is the reference's by the argument that lets an any-hit ray choose its visit order (NEAREST_FIRST above): a leaf visit here applies the
+    // leaf's EXACT box with the reference's formula before any triangle is tested (the COMPACT 4 / 5 leaf phase below); a leaf whose own box passes is reached by
+    // the reference too, because its ancestors' boxes contain it and the slab arithmetic is monotone in the planes (rf_wide.hpp) -- so the reference either tests
+    // the same triangle or has found another one before: occluded either way; and a leaf visited a second time in the regular walk answers as it did the first
+    // time.  Entries are hints only: any leaf word of this scene is a valid first visit, so racing writers, hash collisions and entries left from another sun
+    // position cost time, never the result (tests: test_occluder_cache_is_invisible).
+    constexpr bool kOccluderCache = ANY_HIT && !COUNT && (COMPACT == 3 || COMPACT == 4 || COMPACT == 5);
+    // (the exact quad records test a leaf's box at its parent's step, not at the leaf: a launch of theirs that uses the cache applies the box at the leaf too, as
+    // the conservative layouts always do -- a second, identical test for the leaves reached by the walk, THE test for the ones visited first)
+    const bool     leafBoxAtLeaf = COMPACT == 4 || COMPACT == 5 || (COMPACT == 3 && kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr);
+    const bool     occluderCache = kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr;
     const auto occluderCell = [&](float ox, float oy, float oz) -> uint32_t {
         const uint32_t cx = static_cast<uint32_t>(__float2int_rd((ox - wide.rootLo.x) * wide.occScale)), cy = static_cast<uint32_t>(__float2int_rd((oy - wide.rootLo.y) * wide.occScale)),
                        cz = static_cast<uint32_t>(__float2int_rd((oz - wide.rootLo.z) * wide.occScale));
@@ -1055,15 +1085,25 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
                 if constexpr (kOccluderCache)
                 {
-                    uint32_t hint = (flags & kFlagOccluderWave) != 0u ? waveOccluder : 0u;
-                    if (occluderCache && wide.occGrid != nullptr)
+                    uint32_t hint = 0u;
+                    uint32_t later[kOccSlots > 1 ? kOccSlots - 1 : 1] = {};
+                    if (occluderCache)
                     {
-                        const uint32_t g = wide.occGrid[occluderCell(o.x, o.y, o.z)];
-                        if (g != 0u) hint = g;
+                        uint32_t e[kOccSlots];
+                        loadOccluderCell(wide.occGrid + kOccSlots * static_cast<size_t>(occluderCell(o.x, o.y, o.z)), e);
+                        if (e[0] != 0u)
+                        {
+                            hint = e[0];
+#pragma unroll
+                            for (int k = 1; k < kOccSlots; ++k) later[k - 1] = e[k];
+                        }
                     }
                     if (occluderCache && hint != 0u && node == 0u)
                     {
-                        push(0u, 0.0f); // the root waits (an empty stack: always room)
+                        push(0u, 0.0f); // the root waits (an empty stack: always room for it and the cell's entries)
+#pragma unroll
+                        for (int k = kOccSlots - 1; k >= 1; --k)
+                            if (later[k - 1] != 0u) push(later[k - 1], 0.0f);
                         node = hint;
                         negMask |= kNegTriedHint;
 #if defined(RF_EXP_PHASE)
@@ -1552,7 +1592,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             bool finished = false;
             if (kPhase) ++wLeafPhase;
             float4 firstA{}, firstB{}, firstC{};
-            if constexpr (COMPACT == 4 || COMPACT == 5)
+            if (leafBoxAtLeaf)
             {
                 // The half-precision / local-grid quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
                 // test its box, exactly, with its own formula, against the rayTMax of this moment -- happens here.  The leaf's box
@@ -1563,7 +1603,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 float     bn, bf;
                 bool      boxNaN;
                 PackedRay exact = pr;
-                if (__builtin_expect((negMask & 8u) != 0u, 0))
+                if ((COMPACT == 4 || COMPACT == 5) && __builtin_expect((negMask & 8u) != 0u, 0))
                 {
                     // class B: the infinite components of 1/d that the conservative tests replaced by +-1e30 (refill) are infinite again
                     const float inf = __uint_as_float(0x7F800000u);
@@ -1589,7 +1629,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 Vec3           p0, p1, p2;
                 // the same triangle in every lane of this leaf phase (one pixel's samples reaching the same leaf): scalar cache
                 const uint32_t uTri = __builtin_amdgcn_readfirstlane(tri);
-                if ((COMPACT == 4 || COMPACT == 5) && i == 0u)
+                if (leafBoxAtLeaf && i == 0u)
                 {
                     p0 = vec3(firstA.x, firstA.y, firstA.z), p1 = vec3(firstB.x, firstB.y, firstB.z), p2 = vec3(firstC.x, firstC.y, firstC.z);
                 }
@@ -1642,12 +1682,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             else popNext();
         }
-        if constexpr (kOccluderCache)
-        {
-            // the leaf of (one of) the lanes that just found an occluder becomes the wave's first candidate
-            const unsigned long long found = __ballot(occluderWord != 0u);
-            if (occluderCache && found != 0ull) waveOccluder = __builtin_amdgcn_readlane(occluderWord, __builtin_ctzll(found));
-        }
 
         // ---- write back finished rays
         if (kSpill && node == kNodeDone && !needScalar && !occluded)
@@ -1682,8 +1716,31 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             if constexpr (kOccluderCache)
             {
-                if (occluderCache && wide.occGrid != nullptr && (occluderWord != 0u || (!occluded && (negMask & kNegTriedHint) != 0u)))
-                    wide.occGrid[occluderCell(pr.oXY.x, pr.oXY.y, pr.oZ)] = occluderWord; // (0: the hint failed and the ray reached the sun)
+                // kOccSlots entries per cell, most recent first: a new occluder goes to the front (the others move back, the last one drops out); a ray
+                // that tried the cell's entries and reached the sun drops the first one
+                if (occluderCache && (occluderWord != 0u || (!occluded && (negMask & kNegTriedHint) != 0u)))
+                {
+                    uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(occluderCell(pr.oXY.x, pr.oXY.y, pr.oZ));
+                    uint32_t        old[kOccSlots], now[kOccSlots];
+                    loadOccluderCell(cell, old);
+                    if (occluderWord == 0u)
+                    {
+#pragma unroll
+                        for (int k = 0; k < kOccSlots; ++k) now[k] = k + 1 < kOccSlots ? old[k + 1 < kOccSlots ? k + 1 : k] : 0u;
+                        storeOccluderCell(cell, now);
+                    }
+                    else if (occluderWord != old[0])
+                    {
+                        int at = kOccSlots - 1; // where the word sits already (else: the last place is given up)
+#pragma unroll
+                        for (int k = kOccSlots - 2; k >= 1; --k)
+                            if (old[k] == occluderWord) at = k;
+                        now[0] = occluderWord;
+#pragma unroll
+                        for (int k = 1; k < kOccSlots; ++k) now[k] = k <= at ? old[k - 1] : old[k];
+                        storeOccluderCell(cell, now);
+                    }
+                }
             }
             if (ANY_HIT)
             {
@@ -2492,8 +2549,8 @@ struct Renderer::Impl
     bool     wideUsable = true;
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
-    uint32_t optRefillMinOccluder = 24;      // refill threshold of the cached any-hit launches from bounce 2 on (0: the common one)
-    uint32_t optOccluderWaveBounces = 1;     // bounces 1..n: a cell without an entry falls back to the wave's last occluder
+    bool     leafBoxesValid = false;   // every leaf's exact box sits in its first triangle record (leafBoxesIntoTriangles)
+    uint32_t optOccluderGridLog2Cells = 22; // table size: 2^n cells of kOccSlots words
     uint32_t optOccluderGridCells = 1024; // occluder grid: cells along the longest axis of the root box (0: no grid, the wave's last occluder only)
     DeviceBuffer<uint32_t> occluderGrid;
     uint32_t optOccluderCacheBounces = 64; // the any-hit launches of bounces 1..n try the wave's last occluder leaf first (kFlagOccluderCache)
@@ -2832,7 +2889,7 @@ struct Renderer::Impl
         wide.occGrid = nullptr;
         if (optOccluderCacheBounces != 0u && optOccluderGridCells != 0u)
         {
-            constexpr size_t kOccluderGridEntries = size_t{1} << 22; // 16 MB
+            const size_t kOccluderGridEntries = (size_t{1} << optOccluderGridLog2Cells) * kOccSlots;
             if (occluderGrid.count != kOccluderGridEntries)
             {
                 occluderGrid.alloc(kOccluderGridEntries);
@@ -2841,7 +2898,7 @@ struct Renderer::Impl
             const float extent = std::max({wide.rootHi.x - wide.rootLo.x, wide.rootHi.y - wide.rootLo.y, wide.rootHi.z - wide.rootLo.z, 1e-20f});
             wide.occGrid = occluderGrid.ptr;
             wide.occScale = static_cast<float>(optOccluderGridCells) / extent;
-            wide.occMask = static_cast<uint32_t>(kOccluderGridEntries - 1);
+            wide.occMask = static_cast<uint32_t>(kOccluderGridEntries / kOccSlots - 1);
         }
         BatchTiming bt{getEvent(), getEvent(), numSamples};
         RF_HIP(hipEventRecord(bt.start, stream));
@@ -2936,9 +2993,9 @@ struct Renderer::Impl
             const bool     quadShadowNow = optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
             const bool     conservativeShadowNow = quadShadowNow && ((wide.quadLocal != nullptr && optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce) ||
                                                                       (wide.quadHalf != nullptr && optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce));
-            const bool     cachedShadow = traversalVariant != 0 && !counting && bounce > optPacketBounces && shadowNearestFirst && conservativeShadowNow && bounce <= optOccluderCacheBounces;
-            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (cachedShadow ? kFlagOccluderCache : 0u) | (cachedShadow && bounce <= optOccluderWaveBounces ? kFlagOccluderWave : 0u);
-            const uint32_t refillShadow = cachedShadow && bounce >= 2 && optRefillMinOccluder != 0u ? optRefillMinOccluder : optRefillMin;
+            const bool     exactQuadShadowNow = quadShadowNow && !conservativeShadowNow && wide.quad != nullptr && leafBoxesValid; // (its leaf visits then apply the box in the leaf's triangle record)
+            const bool     cachedShadow = traversalVariant != 0 && !counting && bounce > optPacketBounces && shadowNearestFirst && (conservativeShadowNow || exactQuadShadowNow) && bounce <= optOccluderCacheBounces;
+            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (cachedShadow ? kFlagOccluderCache : 0u);
             launchTimed(3, [&] {
                 if (traversalVariant == 0)
                 {
@@ -2954,46 +3011,46 @@ struct Renderer::Impl
                 {
                     if (counting)
                         hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.quadLocal != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                              optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce)
                     {
                         if (optShadowSignOrder)
                             hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
                             hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quadHalf != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                              optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce)
                     {
                         if (optShadowSignOrder)
                             hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
                             hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                               cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
                         hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce)
                         hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce)
                         hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else
                         hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
-                                           cursorShadow, counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                 }
                 else if (counting)
                     hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                 else
                     hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
-                                       counters.ptr, refillShadow, optLeafVote, chunkNow, kTMax, shadowFlags);
+                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
             }, bounce - 1);
             std::swap(qIn, qOut);
             std::swap(ps.rayD, ps.rayDOut);
@@ -3115,7 +3172,8 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             padded[kTriStride * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
         }
         // ... and the exact box of every leaf in the spare floats of its first triangle (read by the half-precision quad kernels)
-        if (!leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n))
+        m.leafBoxesValid = leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n);
+        if (!m.leafBoxesValid)
         {
             // leaves that share a first triangle (hand-made tree): one slot cannot hold two exact boxes, so the layouts that cull a leaf by
             // the box in that slot stay off and the exact records (which carry every box themselves) are used
@@ -3552,8 +3610,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;
-    else if (name == "occluder_wave_bounces") mImpl->optOccluderWaveBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
-    else if (name == "refill_min_occluder") mImpl->optRefillMinOccluder = static_cast<uint32_t>(std::max<int64_t>(value, 0));
+    else if (name == "occluder_grid_log2_cells") mImpl->optOccluderGridLog2Cells = static_cast<uint32_t>(std::clamp<int64_t>(value, 4, 26));
     else if (name == "occluder_grid_cells") mImpl->optOccluderGridCells = static_cast<uint32_t>(std::clamp<int64_t>(value, 0, 1 << 16));
     else if (name == "occluder_cache_bounces") mImpl->optOccluderCacheBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "reserve_samples")

@@ -428,6 +428,37 @@ def test_atrium_crops_vs_oracle_1080p_8_bounces(atrium):
     assert s["closest_node_visits"] > 30 * s["closest_rays"]
 
 
+def test_occluder_cache_is_invisible(atrium, duck_pt):
+    """The any-hit launches' occluder cache (kTraceWide, kFlagOccluderCache: a shadow ray first visits the leaf that stopped the last ray from its
+    cell of the scene) only changes the ORDER in which an any-hit ray looks at leaves.  Same image bit for bit with the cache off, cold, warm,
+    stale (the sun has moved since the grid was filled: every entry points at the wrong occluder), with cells so coarse that whole rooms share one, and
+    with a table so small that every entry is fought over."""
+    for pt, (W, H, spp, bounces) in ((atrium, (480, 270, 4, 6)), (duck_pt, (200, 150, 4, 4))):
+        skies = [rf.make_sky(), rf.make_sky(3.0, (0.3, 0.3, 0.3), 60.0, 140.0), rf.make_sky()]
+        off, _ = _renderer(pt, W, H, spp, bounces, sky=skies[0])
+        off.set_option("occluder_cache_bounces", 0)
+        want = []
+        for sky in skies:
+            off.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, sky, 0.25))
+            off.render(spp)
+            want.append(off.read_accumulation()[0])
+        off.close()
+        assert not np.array_equal(bits(want[0]), bits(want[1]))          # the sun really moved
+        assert np.array_equal(bits(want[0]), bits(want[2]))
+        for cells, log2_table in ((1024, 22), (8, 22), (4096, 6)):           # default; whole rooms in one cell; a 64-cell table (every entry fought over)
+            r, _ = _renderer(pt, W, H, spp, bounces, sky=skies[0])
+            r.set_option("occluder_grid_cells", cells)
+            r.set_option("occluder_grid_log2_cells", log2_table)
+            for sky, ref in zip(skies, want):                             # cold, then stale, then stale the other way round
+                r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, sky, 0.25))
+                r.render(spp)
+                assert np.array_equal(bits(r.read_accumulation()[0]), bits(ref)), (cells, log2_table)
+            r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, skies[2], 0.5))   # warm
+            r.render(spp)
+            assert np.array_equal(bits(r.read_accumulation()[0]), bits(want[2])), (cells, log2_table, "warm")
+            r.close()
+
+
 def test_atrium_config5_4k_16_bounces_crops_and_queue_occupancy(atrium):
     """BASELINE.json config 5 geometry (3840x2160, 16 bounces; NEE is always on): oracle parity on crops and
     the per-bounce queue statistics (queue occupancy per bounce)."""
@@ -783,7 +814,15 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
     if seed % 3 == 2:                                           # ... on the 32-byte records
         r.set_option("hot_from_bounce", 1)
         r.set_option("hot_shadow_from_bounce", 1)
-    r.render(spp)
+    if seed % 6 in (0, 5):                                      # occluder cache: cells as large as the scene / a few per object (entries that rarely fit), or off
+        r.set_option("occluder_grid_cells", (3, 40)[seed % 2])
+    if seed % 11 == 4:
+        r.set_option("occluder_cache_bounces", 0)
+    if seed % 2:                                                # one batch per sample: every batch after the first starts on a warm occluder grid
+        for _ in range(spp):
+            r.render(1)
+    else:
+        r.render(spp)
     img, acc = r.read_accumulation()
     assert acc == spp
     sc, _ = oracle_scene_from_pt(pt)

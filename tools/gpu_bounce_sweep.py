@@ -13,7 +13,7 @@ if os.environ.get("RF_SCENE", "atrium") == "duck":      # BASELINE.json config 2
     W, H, b = 800, 600, 4
 else:
     if int(os.environ.get("RF_SCENE_SCALE", 1)) > 1: rf.set_bake_bvh_builder(0)      # GPU builder: same node bytes, 40x faster at that size
-    pt, info = scenes.atrium(scale=int(os.environ.get("RF_SCENE_SCALE", 1)))
+    pt, info = scenes.atrium(int(os.environ.get("RF_SCENE_SCALE", 1)), os.environ.get("RF_SCENE_DETAIL", "plain"))
     W, H, b = 1920, 1080, 8
 cam = rf.fly_camera(W, H)
 r = rf.ReferencePathTracer(rf.make_render_parameters(W, H, cam, spp, b, rf.make_sky(), 0.25), pt.scene())
