@@ -451,6 +451,7 @@ def main():
                     "process group, the product's RCCL communicator, the frame-end exchange (the rank sends its shard to itself) and the device un-tile")
     ap.add_argument("--no-live-counters", action="store_true", help="skip the two extra passes under `rocprofv3 --pmc` that measure the roofline's `traffic` in this run "
                     "(the committed per-ray profile x the live ray count is used then)")
+    ap.add_argument("--no-occluder-ablation", action="store_true", help="skip the untimed repeat with the occluder cache off")
     ap.add_argument("--repeat", type=int, default=3, help="timed regions of K steps each; the median one is reported (min / max beside it)")
     args = ap.parse_args()
 
@@ -636,6 +637,29 @@ def main():
         r.set_counting(False)
         assert cs["closest_rays"] == s["closest_rays"] and cs["shadow_rays"] == s["shadow_rays"], "counting pass traced different rays"
 
+    # ---- the same K steps once more with the any-hit launches' occluder cache off (untimed; one GPU): what the figure above owes to it, and that
+    # the image does not (kTraceWide, kFlagOccluderCache: a shadow ray first visits the leaves that stopped the last rays from its cell of the scene)
+    occluder = None
+    if rank == 0 and world == 1 and not multi and not args.no_occluder_ablation and not args.no_counting:   # (--no-counting: profiling runs trace the timed launches only)
+        r.set_option("occluder_cache_bounces", 0)
+        r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.375))
+        # frameCount is warm_spp + R spp (+ spp of the counting pass): the same sample indices again
+        r.set_timing(True); r.reset_stats()
+        t0 = time.perf_counter(); r.render(spp); r.synchronize(); t_off = time.perf_counter() - t0
+        s_off = r.stats()
+        r.set_timing(False)
+        img_off = r.read_accumulation()[0]
+        r.set_option("occluder_cache_bounces", 64)
+        occluder = {"enabled": True,
+                    "value_with_cache_off": round((s_off["closest_rays"] + s_off["shadow_rays"]) / t_off * 1e-6, 1),
+                    "ms_shadow": round(s["ms_shadow"], 3), "ms_shadow_with_cache_off": round(s_off["ms_shadow"], 3),
+                    "shadow_rays_answered_by_first_look": int(s.get("shadow_rays_hint_answered", 0)),
+                    "same_rays": bool(s_off["closest_rays"] == s["closest_rays"] and s_off["shadow_rays"] == s["shadow_rays"]),
+                    "image_bit_identical": bool(np.array_equal(np.asarray(img_off).view(np.uint32), np.asarray(image).view(np.uint32))),
+                    "note": "one untimed repeat of the same frames with occluder_cache_bounces = 0; every shadow ray is traced and counted in both"}
+        log(f"[bench] occluder cache off: {occluder['value_with_cache_off']} Mrays/s, shadow launches {occluder['ms_shadow_with_cache_off']} ms against {occluder['ms_shadow']}, "
+            f"image bit-identical: {occluder['image_bit_identical']}")
+
     # ---- roofline of the dominant kernel (closest-hit traversal) + one-line entries for the shadow traversal and kShade
     live = None
     if rank == 0 and world == 1 and not multi and not args.no_live_counters and "ROCPROFILER_REGISTER_ROOT" not in os.environ and "ROCP_TOOL_LIBRARIES" not in os.environ:
@@ -685,6 +709,8 @@ def main():
             "per_bounce_rank0": per_bounce,
             "roofline": roofline,
         }
+        out["occluder_cache"] = occluder if occluder is not None else {"enabled": True, "value_with_cache_off": None,
+                                                                         "note": "the untimed repeat with the cache off runs on one unsharded GPU only (and not with --no-counting)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["parity_crop"] = cpu_baseline(pt, W, H, B, last_first_frame, spp, args.cpu_seconds, image)
             # scene bake beside it: the reference's recursive builder as restated on the host (one

@@ -121,6 +121,10 @@ typedef struct rf_stats
      * scalar one (axis-parallel / non-finite rays, origins outside the conservative records' bound, more than 48 pending
      * entries: a full 12-entry LDS stack first evicts its oldest entries to scratch) -- results are identical. */
     uint64_t abandoned_rays, scalar_redo_rays;
+    /* Of shadow_rays: rays whose occluder was found by the any-hit launch's first look (kShadowFirstLook: the leaves that stopped the last shadow rays
+     * from the same cell of the scene, tested with the reference's box and triangle arithmetic) and that therefore never entered the BVH walk.
+     * Same visibility bit; reported so that a rays-per-second figure can be read with and without them. */
+    uint64_t shadow_rays_hint_answered;
 } rf_stats;
 
 typedef struct rf_renderer rf_renderer;

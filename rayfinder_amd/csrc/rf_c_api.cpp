@@ -322,6 +322,7 @@ int rf_renderer_get_stats(rf_renderer* r, rf_stats* out)
         out->shadow_record_fetches = s.shadowRecordFetches;
         out->abandoned_rays = s.abandonedRays;
         out->scalar_redo_rays = s.scalarRedoRays;
+        out->shadow_rays_hint_answered = s.shadowRaysHintAnswered;
         return RF_OK;
     });
 }

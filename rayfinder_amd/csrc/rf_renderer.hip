@@ -722,6 +722,8 @@ constexpr uint32_t kFlagUniformTri = 8u;          // the same for the triangles 
 constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path for records that every descending lane shares
 constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
 constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaves that stopped the last rays from its cell of the scene (see kTraceWide)
+constexpr uint32_t kFlagOccluderNoTry = 32u;      // ... the launch runs behind kShadowFirstLook: its rays have had their first look, it only records what stopped them
+constexpr uint32_t kFlagNoRayCount = 64u;         // the launch's rays are counted elsewhere (kShadowFirstLook counted the whole queue)
 #if defined(RF_EXP_OCC_SLOTS)
 constexpr int kOccSlots = RF_EXP_OCC_SLOTS;
 #else
@@ -1022,6 +1024,16 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // the ray's state sits at its QUEUE position: the lanes of a refill read consecutive elements (coalesced), and
                 // the closest-hit launch does not read the queue itself at all
                 resultIndex = myPos;
+                bool triedCell = false;
+                if constexpr (kOccluderCache)
+                {
+                    if (wide.rayList != nullptr)
+                    {
+                        const uint32_t e = wide.rayList[myPos]; // behind kShadowFirstLook: the rays it could not answer, by queue position
+                        resultIndex = e & 0x7FFFFFFFu;
+                        triedCell = (e >> 31) != 0u;
+                    }
+                }
                 if (ANY_HIT) slot = loadQ(queue + resultIndex); // the radiance sum and the blue-noise pair are the path's: by slot
                 // the NEE term this ray decides about: read with the rest of the ray (consecutive queue positions: coalesced) instead of
                 // at write-back, where every finishing lane gathered its own 12 bytes and the wave waited for them
@@ -1038,7 +1050,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 pr = packRay(ray);
                 rayDir = dir;
                 const uint32_t rayClass = classifyRay(ray);
-                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u);
+                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u) | (triedCell ? 16u : 0u);
                 rayTMax = tMax;
                 stackSize = spBase;
 #if defined(RF_EXP_PHASE)
@@ -1087,7 +1099,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 {
                     uint32_t hint = 0u;
                     uint32_t later[kOccSlots > 1 ? kOccSlots - 1 : 1] = {};
-                    if (occluderCache)
+                    if (occluderCache && (flags & kFlagOccluderNoTry) == 0u)
                     {
                         uint32_t e[kOccSlots];
                         loadOccluderCell(wide.occGrid + kOccSlots * static_cast<size_t>(occluderCell(o.x, o.y, o.z)), e);
@@ -1813,7 +1825,106 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         if (lane == 0 && ANY_HIT) atomicAdd(&counters->occluderTried, ot), atomicAdd(&counters->occluderHit, oh), atomicAdd(&counters->occludedRays, oc);
     }
 #endif
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !(flags & kFlagNoRayCount)) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// kShadowFirstLook: the occluder cache (kTraceWide, kFlagOccluderCache) without the traversal kernel around it.  Once the grid is warm nine
+// shadow rays in ten are stopped by one of the (up to) kOccSlots leaves their cell names -- 1.4 leaf visits and no interior step at all --
+// and a persistent, stack-carrying, lane-refilling kernel is a poor place for work that short.  This kernel walks the bounce's shadow queue
+// densely, one ray per lane and nothing to carry: cell of the origin -> its leaves in turn -> each leaf's exact box with the reference's
+// formula (leafBoxesIntoTriangles) -> the leaf's triangles.  A ray stopped there is finished (its NEE term times 0, exactly as the
+// traversal's write-back adds it; a leaf other than the cell's first moves to the front); every other ray's queue position goes onto a list
+// that the traversal launch works through -- without a first look of its own (kFlagOccluderNoTry), recording what it finds in the grid.
+//
+// Same visibility as the reference's shadowRay (wgsl:321-368), by the argument at kOccluderCache: a triangle is tested there iff the walk
+// reaches its leaf, i.e. iff the boxes of the leaf and of all its ancestors pass; an ancestor's box contains the leaf's and the slab
+// arithmetic is monotone in the planes, so a ray that passes the leaf's own test passes every ancestor's: the reference either reaches this
+// leaf and finds the same triangle, or has found another one before -- occluded either way.  Rays that are not class A (rf_wide.hpp: an
+// infinite 1/direction component, a non-finite origin), big leaves and cells without an entry are simply passed on.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
+                                                            const uint32_t* queueCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax, uint32_t firstBounce)
+{
+    __shared__ uint32_t sScratch[8];
+    const uint32_t      count = *queueCount;
+    const uint32_t      tiles = (count + kItems * kBlock - 1) / (kItems * kBlock);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
+    // (one entry after the other: staging the kItems entries of a thread -- four cells, then four triangle records in flight per lane -- takes 163
+    // registers, three waves per SIMD instead of eight, and measured 17 % slower: profiles/r04_occluder/firstlook2.log)
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
+    {
+        bool     keep[kItems];
+        uint32_t entry[kItems];
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+        {
+            const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
+            keep[k] = i < count;
+            entry[k] = i;
+            if (i >= count) continue;
+            const Vec3     o = load3(ps.rayO + i);
+            const uint32_t cx = static_cast<uint32_t>(__float2int_rd((o.x - wide.rootLo.x) * wide.occScale)), cy = static_cast<uint32_t>(__float2int_rd((o.y - wide.rootLo.y) * wide.occScale)),
+                           cz = static_cast<uint32_t>(__float2int_rd((o.z - wide.rootLo.z) * wide.occScale));
+            uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(((cx * 73856093u) ^ (cy * 19349663u) ^ (cz * 83492791u)) & wide.occMask);
+            uint32_t        e[kOccSlots];
+            loadOccluderCell(cell, e);
+            if (e[0] == 0u) continue;
+            const Vec3    nz = load3(ps.noiseOut + i);
+            const Vec3    dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
+            const RayPrep ray = prepareRay(o, dir);
+            if (classifyRay(ray) != kRayPlain) continue;
+            entry[k] = i | 0x80000000u; // has tried its cell's leaves
+            const PackedRay pr = packRay(ray);
+            int             at = -1; // which of the cell's leaves stopped the ray
+#pragma unroll
+            for (int j = 0; j < kOccSlots; ++j)
+            {
+                const uint32_t w = e[j];
+                // (a leaf word with its triangle count in the word, not in the big-leaf table)
+                if (at >= 0 || (w & kWideLeafBit) == 0u || ((w >> kWideIndexBits) & 7u) == 7u) continue;
+                const uint32_t first = w & ((1u << kWideIndexBits) - 1u), n = ((w >> kWideIndexBits) & 7u) + 1u;
+                const float4*  t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
+                const float4   a = t0[0], b = t0[1], c = t0[2];
+                const v3f      hi = *reinterpret_cast<const v3f*>(t0 + 3);
+                float          bn, bf;
+                bool           boxNaN;
+                slabSingleBounds(pr, a.w, b.w, c.w, hi.x, hi.y, hi.z, bn, bf, boxNaN);
+                if (!(bn <= bf && bf > 0.0f && bn < tMax)) continue; // the reference rejects this leaf
+                TriangleHit th;
+                bool        stopped = intersectTriangle(o, dir, vec3(a.x, a.y, a.z), vec3(b.x, b.y, b.z), vec3(c.x, c.y, c.z), tMax, th);
+                for (uint32_t t = 1; t < n && !stopped; ++t)
+                {
+                    const v3f q0 = *reinterpret_cast<const v3f*>(t0 + kTriStride * t), q1 = *reinterpret_cast<const v3f*>(t0 + kTriStride * t + 1),
+                              q2 = *reinterpret_cast<const v3f*>(t0 + kTriStride * t + 2);
+                    stopped = intersectTriangle(o, dir, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), tMax, th);
+                }
+                if (stopped) at = j;
+            }
+            if (at < 0) continue;
+            keep[k] = false;
+            if (at > 0)
+            {
+                uint32_t now[kOccSlots];
+                now[0] = e[at];
+#pragma unroll
+                for (int j = 1; j < kOccSlots; ++j) now[j] = j <= at ? e[j - 1] : e[j];
+                storeOccluderCell(cell, now);
+            }
+            // the traversal's write-back for an occluded ray (kTraceWide): radiance += (pending * 0) * invPdf -- a sum that keeps its bits unless the
+            // product is NaN, or the sum is not in memory yet (bounce 1)
+            const Vec3 add = (load3(ps.pending + i) * 0.0f) * __uint_as_float(kSolarInvPdfBits);
+            const bool unchanged = firstBounce == 0u && add.x == 0.0f && add.y == 0.0f && add.z == 0.0f;
+            if (!unchanged)
+            {
+                const uint32_t slot = queue[i];
+                const Vec3     radiance = (firstBounce != 0u ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot)) + add;
+                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            }
+        }
+        blockAppend<kItems>(keep, entry, list, listCount, sScratch);
+    }
 }
 
 
@@ -2087,13 +2198,21 @@ __global__ void kHitPoints(DeviceScene scene, const float4* hit, P3* rayO, uint3
 
 // Queue occupancy per bounce: Q[b-1] paths enter bounce b (closest-hit rays), Q[b] of them hit
 // something (shadow rays).  Folded into running totals at the end of every batch.
-__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals)
+// `listCounts` / `lookMask`: bounces whose any-hit launch ran behind kShadowFirstLook (bit b) -- Q[b] minus the length of its list is what that kernel answered.
+__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals, const uint32_t* listCounts, unsigned long long lookMask, unsigned long long* lookBatch)
 {
     const uint32_t b = threadIdx.x;
     if (b >= numBounces) return;
     const uint32_t k = min(b, RenderStats::kMaxBounceStats - 1);
     atomicAdd(&totals[k], static_cast<unsigned long long>(queueCounts[kLineWords * b]));
     atomicAdd(&totals[RenderStats::kMaxBounceStats + k], static_cast<unsigned long long>(queueCounts[kLineWords * (b + 1)]));
+    if ((lookMask >> b) & 1ull)
+    {
+        const unsigned long long rays = queueCounts[kLineWords * (b + 1)], answered = rays - listCounts[kLineWords * b];
+        atomicAdd(&totals[2 * RenderStats::kMaxBounceStats + k], answered);
+        atomicAdd(&lookBatch[0], answered); // this batch alone: the host decides from it whether the first look pays (Impl::firstLookHoldOff)
+        atomicAdd(&lookBatch[1], rays);
+    }
 }
 
 // image[lp] += radiance of samples 0..numSamples-1 in order (f32, wgsl:55); image is the compact
@@ -2535,7 +2654,7 @@ struct Renderer::Impl
     DeviceBuffer<float4>    sRad, sHit;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
     DeviceBuffer<DeviceCounters> counters;
-    DeviceBuffer<unsigned long long> bounceTotals; // 2 x kMaxBounceStats
+    DeviceBuffer<unsigned long long> bounceTotals; // 3 x kMaxBounceStats: closest-hit rays, shadow rays, shadow rays answered by kShadowFirstLook
 
     // deferred-lighting variant: its own frame counter and buffers (array<array<f32, 3>>)
     uint32_t               deferredFrameCount = 0;
@@ -2549,6 +2668,17 @@ struct Renderer::Impl
     bool     wideUsable = true;
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
     bool     shadowNearestFirst = true; // shadow rays: nearest child first (visibility is order independent)
+    // the cached any-hit launches of bounce >= this run behind kShadowFirstLook (0: never).  From bounce 2: the coherent launch of bounce 1 costs less per ray than
+    // a pass over the queue does (atrium -4 %, Duck +14 % with it: profiles/r04_occluder/firstlook_scenes2.log)
+    uint32_t optShadowFirstLookFromBounce = 2;
+    bool     occluderGridWarm = false;       // a batch has filled the occluder grid since it was allocated
+    // kShadowFirstLook pays where most shadow rays are stopped by their cell's leaves; in a scene lit from everywhere it only adds a pass over the queue.  Every
+    // batch reports {answered, rays} of its first looks (asynchronously: read when the copy has landed); below a quarter the next 16 batches go without.
+    DeviceBuffer<unsigned long long> lookBatch;
+    unsigned long long*              lookBatchHost = nullptr;
+    hipEvent_t                       lookEvent = nullptr;
+    bool                             lookPending = false;
+    uint32_t                         firstLookHoldOff = 0;
     bool     leafBoxesValid = false;   // every leaf's exact box sits in its first triangle record (leafBoxesIntoTriangles)
     uint32_t optOccluderGridLog2Cells = 22; // table size: 2^n cells of kOccSlots words
     uint32_t optOccluderGridCells = 1024; // occluder grid: cells along the longest axis of the root box (0: no grid, the wave's last occluder only)
@@ -2887,12 +3017,14 @@ struct Renderer::Impl
         const uint32_t numBounces = fp.numBounces;
 
         wide.occGrid = nullptr;
+        wide.rayList = nullptr;
         if (optOccluderCacheBounces != 0u && optOccluderGridCells != 0u)
         {
             const size_t kOccluderGridEntries = (size_t{1} << optOccluderGridLog2Cells) * kOccSlots;
             if (occluderGrid.count != kOccluderGridEntries)
             {
                 occluderGrid.alloc(kOccluderGridEntries);
+                occluderGridWarm = false;
                 RF_HIP(hipMemsetAsync(occluderGrid.ptr, 0, kOccluderGridEntries * sizeof(uint32_t), stream));
             }
             const float extent = std::max({wide.rootHi.x - wide.rootLo.x, wide.rootHi.y - wide.rootLo.y, wide.rootHi.z - wide.rootLo.z, 1e-20f});
@@ -2900,16 +3032,31 @@ struct Renderer::Impl
             wide.occScale = static_cast<float>(optOccluderGridCells) / extent;
             wide.occMask = static_cast<uint32_t>(kOccluderGridEntries / kOccSlots - 1);
         }
+        if (lookBatch.count == 0)
+        {
+            lookBatch.alloc(2);
+            RF_HIP(hipHostMalloc(reinterpret_cast<void**>(&lookBatchHost), 2 * sizeof(unsigned long long)));
+            RF_HIP(hipEventCreateWithFlags(&lookEvent, hipEventDisableTiming));
+        }
+        if (lookPending && hipEventQuery(lookEvent) == hipSuccess)
+        {
+            lookPending = false;
+            if (lookBatchHost[1] != 0ull && lookBatchHost[0] * 4ull < lookBatchHost[1]) firstLookHoldOff = 16u;
+        }
+        else if (firstLookHoldOff != 0u) --firstLookHoldOff;
+        RF_HIP(hipMemsetAsync(lookBatch.ptr, 0, 2 * sizeof(unsigned long long), stream));
         BatchTiming bt{getEvent(), getEvent(), numSamples};
         RF_HIP(hipEventRecord(bt.start, stream));
 
         // device words, one per 64-byte line (they are all hot atomics): [0, B]: queue lengths per
         // bounce; [B+1, 2B]: miss-list length per bounce; then two work cursors per bounce for the traversal launches
         constexpr uint32_t kLine = kLineWords;
-        const uint32_t words = kLine * (2 * numBounces + 1) + kLine * kShards * 2 * numBounces;
+        const uint32_t words = kLine * (2 * numBounces + 1) + kLine * kShards * 2 * numBounces + kLine * numBounces;
         if (queueCounts.count < words) queueCounts.alloc(words);
         uint32_t* const missCounts = queueCounts.ptr + kLine * (numBounces + 1);
         uint32_t* const cursors = queueCounts.ptr + kLine * (2 * numBounces + 1);
+        uint32_t* const listCounts = cursors + kLine * kShards * 2 * numBounces; // lengths of the lists kShadowFirstLook leaves to the any-hit launches, per bounce
+        unsigned long long lookMask = 0ull;
         const uint32_t  itemBlocks = static_cast<uint32_t>((paths + kBlock * kItems - 1) / (kBlock * kItems));
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
 
@@ -2995,8 +3142,21 @@ struct Renderer::Impl
                                                                       (wide.quadHalf != nullptr && optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce));
             const bool     exactQuadShadowNow = quadShadowNow && !conservativeShadowNow && wide.quad != nullptr && leafBoxesValid; // (its leaf visits then apply the box in the leaf's triangle record)
             const bool     cachedShadow = traversalVariant != 0 && !counting && bounce > optPacketBounces && shadowNearestFirst && (conservativeShadowNow || exactQuadShadowNow) && bounce <= optOccluderCacheBounces;
-            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (cachedShadow ? kFlagOccluderCache : 0u);
+            // ... behind kShadowFirstLook (see there) from the second batch on: the first batch of a renderer fills the grid (the traversal kernel's own first look serves)
+            const bool      firstLook = cachedShadow && optShadowFirstLookFromBounce != 0u && bounce >= optShadowFirstLookFromBounce && bounce <= 64u && occluderGridWarm && firstLookHoldOff == 0u;
+            uint32_t* const listCount = listCounts + kLine * (bounce - 1);
+            uint32_t* const countShadow = firstLook ? listCount : countOut;
+            if (firstLook) lookMask |= 1ull << (bounce - 1);
+            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (cachedShadow ? kFlagOccluderCache : 0u) | (firstLook ? (kFlagOccluderNoTry | kFlagNoRayCount) : 0u);
             launchTimed(3, [&] {
+                WideScene wide = this->wide; // (the launches below name `wide`)
+                if (firstLook)
+                {
+                    // (the bounce's input queue is free by now -- kShade and kSky have consumed it -- and holds the list)
+                    const dim3 lookGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
+                    hipLaunchKernelGGL(kShadowFirstLook, lookGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, qIn, listCount, counters.ptr, kTMax, bounce == 1 ? 1u : 0u);
+                    wide.rayList = qIn;
+                }
                 if (traversalVariant == 0)
                 {
                     if (counting)
@@ -3010,46 +3170,46 @@ struct Renderer::Impl
                 else if (shadowNearestFirst)
                 {
                     if (counting)
-                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.quadLocal != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                              optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce)
                     {
                         if (optShadowSignOrder)
-                            hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                            hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
-                            hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                            hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quadHalf != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
                              optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce)
                     {
                         if (optShadowSignOrder)
-                            hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                            hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                         else
-                            hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                            hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                                cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     }
                     else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce)
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce)
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                     else
-                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countOut,
+                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
                                            cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                 }
                 else if (counting)
-                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
+                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow, cursorShadow,
                                        counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
                 else
-                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, cursorShadow,
+                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow, cursorShadow,
                                        counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
             }, bounce - 1);
             std::swap(qIn, qOut);
@@ -3057,7 +3217,14 @@ struct Renderer::Impl
             std::swap(ps.thr, ps.thrOut);
             std::swap(ps.noise, ps.noiseOut);
         }
-        hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr);
+        hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr, listCounts, lookMask, lookBatch.ptr);
+        if (lookMask != 0ull && lookBatchHost != nullptr)
+        {
+            RF_HIP(hipMemcpyAsync(lookBatchHost, lookBatch.ptr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            RF_HIP(hipEventRecord(lookEvent, stream));
+            lookPending = true;
+        }
+        if (wide.occGrid != nullptr) occluderGridWarm = true;
         launchTimed(4, [&] {
             if (fp.slotGroupShift == 0u && numSamples > 4u && numSamples <= kAccMaxSamples && optAccumulateRuns)
                 hipLaunchKernelGGL(kAccumulateRuns, dim3((fp.pixelsPadded + kAccPixels - 1) / kAccPixels), dim3(64), kAccPixels * 3u * (numSamples + 1u) * sizeof(float), stream, fp,
@@ -3248,7 +3415,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     DeviceCounters zero{};
     m.counters.upload(&zero, 1);
     {
-        const std::vector<unsigned long long> z(2 * RenderStats::kMaxBounceStats, 0ull);
+        const std::vector<unsigned long long> z(3 * RenderStats::kMaxBounceStats, 0ull);
         m.bounceTotals.upload(z.data(), z.size());
     }
     {
@@ -3301,6 +3468,8 @@ Renderer::~Renderer()
         (void)hipEventDestroy(b.stop);
     }
     for (auto e : mImpl->eventPool) (void)hipEventDestroy(e);
+    if (mImpl->lookEvent) (void)hipEventDestroy(mImpl->lookEvent);
+    if (mImpl->lookBatchHost) (void)hipHostFree(mImpl->lookBatchHost);
     (void)hipStreamDestroy(mImpl->stream);
 }
 
@@ -3610,6 +3779,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;
+    else if (name == "shadow_first_look_from_bounce") mImpl->optShadowFirstLookFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "occluder_grid_log2_cells") mImpl->optOccluderGridLog2Cells = static_cast<uint32_t>(std::clamp<int64_t>(value, 4, 26));
     else if (name == "occluder_grid_cells") mImpl->optOccluderGridCells = static_cast<uint32_t>(std::clamp<int64_t>(value, 0, 1 << 16));
     else if (name == "occluder_cache_bounces") mImpl->optOccluderCacheBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
@@ -3649,7 +3819,7 @@ void Renderer::resetStats()
     m.collectTimings();
     DeviceCounters zero{};
     RF_HIP(hipMemcpy(m.counters.ptr, &zero, sizeof zero, hipMemcpyHostToDevice));
-    RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 2 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
+    RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 3 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
     m.hostStats = RenderStats{};
     m.primaryRaysHost = 0;
 }
@@ -3707,12 +3877,13 @@ RenderStats Renderer::stats()
                          steps / (64.0 * c.descendTrips[k]), tris / (64.0 * c.leafTrips[k]));
         }
     }
-    unsigned long long totals[2 * RenderStats::kMaxBounceStats];
+    unsigned long long totals[3 * RenderStats::kMaxBounceStats];
     RF_HIP(hipMemcpy(totals, m.bounceTotals.ptr, sizeof totals, hipMemcpyDeviceToHost));
     for (uint32_t b = 0; b < RenderStats::kMaxBounceStats; ++b)
     {
         s.closestRaysByBounce[b] = totals[b];
         s.shadowRaysByBounce[b] = totals[RenderStats::kMaxBounceStats + b];
+        s.shadowRaysHintAnswered += totals[2 * RenderStats::kMaxBounceStats + b];
     }
     return s;
 }

@@ -87,7 +87,10 @@ struct WideScene
     // which the last shadow ray that left that cell found its occluder, 0: nothing known.  Hints only: any leaf word a kernel wrote is a valid first visit.
     uint32_t*     occGrid;   // or nullptr
     float         occScale;  // cells per unit length
-    uint32_t      occMask;   // entries - 1 (a power of two)
+    uint32_t      occMask;   // cells - 1 (a power of two)
+    // any-hit launches behind kShadowFirstLook: the queue POSITIONS of the rays still to trace (bit 31: the ray has tried its cell's leaves), or nullptr = every
+    // position of the queue; the launch's count argument is then the length of this list
+    const uint32_t* rayList;
 };
 
 struct WideBuild

@@ -449,6 +449,7 @@ def test_occluder_cache_is_invisible(atrium, duck_pt):
             r, _ = _renderer(pt, W, H, spp, bounces, sky=skies[0])
             r.set_option("occluder_grid_cells", cells)
             r.set_option("occluder_grid_log2_cells", log2_table)
+            r.set_option("shadow_first_look_from_bounce", {1024: 2, 8: 1, 4096: 0}[cells])   # the default; kShadowFirstLook at every bounce; in-kernel first look only
             for sky, ref in zip(skies, want):                             # cold, then stale, then stale the other way round
                 r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, sky, 0.25))
                 r.render(spp)
@@ -818,6 +819,8 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
         r.set_option("occluder_grid_cells", (3, 40)[seed % 2])
     if seed % 11 == 4:
         r.set_option("occluder_cache_bounces", 0)
+    if seed % 5 in (2, 4):                                      # kShadowFirstLook from bounce 1 / never (default: from bounce 2, once the grid is warm)
+        r.set_option("shadow_first_look_from_bounce", 1 if seed % 5 == 2 else 0)
     if seed % 2:                                                # one batch per sample: every batch after the first starts on a warm occluder grid
         for _ in range(spp):
             r.render(1)
