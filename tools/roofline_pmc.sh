@@ -79,7 +79,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 d = collections.OrderedDict()
 for r in rows:
     k = r.get("Kernel_Name", "")
-    kind = "closest" if "kTraceWide<false" in k else "shadow" if "kTraceWide<true" in k else None
+    kind = "closest" if "kTraceWide<false" in k else "shadow" if "kTraceWide<true" in k else "shadow_look" if "kShadowFirstLook" in k else None   # (shadow_look: the dense first pass of a bounce's any-hit launch)
     if kind is None: continue
     d.setdefault((kind, int(r["Dispatch_Id"])), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 names = sorted({c for v in d.values() for c in v})

@@ -169,8 +169,9 @@ per_ray = dict(
            "the kernel and divided by the rays one launch traces; FETCH_SIZE / WRITE_SIZE (KB) x 1024 x the calibration factors of calibration.json; fabric-side "
            "requests of the 8 L2s (Infinity-Cache hits included)")
 def kernel_block(prefix, rays_timed, label):
-    """Fabric-side bytes and L1 / L2 figures per unit of work for every instantiation of a kernel whose name starts with `prefix`."""
-    names = [n for n in pm if n.startswith(prefix)]
+    """Fabric-side bytes and L1 / L2 figures per unit of work for every instantiation of a kernel whose name starts with `prefix` (or one of several)."""
+    prefixes = (prefix,) if isinstance(prefix, str) else tuple(prefix)
+    names = [n for n in pm if n.startswith(prefixes)]
     if not names or not rays_timed:
         return None
     kk = {"_dispatches": sum(pm[n]["_dispatches"] for n in names)}
@@ -190,7 +191,9 @@ def kernel_block(prefix, rays_timed, label):
 # the other two kernels the bench line prices: the shadow traversal (per shadow ray; random record gathers like the closest-hit
 # kernel: same read calibration) and kShade (per queue entry = per closest-hit ray; its reads are a mix of coalesced streams --
 # counted at 0.5 -- and 128-byte record gathers -- counted at ~1 --, so its bytes are reported with BOTH factors as a bracket)
-sh = kernel_block("kTraceWide<true", bench["rays"]["shadow"], "kTraceWide<shadow>")
+# (round 4: from bounce 2 on an any-hit launch is kShadowFirstLook -- the dense pass over the queue that answers the rays their cell's leaves stop -- followed by
+# kTraceWide<true, ...> over the rest: both are "the shadow traversal", per shadow ray of the queue)
+sh = kernel_block(("kTraceWide<true", "kShadowFirstLook"), bench["rays"]["shadow"], "kTraceWide<shadow> + kShadowFirstLook")
 if sh:
     sh["hbm_side_bytes_per_unit"] = round(fc * sh["fetch_size_bytes_per_unit"] + wc * sh["write_size_bytes_per_unit"], 2)
     per_ray["shadow"] = sh
@@ -249,6 +252,16 @@ for kind in ("closest", "shadow"):
     if not rows or not nb:
         continue
     last = sorted(rows)[-nb:]          # the timed batch's launches are the last nb dispatches of the kernel
+    if kind == "shadow" and pb.get("shadow_look"):
+        # the first looks of the timed batch are the LAST dispatches of that kernel and belong to its last bounces (a cold first batch has none; bounce 1 has none
+        # by default): their counters -- cycles included -- are added to the traversal launch of the same bounce
+        looks = pb["shadow_look"]
+        lk = sorted(looks)[-min(nb - 1, len(looks)):] if nb > 1 else []
+        merged_rows = {j: dict(rows[j]) for j in last}
+        for j, jl in zip(last[len(last) - len(lk):], lk):
+            for c, v in looks[jl].items():
+                merged_rows[j][c] = merged_rows[j].get(c, 0.0) + v
+        rows = merged_rows
     for b, j in zip(bounces, last):
         c = rows[j]
         rays = b[f"{kind}_rays"]
