@@ -198,6 +198,11 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *   shadow_record_order 0 | 1          shadow launches on the 64-byte quad layouts: nearest-first | entries in record order (default: the
  *                                      cheaper step wins where the VALU binds)
  *   packet_bounces n                   bounces 1..n traced by lockstep wave packets (default 0)
+ *   occluder_cache_bounces n           the any-hit launches of bounces 1..n first visit the leaves that stopped the last shadow rays from the
+ *                                      ray's cell of the scene (default 64; 0: off).  occluder_grid_cells c: cells along the longest extent of the
+ *                                      scene (default 1024); occluder_grid_log2_cells n: table of 2^n cells x 16 bytes (default 22);
+ *                                      shadow_first_look_from_bounce b: from this bounce on that first look is a dense pass of its own
+ *                                      (kShadowFirstLook; default 2, 0: never).  Same image with any setting.
  *   slot_group_shift, sample_sort, accumulate_runs, shade_blocks, reserve_samples, persistent_blocks, extra_lds
  *                                      path-slot order, accumulation kernel, grid sizes, occupancy experiments
  *   query_variant 0 | 2, query_compact 0 .. 5       kernels / record layout behind rf_renderer_intersect_rays / _occluded_rays (tests) */
