@@ -730,6 +730,14 @@ constexpr int kOccSlots = RF_EXP_OCC_SLOTS;
 constexpr int kOccSlots = 4; // entries per cell of the occluder grid (1, 2 or 4: shadow launches of the atrium -19 / -29 / -34 %, profiles/r04_occluder)
 #endif
 static_assert(kOccSlots == 1 || kOccSlots == 2 || kOccSlots == 4, "one aligned load per cell");
+// cell of a point -> table index.  (Blocks of 4 x 4 x 4 neighbouring cells sharing 1 KB of the table -- the block hashed, the cell's place inside it from its low
+// coordinate bits, so that a wave's rays read neighbouring lines -- measured -0.7 %: profiles/r04_occluder/occ_blocks.log.)
+__device__ __forceinline__ uint32_t occluderCellIndex(const WideScene& wide, float ox, float oy, float oz)
+{
+    const uint32_t cx = static_cast<uint32_t>(__float2int_rd((ox - wide.rootLo.x) * wide.occScale)), cy = static_cast<uint32_t>(__float2int_rd((oy - wide.rootLo.y) * wide.occScale)),
+                   cz = static_cast<uint32_t>(__float2int_rd((oz - wide.rootLo.z) * wide.occScale));
+    return ((cx * 73856093u) ^ (cy * 19349663u) ^ (cz * 83492791u)) & wide.occMask;
+}
 __device__ __forceinline__ void loadOccluderCell(const uint32_t* cell, uint32_t (&e)[kOccSlots])
 {
     if constexpr (kOccSlots == 1) e[0] = *cell;
@@ -827,11 +835,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // the conservative layouts always do -- a second, identical test for the leaves reached by the walk, THE test for the ones visited first)
     const bool     leafBoxAtLeaf = COMPACT == 4 || COMPACT == 5 || (COMPACT == 3 && kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr);
     const bool     occluderCache = kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr;
-    const auto occluderCell = [&](float ox, float oy, float oz) -> uint32_t {
-        const uint32_t cx = static_cast<uint32_t>(__float2int_rd((ox - wide.rootLo.x) * wide.occScale)), cy = static_cast<uint32_t>(__float2int_rd((oy - wide.rootLo.y) * wide.occScale)),
-                       cz = static_cast<uint32_t>(__float2int_rd((oz - wide.rootLo.z) * wide.occScale));
-        return ((cx * 73856093u) ^ (cy * 19349663u) ^ (cz * 83492791u)) & wide.occMask;
-    };
+    const auto occluderCell = [&](float ox, float oy, float oz) -> uint32_t { return occluderCellIndex(wide, ox, oy, oz); };
     constexpr uint32_t kNegTriedHint = 16u; // negMask: the ray started at a hint
 
     // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
@@ -1865,9 +1869,7 @@ __global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, Wi
             entry[k] = i;
             if (i >= count) continue;
             const Vec3     o = load3(ps.rayO + i);
-            const uint32_t cx = static_cast<uint32_t>(__float2int_rd((o.x - wide.rootLo.x) * wide.occScale)), cy = static_cast<uint32_t>(__float2int_rd((o.y - wide.rootLo.y) * wide.occScale)),
-                           cz = static_cast<uint32_t>(__float2int_rd((o.z - wide.rootLo.z) * wide.occScale));
-            uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(((cx * 73856093u) ^ (cy * 19349663u) ^ (cz * 83492791u)) & wide.occMask);
+            uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(occluderCellIndex(wide, o.x, o.y, o.z));
             uint32_t        e[kOccSlots];
             loadOccluderCell(cell, e);
             if (e[0] == 0u) continue;
