@@ -460,6 +460,30 @@ def test_occluder_cache_is_invisible(atrium, duck_pt):
             r.close()
 
 
+def test_occluder_cache_engages_on_the_atrium(atrium):
+    """The cache is not silently off: on the second batch of a handle (warm grid) kShadowFirstLook settles most of the shadow rays of bounces >= 2, the shadow
+    launches take clearly less time than with the cache off, and the per-bounce ray counts do not change (every shadow ray is still counted)."""
+    W, H, spp, bounces = 1920, 1080, 16, 8                            # (33 M paths per batch: launches long enough for their time to mean something)
+    r, _ = _renderer(atrium, W, H, spp, bounces)
+    r.render(spp); r.synchronize()                                   # first batch: fills the grid
+    res = {}
+    for name, n in (("on", 64), ("off", 0)):
+        r.set_option("occluder_cache_bounces", n)
+        r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.3 + 0.1 * (n == 0)))
+        r.set_timing(True); r.reset_stats()
+        r.render(spp); r.synchronize()
+        res[name] = (r.stats(), r.bounce_stats(), r.read_accumulation()[0])
+    r.close()
+    on, off = res["on"][0], res["off"][0]
+    deep = float(np.sum(res["on"][1]["shadow_rays"][1:]))
+    assert on["shadow_rays"] == off["shadow_rays"] and on["closest_rays"] == off["closest_rays"]
+    assert np.array_equal(np.asarray(res["on"][1]["shadow_rays"]), np.asarray(res["off"][1]["shadow_rays"]))
+    assert off["shadow_rays_hint_answered"] == 0
+    assert on["shadow_rays_hint_answered"] > 0.6 * deep, (on["shadow_rays_hint_answered"], deep)
+    assert on["ms_shadow"] < 0.85 * off["ms_shadow"], (on["ms_shadow"], off["ms_shadow"])
+    assert np.array_equal(bits(res["on"][2]), bits(res["off"][2]))
+
+
 def test_atrium_config5_4k_16_bounces_crops_and_queue_occupancy(atrium):
     """BASELINE.json config 5 geometry (3840x2160, 16 bounces; NEE is always on): oracle parity on crops and
     the per-bounce queue statistics (queue occupancy per bounce)."""
