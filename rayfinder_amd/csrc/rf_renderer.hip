@@ -105,6 +105,22 @@ __device__ __forceinline__ void store3(P3* p, Vec3 v)
     o.x = v.x, o.y = v.y, o.z = v.z;
     *p = o;
 }
+// The same with the non-temporal hint, for kShade's streams: 100 B per hit written once and read once by the next launches -- tens of GB per bounce that would
+// otherwise push what IS reused (shading records, texels, BVH records, the occluder grid) out of L2 / Infinity Cache: kShade -4.4 % (profiles/r04_occluder/
+// nt_shade2.log).  The hint on kRaygen's stores, kShadowFirstLook's loads and the traversal kernels' hit records as well measured nothing more; on the traversal
+// kernels' own path-state accesses it measured 1 % slower (round 2) -- those stay plain.
+typedef float v3fu __attribute__((ext_vector_type(3), aligned(4)));
+__device__ __forceinline__ void store3nt(P3* p, Vec3 v)
+{
+    v3fu o;
+    o.x = v.x, o.y = v.y, o.z = v.z;
+    __builtin_nontemporal_store(o, reinterpret_cast<v3fu*>(p));
+}
+__device__ __forceinline__ Vec3 load3nt(const P3* p)
+{
+    const v3fu v = __builtin_nontemporal_load(reinterpret_cast<const v3fu*>(p));
+    return vec3(v.x, v.y, v.z);
+}
 
 // Path-state accesses of the traversal kernels (queue entry, origin, direction, result: touched once per ray).  A build with
 // the non-temporal hint on them measured 1 % slower (shadow kernel 32.2 -> 33.3 ms per 32 spp), so they are plain.
@@ -450,7 +466,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
                 // what pass 2 needs of this entry, read here in INPUT order (coalesced) and handed over in LDS: pass 2 works in the
                 // tile's sorted order, where the 64 lanes of a wave would gather from ~57 different lines per stream
                 const uint32_t l = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
-                const Vec3     t = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i), z = load3(ps.noise + i);
+                const Vec3     t = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3nt(ps.thr + i), z = load3nt(ps.noise + i);
                 sIn[l] = t.x, sIn[kTile + l] = t.y, sIn[2 * kTile + l] = t.z;
                 sIn[3 * kTile + l] = z.x, sIn[4 * kTile + l] = z.y, sIn[5 * kTile + l] = z.z;
                 sIn[6 * kTile + l] = hitRec.x, sIn[7 * kTile + l] = hitRec.y, sIn[8 * kTile + l] = hitRec.z;
@@ -560,7 +576,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             const Vec3 p0 = cur.p0, p1 = cur.p1, p2 = cur.p2;
             const Vec3 e1 = p1 - p0, e2 = p2 - p0;
             const Vec3 hp = offsetRay(p0 + hu * e1 + hv * e2, normalize(cross(e1, e2)));
-            store3(ps.rayO + out, hp); // (this bounce's origins have been consumed by the closest-hit launch)
+            store3nt(ps.rayO + out, hp); // (this bounce's origins have been consumed by the closest-hit launch)
         }
         // SORTED: this thread's entry is the tile's `local`-th in input order; its throughput and blue-noise triple were read in input
         // order (coalesced) by pass 1 and wait in LDS -- gathered from memory, the 64 lanes of a wave would touch ~57 different lines of
@@ -574,11 +590,11 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
         }
         else
         {
-            throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + i); // wgsl:184
-            nz = load3(ps.noise + i);
+            throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3nt(ps.thr + i); // wgsl:184
+            nz = load3nt(ps.noise + i);
         }
         const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
-        store3(ps.noiseOut + out, nz); // travels with the path: dense for this bounce's shadow launch and for the next kShade
+        store3nt(ps.noiseOut + out, nz); // travels with the path: dense for this bounce's shadow launch and for the next kShade
         const float4  a0 = cur.a0, a1 = cur.a1, a2 = cur.a2, a3 = cur.a3;
         const Vec3    n0 = vec3(a0.x, a0.y, a0.z), n1 = vec3(a0.w, a1.x, a1.y), n2 = vec3(a1.z, a1.w, a2.x);
         const float   b0 = 1.0f - hu - hv, b1 = hu, b2 = hv; // wgsl:515
@@ -597,7 +613,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
         const Vec3 brdf = albedo * kFrac1Pi;
         const Vec3 reflectance = brdf * dot(n, lightDirection);
         const Vec3 pend = (throughput * lightIntensity) * reflectance;
-        store3(ps.pending + out, pend); // read by the shadow launch at the same queue position
+        store3nt(ps.pending + out, pend); // read by the shadow launch at the same queue position
 
         if (!isLastBounce)
         {
@@ -608,8 +624,8 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             pixarOnb(n, bu, bv);
             const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
             const Vec3 t2 = throughput * albedo;
-            store3(ps.rayDOut + out, wi);
-            store3(ps.thrOut + out, t2);
+            store3nt(ps.rayDOut + out, wi);
+            store3nt(ps.thrOut + out, t2);
         }
     };
     if constexpr (kPipelined)
