@@ -1624,6 +1624,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             bool finished = false;
             if (kPhase) ++wLeafPhase;
             float4 firstA{}, firstB{}, firstC{};
+            uint32_t leafHint = 0u;
             if (leafBoxAtLeaf)
             {
                 // The half-precision / local-grid quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
@@ -1631,7 +1632,14 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // rides in the spare floats of its first triangle record (leafBoxesIntoTriangles): the same 64-byte line.
                 const float4* t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
                 firstA = t0[0], firstB = t0[1], firstC = t0[2];
-                const v3f hi = *reinterpret_cast<const v3f*>(t0 + 3);
+                float4 hi;
+                if constexpr (kOccluderCache) hi = t0[3]; // .w: what the occluder cache remembers for this leaf (leafBoxesIntoTriangles)
+                else
+                {
+                    const v3f h3 = *reinterpret_cast<const v3f*>(t0 + 3);
+                    hi = make_float4(h3.x, h3.y, h3.z, 0.0f);
+                }
+                if constexpr (kOccluderCache) leafHint = __float_as_uint(hi.w);
                 float     bn, bf;
                 bool      boxNaN;
                 PackedRay exact = pr;
@@ -1706,7 +1714,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             if (finished)
             {
-                if (kOccluderCache) occluderWord = node;
+                if (kOccluderCache) occluderWord = leafHint != 0u ? leafHint : node;
 #if defined(RF_EXP_PHASE)
                 if (ANY_HIT) { ++phaseOccluded; if (phaseFromCache && stackSize == spBase + kSpStep) ++phaseOccHit; }
 #endif
@@ -2697,6 +2705,7 @@ struct Renderer::Impl
     hipEvent_t                       lookEvent = nullptr;
     bool                             lookPending = false;
     uint32_t                         firstLookHoldOff = 0;
+    uint32_t occluderHintLevels = 0;  // see leafBoxesIntoTriangles (0: the cache remembers leaves)
     bool     leafBoxesValid = false;   // every leaf's exact box sits in its first triangle record (leafBoxesIntoTriangles)
     uint32_t optOccluderGridLog2Cells = 22; // table size: 2^n cells of kOccSlots words
     uint32_t optOccluderGridCells = 1024; // occluder grid: cells along the longest axis of the root box (0: no occluder cache)
@@ -3161,7 +3170,7 @@ struct Renderer::Impl
             const bool     exactQuadShadowNow = quadShadowNow && !conservativeShadowNow && wide.quad != nullptr && leafBoxesValid; // (its leaf visits then apply the box in the leaf's triangle record)
             const bool     cachedShadow = traversalVariant != 0 && !counting && bounce > optPacketBounces && shadowNearestFirst && (conservativeShadowNow || exactQuadShadowNow) && bounce <= optOccluderCacheBounces;
             // ... behind kShadowFirstLook (see there) from the second batch on: the first batch of a renderer fills the grid (the traversal kernel's own first look serves)
-            const bool      firstLook = cachedShadow && optShadowFirstLookFromBounce != 0u && bounce >= optShadowFirstLookFromBounce && bounce <= 64u && occluderGridWarm && firstLookHoldOff == 0u;
+            const bool      firstLook = cachedShadow && occluderHintLevels == 0u && optShadowFirstLookFromBounce != 0u && bounce >= optShadowFirstLookFromBounce && bounce <= 64u && occluderGridWarm && firstLookHoldOff == 0u;
             uint32_t* const listCount = listCounts + kLine * (bounce - 1);
             uint32_t* const countShadow = firstLook ? listCount : countOut;
             if (firstLook) lookMask |= 1ull << (bounce - 1);
@@ -3357,7 +3366,32 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             padded[kTriStride * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
         }
         // ... and the exact box of every leaf in the spare floats of its first triangle (read by the half-precision quad kernels)
-        m.leafBoxesValid = leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n);
+        {
+            // What the occluder cache remembers per stopped ray: the leaf -- or, where the leaves are small against the sun disc's footprint at the occluder (the
+            // next ray from the same place is stopped by a NEIGHBOUR of that triangle), a record a few levels above it.  Footprint: the disc's 0.51 degrees over a
+            // third of the scene = 0.003 extents; every quad level doubles the patch.  Atrium (18-cm leaves in 30 m): 0 -- the leaf; its x8 tessellation (2.3 cm): 2
+            // (shadow launches -22 % against -2 % with leaves: profiles/r04_occluder/x8_hint_levels.log).
+            std::vector<float> diag;
+            diag.reserve(sceneView.bvhNodes.size() / 2 + 1);
+            for (const BvhNode& nd : sceneView.bvhNodes)
+                if (nd.triangleCount != 0)
+                {
+                    const float dx = nd.aabb.max.x - nd.aabb.min.x, dy = nd.aabb.max.y - nd.aabb.min.y, dz = nd.aabb.max.z - nd.aabb.min.z;
+                    diag.push_back(std::sqrt(dx * dx + dy * dy + dz * dz));
+                }
+            const Aabb& root = sceneView.bvhNodes[0].aabb;
+            const float extent = std::max({root.max.x - root.min.x, root.max.y - root.min.y, root.max.z - root.min.z});
+            m.occluderHintLevels = 0;
+            if (!diag.empty() && extent > 0.0f)
+            {
+                std::nth_element(diag.begin(), diag.begin() + diag.size() / 2, diag.end());
+                const float median = diag[diag.size() / 2];
+                if (median > 0.0f && std::isfinite(median) && std::isfinite(extent))
+                    m.occluderHintLevels = static_cast<uint32_t>(std::clamp(static_cast<int>(std::floor(std::log2(0.003f * extent / median))) + 1, 0, 3));
+            }
+            if (const char* v = std::getenv("RF_OCCLUDER_HINT_LEVELS")) m.occluderHintLevels = static_cast<uint32_t>(std::clamp(std::atoi(v), 0, 8)); // experiments
+        }
+        m.leafBoxesValid = leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n, m.occluderHintLevels);
         if (!m.leafBoxesValid)
         {
             // leaves that share a first triangle (hand-made tree): one slot cannot hold two exact boxes, so the layouts that cull a leaf by

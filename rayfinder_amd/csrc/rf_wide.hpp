@@ -188,8 +188,25 @@ inline uint16_t halfDirected(float v, bool down, bool& ok)
 // Returns false when two leaves claim the same first-triangle slot (a hand-made tree: validateScene only checks that leaf ranges lie inside the
 // triangle array, not that they are disjoint): the later leaf's box would overwrite the earlier one's, the half-precision / local-grid kernels
 // would cull with a box that is not the leaf's, and the image would depend on the record layout.  The caller keeps those layouts off then.
-inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles)
+inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles, uint32_t hintLevels = 0)
 {
+    // record[3].w: what the occluder cache (kTraceWide, any-hit) remembers when a ray is stopped in this leaf.  0: the leaf's own child word.  Else the QUAD record
+    // index (numbering of buildWide: the interior nodes at even depth, in node order) of the record `hintLevels` quad levels above the leaf (1: the record that has
+    // the leaf among its entries) -- for scenes whose triangles are small against the sun disc's footprint, where the NEXT ray from the same place is stopped by a
+    // neighbour of this triangle rather than by the triangle itself.  Any record is a valid place to start an any-hit ray: the entry only decides what it looks at first.
+    std::vector<uint32_t> parent, quadIndex, depth;
+    if (hintLevels != 0)
+    {
+        parent.assign(count, 0u), quadIndex.assign(count, 0u), depth.assign(count, 0u);
+        uint32_t numQuad = 0;
+        for (size_t i = 0; i < count; ++i) // (a node's parent precedes it: depth-first order)
+        {
+            if (nodes[i].triangleCount != 0) continue;
+            if ((depth[i] & 1u) == 0u) quadIndex[i] = numQuad++;
+            for (const size_t c : {i + 1, static_cast<size_t>(nodes[i].secondChildOffset)})
+                if (c < count && c > i) parent[c] = static_cast<uint32_t>(i), depth[c] = depth[i] + 1u;
+        }
+    }
     std::vector<bool> claimed(numTriangles, false);
     bool              distinct = true;
     for (size_t i = 0; i < count; ++i)
@@ -198,9 +215,17 @@ inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* t
         if (n.triangleCount == 0 || n.trianglesOffset >= numTriangles) continue;
         if (claimed[n.trianglesOffset]) distinct = false;
         claimed[n.trianglesOffset] = true;
-        float4* t = triangles + 4 * static_cast<size_t>(n.trianglesOffset);
+        float4*  t = triangles + 4 * static_cast<size_t>(n.trianglesOffset);
+        uint32_t hint = 0u;
+        if (hintLevels != 0 && i != 0)
+        {
+            size_t a = parent[i];
+            if (depth[a] & 1u) a = parent[a]; // the record that holds the leaf as an entry
+            for (uint32_t l = 1; l < hintLevels && a != 0; ++l) a = parent[parent[a]];
+            if (a != 0 && quadIndex[a] < (1u << kWideIndexBits)) hint = quadIndex[a]; // (the root is where a ray starts anyway)
+        }
         t[0].w = n.aabb.min.x, t[1].w = n.aabb.min.y, t[2].w = n.aabb.min.z;
-        t[3] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, 0.0f);
+        t[3] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, bitsFloat(hint));
     }
     return distinct;
 }

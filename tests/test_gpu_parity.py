@@ -445,11 +445,16 @@ def test_occluder_cache_is_invisible(atrium, duck_pt):
         off.close()
         assert not np.array_equal(bits(want[0]), bits(want[1]))          # the sun really moved
         assert np.array_equal(bits(want[0]), bits(want[2]))
-        for cells, log2_table in ((1024, 22), (8, 22), (4096, 6)):           # default; whole rooms in one cell; a 64-cell table (every entry fought over)
+        for cells, log2_table in ((1024, 22), (8, 22), (4096, 6), (512, 20)):  # default; whole rooms in one cell; a 64-cell table (every entry fought over); ...
+            # ... and the cache remembering a record two quad levels above the leaf (what a finely tessellated scene gets by itself: the entry is an interior record)
+            os.environ.pop("RF_OCCLUDER_HINT_LEVELS", None)
+            if cells == 512:
+                os.environ["RF_OCCLUDER_HINT_LEVELS"] = "2"
             r, _ = _renderer(pt, W, H, spp, bounces, sky=skies[0])
+            os.environ.pop("RF_OCCLUDER_HINT_LEVELS", None)
             r.set_option("occluder_grid_cells", cells)
             r.set_option("occluder_grid_log2_cells", log2_table)
-            r.set_option("shadow_first_look_from_bounce", {1024: 2, 8: 1, 4096: 0}[cells])   # the default; kShadowFirstLook at every bounce; in-kernel first look only
+            r.set_option("shadow_first_look_from_bounce", {1024: 2, 8: 1, 4096: 0, 512: 2}[cells])   # the default; kShadowFirstLook at every bounce; in-kernel first look only
             for sky, ref in zip(skies, want):                             # cold, then stale, then stale the other way round
                 r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, sky, 0.25))
                 r.render(spp)
@@ -819,7 +824,12 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
                            orc.degrees_to_radians(float(rng.uniform(30, 100))), W / H)
     sky = rf.make_sky(turbidity=float(rng.uniform(1, 10)), albedo=tuple(rng.uniform(0, 1, 3)), sun_zenith_degrees=float(rng.uniform(0, 89)),
                       sun_azimuth_degrees=float(rng.uniform(0, 360)))
-    r, params = _renderer(pt, W, H, spp, bounces, cam=cam, sky=sky, exposure=0.5)
+    if seed % 7 in (3, 6):                                      # the occluder cache remembers a record 1 / 2 / 3 quad levels above the leaf it found the occluder in
+        os.environ["RF_OCCLUDER_HINT_LEVELS"] = str(1 + seed % 3)
+    try:
+        r, params = _renderer(pt, W, H, spp, bounces, cam=cam, sky=sky, exposure=0.5)
+    finally:
+        os.environ.pop("RF_OCCLUDER_HINT_LEVELS", None)
     if seed % 4 != 2:                                           # (default since round 3: the quad records at every bounce)
         r.set_option("quad_from_bounce", 0 if seed % 4 != 1 else 3)
         r.set_option("quad_shadow_from_bounce", 0 if seed % 4 != 3 else 2)
