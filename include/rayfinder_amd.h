@@ -349,7 +349,8 @@ RF_API int rf_build_bvh_gpu(const float* positions36, uint64_t num_triangles, vo
 
 /* Host-only self-check of the render path's BVH record layouts for a flattened tree of 48-B nodes: the 64-byte
  * "children in the parent" records, the compact-capable records and the 32-byte records are built as rf_renderer_create builds
- * them and every variant must decode to the same child planes and child words.  *flags_out: bit 0 = boxes regular (wide
+ * them and every variant must decode to the same child planes and child words.  Also checked: the leaf boxes and the occluder-cache
+ * entries written into the triangle records (every entry is 0 or the index of a quad record that really lies above its leaf, 1 to 3 levels).  *flags_out: bit 0 = boxes regular (wide
  * layout usable), bit 1 = compact-capable records usable, bit 2 = 32-byte records usable.  No reference counterpart. */
 RF_API int rf_check_wide_layouts(const void* nodes48, uint64_t num_nodes, uint32_t* flags_out);
 /* The same check, plus (bit 3 = quad records usable, bit 4 = half-precision quad records usable) the figure the renderer's default

@@ -4107,6 +4107,61 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
     }
     if (!wb.quad.empty())
     {
+        // The leaf boxes and occluder-cache entries leafBoxesIntoTriangles writes into the triangle records (round 4): every leaf's box is its node's; an entry is 0
+        // ("the leaf itself") or the index of a quad record from which the leaf is reached within `levels` steps -- in range, and really above THAT leaf.
+        size_t numTriangles = 0;
+        for (const BvhNode& n : nodes)
+            if (n.triangleCount != 0) numTriangles = std::max(numTriangles, static_cast<size_t>(n.trianglesOffset) + n.triangleCount);
+        const size_t numQuad = wb.quad.size() / 8;
+        for (uint32_t levels = 0; levels <= 3; ++levels)
+        {
+            std::vector<float4> tri(4 * numTriangles, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            const bool          distinct = leafBoxesIntoTriangles(nodes.data(), nodes.size(), tri.data(), numTriangles, levels);
+            if (!distinct) break; // (leaves sharing a first triangle: the renderer keeps the layouts that read these slots off)
+            for (size_t i = 0; i < nodes.size(); ++i)
+            {
+                const BvhNode& n = nodes[i];
+                if (n.triangleCount == 0) continue;
+                const float4* t = &tri[4 * static_cast<size_t>(n.trianglesOffset)];
+                if (floatBits(t[0].w) != floatBits(n.aabb.min.x) || floatBits(t[1].w) != floatBits(n.aabb.min.y) || floatBits(t[2].w) != floatBits(n.aabb.min.z) ||
+                    floatBits(t[3].x) != floatBits(n.aabb.max.x) || floatBits(t[3].y) != floatBits(n.aabb.max.y) || floatBits(t[3].z) != floatBits(n.aabb.max.z))
+                    fail(i, "leaf box in the triangle record differs from the node's");
+                const uint32_t hint = floatBits(t[3].w);
+                if (levels == 0 && hint != 0u) fail(i, "occluder-cache entry of a leaf: not 0 at level 0");
+                if (hint == 0u) continue;
+                if (hint >= numQuad) fail(i, "occluder-cache entry of a leaf: quad record index out of range");
+                std::vector<uint32_t> frontier{hint};
+                bool                  found = false;
+                for (uint32_t l = 0; l < levels && !found; ++l)
+                {
+                    std::vector<uint32_t> next;
+                    for (const uint32_t r : frontier)
+                    {
+                        const float4*  q = &wb.quad[8 * static_cast<size_t>(r)];
+                        const uint32_t raw[4] = {floatBits(q[6].x), floatBits(q[6].y), floatBits(q[6].z), floatBits(q[6].w)};
+                        for (int e = 0; e < 4; ++e)
+                        {
+                            if (raw[e] == kQuadEmpty) continue;
+                            const uint32_t w = e == 2 ? raw[e] : raw[e] & ~(3u << kWideAxisShift); // (entries 0, 1 and 3 carry split axes)
+                            if ((w & kWideLeafBit) == 0u)
+                            {
+                                if (w >= numQuad) fail(i, "occluder-cache entry of a leaf: a record below it names a record out of range");
+                                next.push_back(w);
+                                continue;
+                            }
+                            uint32_t first = w & ((1u << kWideIndexBits) - 1u);
+                            if (((w >> kWideIndexBits) & 7u) == 7u) first = wb.bigLeaves[first].x;
+                            if (first == n.trianglesOffset) found = true;
+                        }
+                    }
+                    frontier.swap(next);
+                }
+                if (!found) fail(i, "occluder-cache entry of a leaf: the leaf is not below the record it names");
+            }
+        }
+    }
+    if (!wb.quad.empty())
+    {
         // Walk the quad records from the root next to the 64-byte records: the entries of a quad record must be the children of
         // the children the plain record of the same node names (a leaf child filling one slot), with the same leaf words, the
         // split axes of both levels, and the skipped child's box must be the union of its entries (what makes the skip exact).
