@@ -3684,7 +3684,7 @@ void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, ui
     pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
     maxPathsPerBatch = m.effectivePaths ? std::min(m.effectivePaths, m.maxPaths) : m.maxPaths;
     sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.wideQuadLocal.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
-                 m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2);
+                 m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2) + m.occluderGrid.count * sizeof(uint32_t); // (the occluder grid: allocated by the first batch)
 }
 uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }
 
