@@ -35,6 +35,10 @@ The JSON line also carries
   cpu_baseline the CPU oracle (a port of the reference's algorithm) on a bounded crop of the same frame and the
                reference's bvh-visualizer primary-ray loop, on this box's host cores (1 thread and all of them).
   parity_crop  the GPU frame of the timed region against the oracle image of that crop.
+  occluder_cache  one more, UNTIMED repeat of the same frames with the any-hit launches' occluder cache off (a shadow
+               ray first visits the leaves that stopped the last rays from its cell of the scene): the rate and the shadow
+               launches' time without it, the whole image compared bit for bit, and how many shadow rays the first look
+               settled.  Every shadow ray is traced and counted in both; one unsharded GPU only (--no-occluder-ablation skips it).
 """
 import argparse
 import json
