@@ -291,8 +291,12 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
         // is asynchronous: the whole frame may still be in front of it) has drained, so a long first frame does not abort a healthy
         // job; what remains inside the limit is the connection set-up, the transfer, and the wait for the slowest peer to finish ITS
         // frame -- ranks own equal tile counts (+-1), so that wait is a fraction of a frame.
+        // A second, much larger cap (kDrainFactor x the limit, from loop entry) covers the case the first clock never starts in: this rank's OWN queued kernels
+        // never drain (a hung or faulted kernel keeps the event at hipErrorNotReady forever) -- the loop would otherwise spin without any limit.
+        constexpr double kDrainFactor = 20.0;
         const double timeout = commTimeoutSeconds();
-        auto         t0 = std::chrono::steady_clock::now();
+        const auto   entered = std::chrono::steady_clock::now();
+        auto         t0 = entered;
         bool         drained = false;
         for (;;)
         {
@@ -318,6 +322,13 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
                 m.comm = nullptr;
                 throw std::runtime_error("RCCL: the first frame exchange did not complete within " + std::to_string(static_cast<int>(timeout)) + " s on rank " +
                                          std::to_string(m.rank) + " (a peer is missing or disagrees about frame size / root); communicator aborted");
+            }
+            if (!drained && timeout > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - entered).count() > kDrainFactor * timeout)
+            {
+                (void)ncclCommAbort(m.comm);
+                m.comm = nullptr;
+                throw std::runtime_error("RCCL: the work queued in front of the first frame exchange did not drain within " + std::to_string(static_cast<int>(kDrainFactor * timeout)) +
+                                         " s on rank " + std::to_string(m.rank) + " (a kernel of this rank's own frame hangs); communicator aborted");
             }
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }

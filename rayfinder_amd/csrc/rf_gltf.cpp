@@ -558,8 +558,9 @@ BufferViewSpan bufferViewSpan(const Document& doc, std::size_t index)
     s.data = buffer.data() + offset;
     s.size = length;
     s.byteStride = bv.has("byteStride") ? bv.at("byteStride").index() : 0;
-    // glTF 2.0 (bufferView.byteStride): 4 .. 252; 0 = "not given" = tightly packed
-    if (s.byteStride != 0 && (s.byteStride < 4 || s.byteStride > 252)) throw std::runtime_error("glTF: buffer view byteStride outside 4..252");
+    // 0 = "not given" = tightly packed.  glTF 2.0 asks for 4 .. 252 and a stride of at least the element; the reference loads through cgltf and never
+    // calls cgltf_validate (gltf_model.cpp), so it reads a file that breaks those rules with the stride it states -- and so does this reader: what keeps a
+    // hostile stride harmless is strideFits() below (the last element must end inside the view), not a range check
     return s;
 }
 
@@ -578,11 +579,7 @@ AccessorView accessorView(const Document& doc, std::size_t index)
     v.stride = elem;
     if (!acc.has("bufferView")) return v;
     const BufferViewSpan bv = bufferViewSpan(doc, acc.at("bufferView").index());
-    if (bv.byteStride != 0)
-    {
-        if (bv.byteStride < elem) throw std::runtime_error("glTF: buffer view byteStride smaller than the accessor's element");
-        v.stride = bv.byteStride;
-    }
+    if (bv.byteStride != 0) v.stride = bv.byteStride; // (smaller than the element: overlapping reads, as cgltf does them)
     const std::size_t offset = acc.has("byteOffset") ? acc.at("byteOffset").index() : 0;
     if (v.count && (offset > bv.size || !strideFits(v.count, v.stride, elem, bv.size - offset))) throw std::runtime_error("glTF: accessor exceeds its buffer view");
     v.base = bv.data + offset;

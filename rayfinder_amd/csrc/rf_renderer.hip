@@ -910,7 +910,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // kDepth + kEvict * kSpillBlocks pending entries still takes the scalar traversal.  The number of evicted entries rides in bits 8.. of negMask.
     constexpr bool kSpill = !kRefCount;
     constexpr int  kEvict = kDepth >= 9 ? 6 : (kDepth > 4 ? kDepth - 3 : 1), kSpillBlocks = 36 / kEvict; // (6 x 6 by default; the stress build with a 6-entry LDS stack -- make EXP=RF_EXP_STACK=6 -- evicts 3 at a time, all the time)
-    static_assert(kEvict <= kDepth - 3, "after an eviction a quad step's three pushes must fit");
+    static_assert(kEvict >= 3 && kEvict <= kDepth - 2, "a quad step checks the bound once (depth < kDepth - 2) and then pushes up to three entries: an eviction must make room for all three");
     using SpillEntry = std::conditional_t<kStackWordsOnly, uint32_t, uint2>;
     SpillEntry spillBuf[kSpill ? kEvict * kSpillBlocks : 1];
     const auto slotS = [&](int i) -> int { return kPtrStack ? spBase + i * kSpStep : i; };
@@ -3285,6 +3285,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.sortScale = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(kSortBins) << 32) / std::max<uint64_t>(sceneView.positionAttributes.size(), 1), 0xFFFFFFFFull));
 
     // 48-B reference nodes -> 32-B device nodes
+    std::vector<uint32_t> quadIndexOfNode; // buildWide's numbering of the quad records, for the occluder-cache entries of the leaves (leafBoxesIntoTriangles)
     {
         std::vector<float4> packed(2 * sceneView.bvhNodes.size());
         for (size_t i = 0; i < sceneView.bvhNodes.size(); ++i)
@@ -3300,6 +3301,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         }
         m.nodes.upload(packed.data(), packed.size());
         const WideBuild wb = buildWide(sceneView.bvhNodes.data(), sceneView.bvhNodes.size());
+        quadIndexOfNode = wb.quadIndexOfNode;
         m.wideNodes.upload(wb.nodes.data(), wb.nodes.size());
         m.bigLeaves.upload(wb.bigLeaves.data(), wb.bigLeaves.size());
         m.wide.nodes = m.wideNodes.ptr;
@@ -3391,7 +3393,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             }
             if (const char* v = std::getenv("RF_OCCLUDER_HINT_LEVELS")) m.occluderHintLevels = static_cast<uint32_t>(std::clamp(std::atoi(v), 0, 8)); // experiments
         }
-        m.leafBoxesValid = leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n, m.occluderHintLevels);
+        m.leafBoxesValid = leafBoxesIntoTriangles(sceneView.bvhNodes.data(), sceneView.bvhNodes.size(), padded.data(), n, m.occluderHintLevels, &quadIndexOfNode);
         if (!m.leafBoxesValid)
         {
             // leaves that share a first triangle (hand-made tree): one slot cannot hold two exact boxes, so the layouts that cull a leaf by
@@ -4116,7 +4118,7 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
         for (uint32_t levels = 0; levels <= 3; ++levels)
         {
             std::vector<float4> tri(4 * numTriangles, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-            const bool          distinct = leafBoxesIntoTriangles(nodes.data(), nodes.size(), tri.data(), numTriangles, levels);
+            const bool          distinct = leafBoxesIntoTriangles(nodes.data(), nodes.size(), tri.data(), numTriangles, levels, &wb.quadIndexOfNode);
             if (!distinct) break; // (leaves sharing a first triangle: the renderer keeps the layouts that read these slots off)
             for (size_t i = 0; i < nodes.size(); ++i)
             {

@@ -157,6 +157,11 @@ struct WideBuild
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
     bool                boxesRegular = true; // every child box finite (|x| < 1e30) with min <= max (see slabPair)
+    // every child's box lies inside its parent's (true for boxes built as unions; a hand-made tree may break it).  What the two-levels-per-step records, the
+    // conservative layouts' "exact box at the leaf" and the occluder cache's "a leaf whose own box passes is one the reference reaches" all rest on: without it the
+    // renderer keeps to the binary records, which repeat the reference's test node by node
+    bool                boxesNested = true;
+    std::vector<uint32_t> quadIndexOfNode; // per reference node: its quad record, kQuadEmpty for the nodes that have none (leaves, odd levels, unreachable nodes)
 };
 
 // Host: 48-byte reference nodes -> wide records.
@@ -188,23 +193,30 @@ inline uint16_t halfDirected(float v, bool down, bool& ok)
 // Returns false when two leaves claim the same first-triangle slot (a hand-made tree: validateScene only checks that leaf ranges lie inside the
 // triangle array, not that they are disjoint): the later leaf's box would overwrite the earlier one's, the half-precision / local-grid kernels
 // would cull with a box that is not the leaf's, and the image would depend on the record layout.  The caller keeps those layouts off then.
-inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles, uint32_t hintLevels = 0)
+inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* triangles /* 4 float4 per triangle */, size_t numTriangles, uint32_t hintLevels = 0,
+                                   const std::vector<uint32_t>* quadIndexOfNode = nullptr)
 {
     // record[3].w: what the occluder cache (kTraceWide, any-hit) remembers when a ray is stopped in this leaf.  0: the leaf's own child word.  Else the QUAD record
-    // index (numbering of buildWide: the interior nodes at even depth, in node order) of the record `hintLevels` quad levels above the leaf (1: the record that has
-    // the leaf among its entries) -- for scenes whose triangles are small against the sun disc's footprint, where the NEXT ray from the same place is stopped by a
-    // neighbour of this triangle rather than by the triangle itself.  Any record is a valid place to start an any-hit ray: the entry only decides what it looks at first.
-    std::vector<uint32_t> parent, quadIndex, depth;
-    if (hintLevels != 0)
+    // index of the record `hintLevels` quad levels above the leaf (1: the record that has the leaf among its entries) -- for scenes whose triangles are small against
+    // the sun disc's footprint, where the NEXT ray from the same place is stopped by a neighbour of this triangle rather than by the triangle itself.  Any record is
+    // a valid place to start an any-hit ray: the entry only decides what it looks at first.
+    // The index comes from buildWide's OWN numbering (WideBuild::quadIndexOfNode: the nodes reachable from the root in two-level steps) and the ancestors from a walk
+    // that starts at the root: a hand-made tree may hold interior nodes no parent reaches, or children with two parents (validateScene accepts both), and a
+    // numbering recomputed here from node order and depth named the wrong record -- or one past the end -- for them.  A leaf the walk does not reach, or
+    // whose ancestor is not a quad record, remembers itself (0).
+    std::vector<uint32_t> parent;
+    const bool            hints = hintLevels != 0 && quadIndexOfNode != nullptr && quadIndexOfNode->size() == count && count > 0 && nodes[0].triangleCount == 0;
+    if (hints)
     {
-        parent.assign(count, 0u), quadIndex.assign(count, 0u), depth.assign(count, 0u);
-        uint32_t numQuad = 0;
-        for (size_t i = 0; i < count; ++i) // (a node's parent precedes it: depth-first order)
+        parent.assign(count, kQuadEmpty);
+        std::vector<uint32_t> todo{0u};
+        while (!todo.empty())
         {
+            const uint32_t i = todo.back();
+            todo.pop_back();
             if (nodes[i].triangleCount != 0) continue;
-            if ((depth[i] & 1u) == 0u) quadIndex[i] = numQuad++;
-            for (const size_t c : {i + 1, static_cast<size_t>(nodes[i].secondChildOffset)})
-                if (c < count && c > i) parent[c] = static_cast<uint32_t>(i), depth[c] = depth[i] + 1u;
+            for (const size_t c : {static_cast<size_t>(i) + 1, static_cast<size_t>(nodes[i].secondChildOffset)})
+                if (c < count && c > i && parent[c] == kQuadEmpty) parent[c] = i, todo.push_back(static_cast<uint32_t>(c));
         }
     }
     std::vector<bool> claimed(numTriangles, false);
@@ -217,12 +229,17 @@ inline bool leafBoxesIntoTriangles(const BvhNode* nodes, size_t count, float4* t
         claimed[n.trianglesOffset] = true;
         float4*  t = triangles + 4 * static_cast<size_t>(n.trianglesOffset);
         uint32_t hint = 0u;
-        if (hintLevels != 0 && i != 0)
+        if (hints && i != 0 && parent[i] != kQuadEmpty)
         {
-            size_t a = parent[i];
-            if (depth[a] & 1u) a = parent[a]; // the record that holds the leaf as an entry
-            for (uint32_t l = 1; l < hintLevels && a != 0; ++l) a = parent[parent[a]];
-            if (a != 0 && quadIndex[a] < (1u << kWideIndexBits)) hint = quadIndex[a]; // (the root is where a ray starts anyway)
+            const auto& quadIndex = *quadIndexOfNode;
+            uint32_t    a = parent[i];
+            if (quadIndex[a] == kQuadEmpty && a != 0u) a = parent[a]; // the record that holds the leaf as an entry
+            for (uint32_t l = 1; l < hintLevels && a != 0u && a != kQuadEmpty; ++l)
+            {
+                const uint32_t up = parent[a];
+                a = (up == 0u || up == kQuadEmpty) ? 0u : parent[up];
+            }
+            if (a != 0u && a != kQuadEmpty && quadIndex[a] != kQuadEmpty && quadIndex[a] < (1u << kWideIndexBits)) hint = quadIndex[a]; // (the root is where a ray starts anyway)
         }
         t[0].w = n.aabb.min.x, t[1].w = n.aabb.min.y, t[2].w = n.aabb.min.z;
         t[3] = make_float4(n.aabb.max.x, n.aabb.max.y, n.aabb.max.z, bitsFloat(hint));
@@ -334,11 +351,15 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         const float hi[6] = {a.aabb.max.x, a.aabb.max.y, a.aabb.max.z, b.aabb.max.x, b.aabb.max.y, b.aabb.max.z};
         for (int k = 0; k < 6; ++k)
             if (!(std::fabs(lo[k]) < 1e30f && std::fabs(hi[k]) < 1e30f && lo[k] <= hi[k])) out.boxesRegular = false;
+        const float nlo[3] = {n.aabb.min.x, n.aabb.min.y, n.aabb.min.z}, nhi[3] = {n.aabb.max.x, n.aabb.max.y, n.aabb.max.z};
+        for (int k = 0; k < 6; ++k)
+            if (!(lo[k] >= nlo[k % 3] && hi[k] <= nhi[k % 3])) out.boxesNested = false;
     }
     // ---- quad records: the interior nodes reachable from the root in steps of two levels, numbered in node (= depth-first) order
-    if (numInterior > 0 && out.boxesRegular)
+    if (numInterior > 0 && out.boxesRegular && out.boxesNested)
     {
-        std::vector<uint32_t> quadIndex(count, kQuadEmpty);
+        std::vector<uint32_t>& quadIndex = out.quadIndexOfNode;
+        quadIndex.assign(count, kQuadEmpty);
         {
             std::vector<uint8_t>  member(count, 0);
             std::vector<uint32_t> todo{0u};
@@ -410,8 +431,8 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
         }
     }
     if (out.bigLeaves.empty()) out.bigLeaves.push_back(make_uint2(0, 0));
-    if (!out.boxesRegular || numInterior == 0) out.quadUsable = false;
-    if (!out.quadUsable) out.quad.clear();
+    if (!out.boxesRegular || !out.boxesNested || numInterior == 0) out.quadUsable = false;
+    if (!out.quadUsable) out.quad.clear(), out.quadIndexOfNode.clear();
     if (!out.quad.empty())
     {
         // ---- half-precision quad records (see WideBuild::quadHalf)

@@ -12,6 +12,7 @@
 //   gather12<T>   per lane: one dwordx3 of a random 16-B element (path-state streams read at refill)
 //   scatter16<T>  per lane: one 16-B store to a random 16-B element (the hit record written per finished ray)
 //   fill16<T>     coalesced 16-B stores of the whole table
+//   gatherWide<T, BYTES, CHAINS>  (`fetch_calib wide`) random BYTES-byte records, whole record read, CHAINS chains per lane
 // and two cooperative forms of the record fetch (design probes for kTraceWide: how many vector-L1 accesses does a
 // record cost when the lanes of a pair / quad address the SAME line in one instruction?):
 //   gatherPair<T>    lanes 2p, 2p+1 share one record: each loads its 32-byte half (2 x dwordx4), halves are
@@ -27,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x)                                                                                   \
@@ -157,6 +159,41 @@ __global__ __launch_bounds__(256) void gatherQuadLds(const float4* __restrict__ 
     if (acc == 1.2345e-30f) out[0] = acc;
 }
 
+// Round 5: does a WIDER record raise the random-gather rate from HBM?  gatherWide<T, BYTES, CHAINS>: per lane, CHAINS independent
+// dependent-fetch chains, each step reading all BYTES (16-B pieces: BYTES / 16 dwordx4) of a random BYTES-aligned record.  BYTES = 64 is gather56's
+// pattern with the whole line read; 128 / 256 = what an 8-wide / 16-wide BVH record would ask for.  CHAINS = 2 doubles the requests in flight per
+// lane (is the 64-B rate latency-bound or bound by the memory system?).
+template<int T, int BYTES, int CHAINS>
+__global__ __launch_bounds__(256) void gatherWide(const float4* __restrict__ table, uint32_t mask, int iters, float* out)
+{
+    constexpr int  kPieces = BYTES / 16;
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    float          acc = 0.0f;
+    uint32_t       idx[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) idx[c] = hash32(tid * CHAINS + c) & mask;
+    for (int it = 0; it < iters; ++it)
+    {
+        float4 v[CHAINS][kPieces];
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c)
+        {
+            const float4* r = table + kPieces * static_cast<size_t>(idx[c]);
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) v[c][k] = r[k];
+        }
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c)
+        {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) acc += v[c][k].x, w += __float_as_uint(v[c][k].w);
+            idx[c] = hash32(idx[c] + w + it) & mask;
+        }
+    }
+    if (acc == 1.2345e-30f) out[0] = acc;
+}
+
 template<int T>
 __global__ __launch_bounds__(256) void gather12(const float4* __restrict__ table, uint32_t mask, int iters, float* out)
 {
@@ -246,13 +283,53 @@ void runTable(float4* table, float* out, Timer& tm)
     std::fflush(stdout);
 }
 
-int main()
+template<int T, int BYTES, int CHAINS>
+void runWideOne(float4* table, float* out, Timer& tm, int blocks)
+{
+    const size_t   bytes = 1ull << T;
+    const uint32_t mask = static_cast<uint32_t>(bytes / BYTES - 1);
+    const int      iters = 256 * 64 / BYTES * (CHAINS == 1 ? 2 : 1);
+    const double   records = blocks * 256.0 * iters * CHAINS;
+    float          best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep)
+    {
+        tm.start(); hipLaunchKernelGGL((gatherWide<T, BYTES, CHAINS>), dim3(blocks), dim3(256), 0, 0, table, mask, iters, out); const float ms = tm.stop();
+        best = ms < best ? ms : best;
+    }
+    std::printf("{\"kernel\": \"gatherWide<%d,%d,%d>\", \"blocks\": %d, \"records\": %.0f, \"bytes\": %.0f, \"ms\": %.4f, \"Grecords_per_s\": %.2f, \"GBps\": %.1f}\n", T, BYTES, CHAINS, blocks,
+                records, records * BYTES, best, records / best * 1e-6, records * BYTES / best * 1e-6);
+    std::fflush(stdout);
+}
+template<int T>
+void runWide(float4* table, float* out, Timer& tm)
+{
+    const size_t n16 = (1ull << T) / 16;
+    hipLaunchKernelGGL(fill16<T>, dim3(2048), dim3(256), 0, 0, table, n16);
+    for (const int blocks : {2048, 4096}) // 8 / 16 waves per SIMD resident (the second: as many as the registers allow)
+    {
+        runWideOne<T, 64, 1>(table, out, tm, blocks);
+        runWideOne<T, 64, 2>(table, out, tm, blocks);
+        runWideOne<T, 128, 1>(table, out, tm, blocks);
+        runWideOne<T, 128, 2>(table, out, tm, blocks);
+        runWideOne<T, 256, 1>(table, out, tm, blocks);
+    }
+}
+
+int main(int argc, char** argv)
 {
     float4* table;
     float*  out;
     CHECK(hipMalloc(&table, 1ull << 33));
     CHECK(hipMalloc(&out, 64));
     Timer tm;
+    if (argc > 1 && std::string(argv[1]) == "wide") // only the record-width probe (random gathers of 64 / 128 / 256-byte records)
+    {
+        runWide<25>(table, out, tm);
+        runWide<31>(table, out, tm);
+        runWide<33>(table, out, tm);
+        CHECK(hipDeviceSynchronize());
+        return 0;
+    }
     runTable<25>(table, out, tm);
     runTable<30>(table, out, tm);
     runTable<33>(table, out, tm);
