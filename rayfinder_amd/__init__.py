@@ -159,7 +159,7 @@ def check_wide_layouts(nodes):
     nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
     flags = C.c_uint32(0)
     check(lib.rf_check_wide_layouts(_ptr(nodes), nodes.shape[0], C.byref(flags)))
-    return {"regular": bool(flags.value & 1), "compact": bool(flags.value & 2), "hot": bool(flags.value & 4), "quad": bool(flags.value & 8), "quad_half": bool(flags.value & 16), "quad_local": bool(flags.value & 32)}
+    return {"regular": bool(flags.value & 1), "compact": bool(flags.value & 2), "hot": bool(flags.value & 4), "quad": bool(flags.value & 8), "quad_half": bool(flags.value & 16), "quad_local": bool(flags.value & 32), "oct": bool(flags.value & 64)}
 
 
 def wide_layout_stats(nodes):

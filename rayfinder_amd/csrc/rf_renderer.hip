@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -251,6 +252,26 @@ __device__ __forceinline__ uint32_t waveMax(uint32_t v)
     for (int off = 32; off > 0; off >>= 1) v = max(v, static_cast<uint32_t>(__shfl_down(v, off)));
     return v;
 }
+
+// Inclusive scan over the 64 lanes of a wave, DPP only (no LDS): row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 / 31 across them.
+// Must run with all 64 lanes enabled.  MAX: running maximum (of unsigned values; identity 0), else running sum.
+template<bool MAX>
+__device__ __forceinline__ uint32_t waveScanInclusive(uint32_t x)
+{
+    const auto step = [&](auto ctrl, auto rowMask) {
+        const uint32_t y = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), decltype(ctrl)::value, decltype(rowMask)::value, 0xF, true));
+        x = MAX ? max(x, y) : x + y;
+    };
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{}); // row_shr:1
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{}); // row_shr:2
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{}); // row_shr:4
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{}); // row_shr:8
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}); // row_bcast:15 into rows 1 and 3
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{}); // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ uint32_t laneGather(uint32_t value, uint32_t srcLane) { return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(srcLane << 2), static_cast<int>(value))); }
+__device__ __forceinline__ float    laneGather(float value, uint32_t srcLane) { return __uint_as_float(laneGather(__float_as_uint(value), srcLane)); }
 
 // Z-order key of sample k's R2 point (the temporal part of animatedBlueNoise, wgsl:606-615; only the ORDER matters)
 __device__ __forceinline__ uint32_t sampleKey(uint32_t firstFrame, uint32_t spp, uint32_t k)
@@ -739,7 +760,8 @@ constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path f
 constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
 constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaves that stopped the last rays from its cell of the scene (see kTraceWide)
 constexpr uint32_t kFlagOccluderNoTry = 32u;      // ... the launch runs behind kShadowFirstLook: its rays have had their first look, it only records what stopped them
-constexpr uint32_t kFlagNoRayCount = 64u;         // the launch's rays are counted elsewhere (kShadowFirstLook counted the whole queue)
+constexpr uint32_t kFlagNoRayCount = 64u;
+constexpr uint32_t kFlagDenseLeafShift = 8u;       // bits 11..8: leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (0: never; see kTraceWide)         // the launch's rays are counted elsewhere (kShadowFirstLook counted the whole queue)
 #if defined(RF_EXP_OCC_SLOTS)
 constexpr int kOccSlots = RF_EXP_OCC_SLOTS;
 #else
@@ -827,7 +849,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
     constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
     static_assert(!(COMPACT != 0 && COUNT), "the compact-record and quad-record variants have no counting build");
-    static_assert(COMPACT >= 0 && COMPACT <= 5, "0: 64-byte records, 1: compact-capable, 2: 32-byte, 3: quad, 4: half-precision quad, 5: local-grid quad");
+    static_assert(COMPACT >= 0 && COMPACT <= 6, "0: 64-byte records, 1: compact-capable, 2: 32-byte, 3: quad, 4: half-precision quad, 5: local-grid quad, 6: local-grid oct (closest-hit)");
+    static_assert(!(COMPACT == 6 && ANY_HIT), "the oct records serve the closest-hit launches (the any-hit launches start at occluder-cache entries that name quad records)");
+    constexpr bool kConservative = COMPACT == 4 || COMPACT == 5 || COMPACT == 6; // interior tests accept a superset; every leaf's EXACT box is applied at the leaf
     __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
@@ -849,7 +873,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     constexpr bool kOccluderCache = ANY_HIT && !COUNT && (COMPACT == 3 || COMPACT == 4 || COMPACT == 5);
     // (the exact quad records test a leaf's box at its parent's step, not at the leaf: a launch of theirs that uses the cache applies the box at the leaf too, as
     // the conservative layouts always do -- a second, identical test for the leaves reached by the walk, THE test for the ones visited first)
-    const bool     leafBoxAtLeaf = COMPACT == 4 || COMPACT == 5 || (COMPACT == 3 && kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr);
+    const bool     leafBoxAtLeaf = kConservative || (COMPACT == 3 && kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr);
     const bool     occluderCache = kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr;
     const auto occluderCell = [&](float ox, float oy, float oz) -> uint32_t { return occluderCellIndex(wide, ox, oy, oz); };
     constexpr uint32_t kNegTriedHint = 16u; // negMask: the ray started at a hint
@@ -879,6 +903,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // COMPACT == 4 (half-precision quad records): b = -(o / d) per axis, the addend of t' = fma(plane', 1/d, b)
     float hbx = 0.0f, hby = 0.0f, hbz = 0.0f;
     uint32_t lselX = 0u, lselY = 0u, lselZ = 0u; // COMPACT == 5 (local-grid quad records): per-axis v_perm_b32 selectors (see localEntryBounds)
+    uint32_t octKey = 0u; // COMPACT == 6 (oct records): bits 5..0 = 16 x the field of the record's order table this ray reads, bits 8.. = 0x7777 when its positions are flipped (WideBuild::oct)
     uint32_t hrot = 0u; // ... and (1/d.x < 0) << 4 | (1/d.y < 0) << 12 | (1/d.z < 0) << 20: rotate amounts that bring a plane word's NEAR plane into its low half
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
@@ -1089,7 +1114,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 rayTris = 0;
                 rayStackHigh = 0;
                 needScalar = rayClass == kRayIrregular;
-                if constexpr (COMPACT == 4 || COMPACT == 5)
+                if constexpr (kConservative)
                 {
                     // the margin of the half-precision / local-grid planes covers origins within wide.originBound and 1/direction components of
                     // ordinary magnitude (or +-inf: those axes drop out as NaNs): anything else takes the scalar traversal
@@ -1111,6 +1136,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     hbz = -(o.z * pr.iZ);
                     hrot = (ray.negX << 4) | (ray.negY << 12) | (ray.negZ << 20);
                     lselX = ray.negX ? 0x00040005u : 0x00050004u, lselY = ray.negY ? 0x00040005u : 0x00050004u, lselZ = ray.negZ ? 0x00040005u : 0x00050004u;
+                    const uint32_t signXY = ray.negX | (ray.negY << 1);
+                    octKey = ray.negZ ? ((16u * (3u - signXY)) | (0x7777u << 8)) : 16u * signXY;
                 }
                 float      rootTMin;
                 const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
@@ -1158,7 +1185,84 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             if (static_cast<int32_t>(node) >= 0)
             {
                 if (kPhase) ++recordFetches;
-                if constexpr (COMPACT == 3 || COMPACT == 4 || COMPACT == 5)
+                if constexpr (COMPACT == 6)
+                {
+                    // ---- oct records (rf_wide.hpp, WideBuild::oct): the boxes of the node's (up to) eight GREAT-GRANDCHILDREN as 8-bit planes on the record's own
+                    // grid -- three levels of the reference's tree per dependent fetch, seven loads from one 128-byte line.  CONSERVATIVE tests (the leaf phase
+                    // applies the exact boxes).  No ordering network: the record tabulates the position at which each slot is visited for the ray's sign pattern;
+                    // the slots that can still be hit go onto the stack AT THEIR PLACE in that order (a slot's place = the number of hit slots visited after it:
+                    // one popcount of the hit mask in visit order), and the first one comes straight back off the top.
+                    const uint4* n = wide.oct + 8 * static_cast<size_t>(node);
+                    const uint4  v0 = n[0], v1 = n[1], vx = n[2], vy = n[3], vz = n[4], wa = n[5], wb = n[6];
+                    const float  ax = __uint_as_float(v0.w) * pr.iXY.x, ay = __uint_as_float(v1.x) * pr.iXY.y, az = __uint_as_float(v1.y) * pr.iZ;
+                    const float  bx = __builtin_fmaf(-1024.0f, ax, (__uint_as_float(v0.x) - pr.oXY.x) * pr.iXY.x), by = __builtin_fmaf(-1024.0f, ay, (__uint_as_float(v0.y) - pr.oXY.y) * pr.iXY.y),
+                                bz = __builtin_fmaf(-1024.0f, az, (__uint_as_float(v0.z) - pr.oZ) * pr.iZ);
+                    float tq[8], fq[8];
+                    localEntryBounds<0>(vx.x, vy.x, vz.x, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[0], fq[0]);
+                    localEntryBounds<1>(vx.x, vy.x, vz.x, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[1], fq[1]);
+                    localEntryBounds<0>(vx.y, vy.y, vz.y, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[2], fq[2]);
+                    localEntryBounds<1>(vx.y, vy.y, vz.y, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[3], fq[3]);
+                    localEntryBounds<0>(vx.z, vy.z, vz.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[4], fq[4]);
+                    localEntryBounds<1>(vx.z, vy.z, vz.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[5], fq[5]);
+                    localEntryBounds<0>(vx.w, vy.w, vz.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[6], fq[6]);
+                    localEntryBounds<1>(vx.w, vy.w, vz.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[7], fq[7]);
+                    const uint32_t words[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                    // visit positions of the eight slots for this ray's direction signs: four nibbles, slot (c, g, 0) at nibble 2 c + g, slot (c, g, 1) at that ^ 1
+                    const unsigned long long table = (static_cast<unsigned long long>(v1.w) << 32) | v1.z;
+                    const uint32_t           ord = static_cast<uint32_t>(table >> (octKey & 63u)) ^ (octKey >> 8);
+                    // slot e can still be hit  <=>  near <= far && far > 0 && near < rayTMax  <=>  max(near, tiny) <= min(far, pred(rayTMax)): one subtraction whose SIGN
+                    // is the answer (x - y of two different floats is never zero, denormals are kept), shifted straight into the miss mask at the slot's position
+                    const float tiny = __uint_as_float(1u), predTMax = __uint_as_float(__float_as_uint(rayTMax) - 1u); // (rayTMax > 1e-5: a positive normal number)
+                    uint32_t    pos[8], miss = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        pos[2 * j] = (ord >> (4 * j)) & 7u;
+                        pos[2 * j + 1] = pos[2 * j] ^ 1u;
+                    }
+                    float gap[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                    {
+                        gap[e] = isaMin(fq[e], predTMax) - isaMax(tq[e], tiny);
+                        miss |= (__float_as_uint(gap[e]) >> 31) << pos[e];
+                    }
+                    const uint32_t hits = ~miss & 0xFFu; // bit p: the slot visited p-th can still be hit
+                    if (hits != 0u)
+                    {
+                        const int need = __popc(hits);
+                        bool      room = true;
+                        if constexpr (kPtrStack)
+                        {
+                            while (room && stackSize + need * kSpStep > kSpLimit + spBase) room = (stackSize - spBase) >= kEvict * kSpStep && evict();
+                        }
+                        else
+                        {
+                            while (room && stackSize + need > kSpLimit) room = stackSize >= kEvict && evict();
+                        }
+                        if (__builtin_expect(room, 1))
+                        {
+                            const uint32_t later = hits >> 1;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (!(__float_as_uint(gap[e]) >> 31))
+                                {
+                                    const int rank = __popc(later >> pos[e]); // hit slots visited after this one: they lie below it
+                                    if constexpr (kStackWordsOnly) stackAt(stackSize + rank * kSpStep).x = words[e];
+                                    else stackAt(stackSize + rank * kSpStep) = make_uint2(words[e], __float_as_uint(tq[e]));
+                                }
+                            stackSize += need * kSpStep;
+                            popNext();
+                        }
+                        else
+                        {
+                            needScalar = true;
+                            node = kNodeDone;
+                        }
+                    }
+                    else popNext();
+                }
+                else if constexpr (COMPACT == 3 || COMPACT == 4 || COMPACT == 5)
                 {
                     // ---- quad records (rf_wide.hpp): the boxes of the node's (up to) four grandchildren in ONE 128-byte record --
                     // two levels of the reference's tree per dependent fetch.  Entries 0,1 belong to the first child, 2,3 to the
@@ -1612,7 +1716,146 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull) ++phaseLeafWave;
 #endif
         uint32_t occluderWord = 0u; // kOccluderCache: the leaf in which this lane has just found an occluder
-        if (node - kWideLeafBit < kNodeDone - kWideLeafBit)
+        // ---- Leaf phase over dense (lane, triangle) pairs (round 5).  The loop further down tests triangle i of every parked lane's leaf in trip i: a phase lasts as
+        // long as its LONGEST leaf, and on a scene whose leaves differ in length (the atrium with clutter: 1 ... 12 triangles, 7.2 tests per closest-hit ray) most trips
+        // run for a handful of lanes.  When a parked lane's leaf holds kDenseMin triangles or more, the phase runs over PAIRS instead: the lanes' triangle counts are
+        // prefix-summed, pair p = (owner lane, triangle p - offset[owner]) goes to lane p mod 64 of trip p / 64 (whole leaves per trip), which fetches the owner's ray
+        // through ds_bpermute and tests that one triangle against the owner's rayTMax AT ENTRY; the owner then walks through the hits among its own pairs in triangle
+        // order with the reference's `t < rayTMax` (wgsl:385-402).  Same result as the sequential walk: a triangle the walk accepts has t below the rayTMax of that
+        // moment <= the entry value, so it is among the hits here; a hit here that the walk would reject (t >= the rayTMax an earlier triangle left) is rejected by the
+        // owner's own walk over the hits, in the same order with the same comparison.  Any-hit: a leaf with a hit among its pairs stops the ray.
+        // The block is self-contained (its own leaf decode and exact box test) so that the loop below keeps its registers to itself: what it needs of a leaf's
+        // first triangle record is live only inside its own branch.
+        unsigned long long denseDone = 0ull; // lanes whose leaf this block has dealt with
+        if constexpr (!COUNT)
+        {
+            const uint32_t     kDenseMin = (flags >> kFlagDenseLeafShift) & 15u;
+            constexpr uint32_t kDenseMaxLeaf = 16u; // (longer leaves keep the loop below)
+            const bool         atLeafD = node - kWideLeafBit < kNodeDone - kWideLeafBit;
+            // (decided on the count field of the leaf word alone: 7 = a big leaf of 8 or more)
+            if (kDenseMin != 0u && __ballot(atLeafD && ((node >> kWideIndexBits) & 7u) + 1u >= kDenseMin) != 0ull)
+            {
+                uint32_t firstD = 0u, cnt = 0u, hintD = 0u;
+                bool     rejected = false;
+                if (atLeafD)
+                {
+                    firstD = node & ((1u << kWideIndexBits) - 1u), cnt = ((node >> kWideIndexBits) & 7u) + 1u;
+                    if (cnt == 8u)
+                    {
+                        const uint2 big = wide.bigLeaves[firstD];
+                        firstD = big.x;
+                        cnt = big.y;
+                    }
+                    if (cnt > kDenseMaxLeaf) cnt = 0u; // not taken here
+                    else if (leafBoxAtLeaf)
+                    {
+                        // the leaf's exact box, as the loop below applies it (the reference's test at the leaf: same formula, the rayTMax of this moment)
+                        const float* t0 = reinterpret_cast<const float*>(scene.triangles + kTriStride * static_cast<size_t>(firstD));
+                        const float  loX = t0[3], loY = t0[7], loZ = t0[11];
+                        const float4 hi = *reinterpret_cast<const float4*>(t0 + 12);
+                        if constexpr (kOccluderCache) hintD = __float_as_uint(hi.w);
+                        PackedRay exact = pr;
+                        if (kConservative && __builtin_expect((negMask & 8u) != 0u, 0))
+                        {
+                            const float inf = __uint_as_float(0x7F800000u);
+                            if (fabsf(exact.iXY.x) == 1e30f) exact.iXY.x = __builtin_copysignf(inf, exact.iXY.x);
+                            if (fabsf(exact.iXY.y) == 1e30f) exact.iXY.y = __builtin_copysignf(inf, exact.iXY.y);
+                            if (fabsf(exact.iZ) == 1e30f) exact.iZ = __builtin_copysignf(inf, exact.iZ);
+                        }
+                        float bn, bf;
+                        bool  boxNaN;
+                        slabSingleBounds(exact, loX, loY, loZ, hi.x, hi.y, hi.z, bn, bf, boxNaN);
+                        if (__builtin_expect((negMask & 8u) != 0u && boxNaN, 0)) cnt = 0u; // (class B ray with a 0 * inf product: left to the loop below, which sends it to the scalar traversal)
+                        else if (!(bn <= bf && bf > 0.0f && bn < rayTMax))
+                        {
+                            cnt = 0u; // the reference rejects this leaf: no triangle is tested
+                            rejected = true;
+                        }
+                    }
+                }
+                bool dealt = rejected; // this lane's leaf is finished with (rejected by its box, or its pairs have been tested)
+                bool stopped = false;                    // ANY_HIT: a pair of this lane's leaf was hit
+                const uint32_t incl = waveScanInclusive<false>(cnt), off = incl - cnt;
+                const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+                // (worth it when the pairs need fewer trips than the longest leaf has triangles: a pair trip costs about one and a half triangle trips)
+                const uint32_t pairTrips = (total + 63u) / 64u;
+                const bool     goDense = (pairTrips <= 1u) || (pairTrips <= 2u && __ballot(cnt >= 5u) != 0ull) || (pairTrips <= 4u && __ballot(cnt >= 9u) != 0ull);
+                if (goDense)
+                {
+                    const float oX = pr.oXY.x, oY = pr.oXY.y, oZ = pr.oZ;
+                    uint32_t    base = 0u;
+                    while (base < total) // (wave-uniform)
+                    {
+                        // this trip: the leaves that start at or behind `base` and END within the next 64 pairs
+                        const unsigned long long over = __ballot(cnt != 0u && off >= base && off + cnt > base + 64u);
+                        const uint32_t           next = over != 0ull ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(off), __builtin_ctzll(over))) : total;
+                        const bool               inTrip = cnt != 0u && off >= base && off < next;
+                        const uint32_t           segLo = off - base; // (meaningful for inTrip lanes)
+                        // owner of pair slot q: every leaf of the trip drops lane + 1 at the slot of its first pair (ds_permute_b32; the other lanes drop a 0 at a slot
+                        // that starts no leaf -- the highest lane wins a slot, and only zeros compete there), then a running maximum fills the leaf's other slots
+                        const uint32_t           pairs = next - base;
+                        const unsigned long long longer = __ballot(inTrip && cnt >= 2u);
+                        const uint32_t           dump = (pairs < 64u || longer == 0ull) ? (pairs & 63u) : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(segLo), __builtin_ctzll(longer))) + 1u; // (64 one-triangle leaves: every lane sends)
+                        const uint32_t           mark = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>((inTrip ? segLo : dump) << 2), static_cast<int>(inTrip ? lane + 1u : 0u)));
+                        const uint32_t           owner = waveScanInclusive<true>(mark) - 1u;
+                        const bool               pairLive = lane < pairs;
+                        const uint32_t           src = pairLive ? owner : lane;
+                        const uint32_t           triOfPair = laneGather(firstD - off, src) + base + lane;
+                        const Vec3               po = vec3(laneGather(oX, src), laneGather(oY, src), laneGather(oZ, src));
+                        const Vec3               pd = vec3(laneGather(rayDir.x, src), laneGather(rayDir.y, src), laneGather(rayDir.z, src));
+                        const float              pTMax = ANY_HIT ? tMax : laneGather(rayTMax, src);
+                        TriangleHit              th{};
+                        bool                     pairHit = false;
+                        if (pairLive)
+                        {
+                            const v3f a = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * static_cast<size_t>(triOfPair));
+                            const v3f b = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * static_cast<size_t>(triOfPair) + 1);
+                            const v3f c = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * static_cast<size_t>(triOfPair) + 2);
+                            pairHit = intersectTriangle(po, pd, vec3(a.x, a.y, a.z), vec3(b.x, b.y, b.z), vec3(c.x, c.y, c.z), pTMax, th);
+                        }
+                        const unsigned long long hitMask = __ballot(pairHit);
+                        uint32_t                 mine = inTrip ? static_cast<uint32_t>(hitMask >> segLo) & ((1u << cnt) - 1u) : 0u; // hits among this lane's own pairs, bit j = triangle first + j
+                        if constexpr (ANY_HIT)
+                        {
+                            if (mine != 0u) stopped = true;
+                        }
+                        else
+                        {
+                            while (__ballot(mine != 0u) != 0ull) // (wave-uniform: the gathers below read other lanes' registers)
+                            {
+                                const uint32_t j = mine != 0u ? static_cast<uint32_t>(__builtin_ctz(mine)) : 0u;
+                                const uint32_t from = mine != 0u ? segLo + j : lane;
+                                const float    tj = laneGather(th.t, from), uj = laneGather(th.u, from), vj = laneGather(th.v, from);
+                                if (mine != 0u && tj < rayTMax)
+                                {
+                                    rayTMax = tj;
+                                    best.u = uj;
+                                    best.v = vj;
+                                    best.triangle = firstD + j;
+                                }
+                                mine &= mine - 1u;
+                            }
+                        }
+                        if (inTrip) dealt = true;
+                        base = next;
+                    }
+                }
+                else dealt = false; // (not worth it: the loop below takes every leaf, the rejected ones included -- it repeats their box test)
+                // what the loop below does with a leaf it has finished with
+                if (dealt)
+                {
+                    if (ANY_HIT && stopped)
+                    {
+                        occluded = true;
+                        if (kOccluderCache) occluderWord = hintD != 0u ? hintD : node;
+                        node = kNodeDone;
+                    }
+                    else popNext();
+                }
+                denseDone = __ballot(dealt);
+            }
+        }
+        if (node - kWideLeafBit < kNodeDone - kWideLeafBit && ((denseDone >> lane) & 1ull) == 0ull) // (a lane the dense phase has moved on may hold its NEXT leaf by now: that one waits for the next phase)
         {
             uint32_t first = node & ((1u << kWideIndexBits) - 1u), n = ((node >> kWideIndexBits) & 7u) + 1u;
             if (n == 8u)
@@ -1643,7 +1886,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 float     bn, bf;
                 bool      boxNaN;
                 PackedRay exact = pr;
-                if ((COMPACT == 4 || COMPACT == 5) && __builtin_expect((negMask & 8u) != 0u, 0))
+                if (kConservative && __builtin_expect((negMask & 8u) != 0u, 0))
                 {
                     // class B: the infinite components of 1/d that the conservative tests replaced by +-1e30 (refill) are infinite again
                     const float inf = __uint_as_float(0x7F800000u);
@@ -2646,7 +2889,7 @@ struct Renderer::Impl
     hipStream_t stream = nullptr;
 
     DeviceBuffer<float4>            nodes, triangles, wideNodes, wideCompact, wideHot, wideOwn, wideQuad;
-    DeviceBuffer<uint4>             wideQuadHalf, wideQuadLocal;
+    DeviceBuffer<uint4>             wideQuadHalf, wideQuadLocal, wideOct;
     DeviceBuffer<uint2>             bigLeaves;
     WideScene                       wide{};
     DeviceBuffer<float4>            attributes; // 4 per triangle (packed, see the constructor)
@@ -2713,6 +2956,8 @@ struct Renderer::Impl
     uint32_t optOccluderCacheBounces = 64; // the any-hit launches of bounces 1..n first visit the leaves their ray's cell of the occluder grid names (kFlagOccluderCache)
     bool     optShadowSignOrder = true; // the half-precision / local-grid shadow launches (VALU bound) visit entries in record order: a cheaper step beats the shorter walks of nearest-first there
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
+    // leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (kTraceWide; 0: never), from this bounce on
+    uint32_t optDenseLeafMin = 3, optDenseLeafFromBounce = 1;
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
     uint32_t optRefillMinDeep = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at another count: 22 idle lanes on the 64-byte and the
@@ -2729,6 +2974,10 @@ struct Renderer::Impl
     uint32_t               optQuadHalfFromBounce = 0, optQuadHalfShadowFromBounce = 0; // quad launches of bounce >= this read the 64-byte half-precision quad records (0: never; set to 1 at upload when the scene suits them)
     float                  quadHalfAreaRatio = 0.0f;
     uint32_t               optQuadLocalFromBounce = 0, optQuadLocalShadowFromBounce = 0; // ... the 64-byte local-grid quad records (0: never; set to 1 at upload when the half-precision ones do not suit the scene)
+    // closest-hit launches of bounce >= this read the 128-byte oct records (three levels per fetch; 0: never).  Set at upload for scenes whose records + triangles
+    // do not fit the Infinity Cache (kOctMinTreeBytes): there a launch is bound by random lines per second, and a 128-byte line costs about what a 64-byte one does
+    uint32_t               optOctFromBounce = 0;
+    uint64_t               treeBytes = 0; // quad records + triangle records: what the traversal launches touch
     uint32_t               optHotFromBounce = 0, optHotShadowFromBounce = 0; // the 32-byte records (all six planes carried) from this bounce on (0: never); takes precedence
     int                    optQueryCompact = 0;            // the ray-query entry points use the compact-capable (1) / 32-byte (2) records too (tests)
     uint32_t               optExtraLds = 0;      // experiment: dynamic LDS bytes added to the kTraceWide launches (lowers the occupancy)
@@ -2916,6 +3165,7 @@ struct Renderer::Impl
     void queryWide(const float* rays6, uint64_t n, float tMax, bool shadow, std::vector<float4>& out0, std::vector<float4>& out1)
     {
         if (n > 0xFFFFFFFFull) throw std::runtime_error("too many rays");
+        const uint32_t denseFlag = std::min(optDenseLeafMin, 15u) << kFlagDenseLeafShift; // (the dense leaf phase, as in the render path)
         if (!ensurePathState(n)) throw std::runtime_error("out of device memory for the ray batch");
         std::vector<P3>       o(n), d(n);
         std::vector<uint32_t> ids(n);
@@ -2946,55 +3196,58 @@ struct Renderer::Impl
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
             if (shadowNearestFirst && optQueryCompact == 5 && wide.quadLocal != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (optQueryCompact == 5 && wide.quadLocal != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (shadowNearestFirst && optQueryCompact == 4 && wide.quadHalf != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (optQueryCompact == 4 && wide.quadHalf != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (shadowNearestFirst && optQueryCompact == 3 && wide.quad != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (optQueryCompact == 3 && wide.quad != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, false, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (shadowNearestFirst && optQueryCompact == 2 && wide.hot != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (shadowNearestFirst && optQueryCompact == 1 && wide.compact != nullptr)
                 hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else if (shadowNearestFirst)
                 hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
             else
                 hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
         }
         else
         {
-            if (optQueryCompact == 5 && wide.quadLocal != nullptr)
+            if (optQueryCompact == 6 && wide.oct != nullptr)
+                hipLaunchKernelGGL((kTraceWide<false, false, false, 6>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
+            else if (optQueryCompact == 5 && wide.quadLocal != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
             else if (optQueryCompact == 4 && wide.quadHalf != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
             else if (optQueryCompact == 3 && wide.quad != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
             else if (optQueryCompact == 2 && wide.hot != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
             else if (optQueryCompact == 1 && wide.compact != nullptr)
                 hipLaunchKernelGGL((kTraceWide<false, false, false, 1>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
             else
                 hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, 0u);
+                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
             hipLaunchKernelGGL(kHitPoints, dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
         }
         RF_HIP(hipGetLastError());
@@ -3102,7 +3355,8 @@ struct Renderer::Impl
             uint32_t* countOut = queueCounts.ptr + kLine * bounce;
             uint32_t* cursorClosest = cursors + kLine * kShards * 2 * (bounce - 1);
             uint32_t* cursorShadow = cursorClosest + kLine * kShards;
-            const uint32_t uniformFlag = ((optUniformFetch < 0 ? bounce <= 2 : optUniformFetch > 0) ? kFlagUniformFetch : 0u) | (optUniformFetch >= 2 ? kFlagUniformTri : 0u);
+            const uint32_t uniformFlag = ((optUniformFetch < 0 ? bounce <= 2 : optUniformFetch > 0) ? kFlagUniformFetch : 0u) | (optUniformFetch >= 2 ? kFlagUniformTri : 0u) |
+                                         (bounce >= optDenseLeafFromBounce ? (std::min(optDenseLeafMin, 15u) << kFlagDenseLeafShift) : 0u);
             // incoherent closest-hit launches refill earlier: their rays differ most in length, so lanes go idle sooner (per-bounce
             // sweep, profiles/r02_final/bounce_sweep*.log: bounces 3-8 -4 % at 20-24 idle lanes, bounces 1-2 and the shadow launches +6 .. +10 %)
             // ... and the coherent launches of the first bounces, whose rays are short and alike, claim larger chunks (one cursor atomic = one
@@ -3117,7 +3371,8 @@ struct Renderer::Impl
             const bool     primaryOutside = bounce == 1u && !(camReach <= wide.originBound);
             const bool     halfOk = wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce && !primaryOutside;
             const bool     localOk = wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce && !primaryOutside;
-            const bool     halfNow = quadNow && (halfOk || localOk);
+            const bool     octOk = wide.oct != nullptr && optOctFromBounce != 0u && bounce >= optOctFromBounce && !primaryOutside;
+            const bool     halfNow = quadNow && (halfOk || localOk || octOk);
             const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (quadNow && !halfNow ? optRefillMinDeepQuad : optRefillMinDeep) : optRefillMin;
             launchTimed(1, [&] {
                 if (traversalVariant == 0)
@@ -3132,6 +3387,9 @@ struct Renderer::Impl
                                        counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (bounce <= optPacketBounces)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
+                else if (quadNow && octOk)
+                    hipLaunchKernelGGL((kTraceWide<false, false, false, 6>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
+                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
                 else if (quadNow && halfOk)
                     hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
                                        counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
@@ -3349,6 +3607,15 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             m.optQuadLocalFromBounce = m.optQuadHalfFromBounce == 0u ? 2u : 0u;
             m.optQuadLocalShadowFromBounce = ratio <= kQuadLocalShadowMaxAreaRatio ? 2u : 0u;
         }
+        m.wide.oct = nullptr;
+        m.treeBytes = static_cast<uint64_t>(wb.quadLocal.size()) * sizeof(uint4) + static_cast<uint64_t>(sceneView.positionAttributes.size()) * kTriStride * sizeof(float4);
+        if (!wb.oct.empty())
+        {
+            m.wideOct.upload(wb.oct.data(), wb.oct.size());
+            m.wide.oct = m.wideOct.ptr;
+            // from bounce 2, like the local-grid quad records (the coherent launch of bounce 1 gains nothing from fewer, larger fetches)
+            m.optOctFromBounce = m.treeBytes >= kOctMinTreeBytes ? 2u : 0u;
+        }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
         m.wide.rootHi = wb.rootHi;
@@ -3398,9 +3665,9 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         {
             // leaves that share a first triangle (hand-made tree): one slot cannot hold two exact boxes, so the layouts that cull a leaf by
             // the box in that slot stay off and the exact records (which carry every box themselves) are used
-            m.wide.quadHalf = m.wide.quadLocal = nullptr;
-            m.wideQuadHalf.release(), m.wideQuadLocal.release();
-            m.optQuadHalfFromBounce = m.optQuadHalfShadowFromBounce = m.optQuadLocalFromBounce = m.optQuadLocalShadowFromBounce = 0u;
+            m.wide.quadHalf = m.wide.quadLocal = m.wide.oct = nullptr;
+            m.wideQuadHalf.release(), m.wideQuadLocal.release(), m.wideOct.release();
+            m.optQuadHalfFromBounce = m.optQuadHalfShadowFromBounce = m.optQuadLocalFromBounce = m.optQuadLocalShadowFromBounce = m.optOctFromBounce = 0u;
         }
         m.triangles.upload(padded.data(), padded.size());
     }
@@ -3808,6 +4075,8 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "refill_min_deep") mImpl->optRefillMinDeep = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value);
     else if (name == "refill_deep_from_bounce") mImpl->optRefillDeepFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 1));
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
+    else if (name == "dense_leaf_min") mImpl->optDenseLeafMin = static_cast<uint32_t>(std::clamp<int64_t>(value, 0, 15));
+    else if (name == "dense_leaf_from_bounce") mImpl->optDenseLeafFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 1));
     else if (name == "chunk") mImpl->optChunk = mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20)); // (both, as refill_min)
     else if (name == "chunk_early") mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20));
     else if (name == "shade_sort_from_bounce") mImpl->optShadeSortFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
@@ -3826,6 +4095,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "quad_half_shadow_from_bounce") mImpl->optQuadHalfShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "quad_except_mask") mImpl->optQuadExceptMask = static_cast<uint32_t>(value);
     else if (name == "quad_shadow_except_mask") mImpl->optQuadShadowExceptMask = static_cast<uint32_t>(value);
+    else if (name == "oct_from_bounce") mImpl->optOctFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "hot_from_bounce") mImpl->optHotFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "hot_shadow_from_bounce") mImpl->optHotShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "packet_bounces") mImpl->optPacketBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
@@ -4036,7 +4306,7 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
     if (nodes.empty()) throw std::runtime_error("checkWideLayouts: no nodes");
     const WideBuild wb = buildWide(nodes.data(), nodes.size());
     if (quadHalfAreaRatio) *quadHalfAreaRatio = wb.quadHalf.empty() ? 0.0f : wb.quadHalfAreaRatio;
-    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u) | (!wb.quad.empty() ? 8u : 0u) | (!wb.quadHalf.empty() ? 16u : 0u) | (!wb.quadLocal.empty() ? 32u : 0u);
+    const uint32_t  flags = (wb.boxesRegular ? 1u : 0u) | (!wb.compact.empty() ? 2u : 0u) | (!wb.hot.empty() ? 4u : 0u) | (!wb.quad.empty() ? 8u : 0u) | (!wb.quadHalf.empty() ? 16u : 0u) | (!wb.quadLocal.empty() ? 32u : 0u) | (!wb.oct.empty() ? 64u : 0u);
     const size_t    records = wb.nodes.size() / 4;
     const auto      fail = [](size_t r, const char* what) { throw std::runtime_error("wide layout mismatch at record " + std::to_string(r) + ": " + what); };
     if (!wb.quadHalf.empty())
@@ -4227,6 +4497,108 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
             }
         }
         if (visited != wb.quad.size() / 8) fail(0, "quad records: not every record is reachable from the root exactly once");
+    }
+    if (!wb.oct.empty())
+    {
+        // Oct records (round 5): walk them from the root next to the reference nodes.  Slot e = 4 c + 2 g + k must hold what the three levels below the member hold
+        // at that place (a leaf fills the first slot of its range), every plane must lie outside its f32 plane by the margin, an empty slot must fail for every
+        // ray (lo = 255, hi = 0), and for each of the eight direction-sign patterns the positions the KERNEL derives from the order table (kTraceWide, COMPACT == 6)
+        // must put the slots into the order in which the reference's walk (wgsl:409-417 at each of the three levels) reaches them.
+        double R = 0.0;
+        for (const float c : {wb.rootLo.x, wb.rootLo.y, wb.rootLo.z, wb.rootHi.x, wb.rootHi.y, wb.rootHi.z}) R = std::max(R, static_cast<double>(std::fabs(c)));
+        const double margin = (static_cast<double>(wb.originBound) + R) * 3.814697265625e-06 * 0.999; // 2^-18 (a hair less: the builder's own rounding)
+        const size_t numOct = wb.oct.size() / 8;
+        struct Item
+        {
+            uint32_t node, rec;
+        };
+        std::vector<Item> todo{{0u, 0u}};
+        size_t            visited = 0;
+        while (!todo.empty())
+        {
+            const Item at = todo.back();
+            todo.pop_back();
+            ++visited;
+            if (at.rec >= numOct || at.node >= nodes.size() || nodes[at.node].triangleCount != 0) fail(at.rec, "oct record: index out of range or not an interior node");
+            uint32_t slotNode[8];
+            for (uint32_t& v : slotNode) v = kQuadEmpty;
+            const std::function<void(uint32_t, int, int)> place = [&](uint32_t nd, int depth, int base) {
+                if (depth == 3 || (depth > 0 && nodes[nd].triangleCount != 0)) { slotNode[base] = nd; return; }
+                place(nd + 1, depth + 1, base);
+                place(nodes[nd].secondChildOffset, depth + 1, base + (4 >> depth));
+            };
+            place(at.node, 0, 0);
+            const uint4*   o = &wb.oct[8 * static_cast<size_t>(at.rec)];
+            const float    anchor[3] = {bitsFloat(o[0].x), bitsFloat(o[0].y), bitsFloat(o[0].z)}, scale[3] = {bitsFloat(o[0].w), bitsFloat(o[1].x), bitsFloat(o[1].y)};
+            const uint32_t words[8] = {o[5].x, o[5].y, o[5].z, o[5].w, o[6].x, o[6].y, o[6].z, o[6].w};
+            const uint32_t axisWords[3][4] = {{o[2].x, o[2].y, o[2].z, o[2].w}, {o[3].x, o[3].y, o[3].z, o[3].w}, {o[4].x, o[4].y, o[4].z, o[4].w}};
+            for (int e = 0; e < 8; ++e)
+            {
+                for (int ax = 0; ax < 3; ++ax)
+                {
+                    const uint32_t pair = (axisWords[ax][e / 2] >> (16 * (e % 2))) & 0xFFFFu;
+                    if (slotNode[e] == kQuadEmpty)
+                    {
+                        if (pair != 0x00FFu) fail(at.rec, "oct record: an empty slot does not hold the planes no ray passes");
+                        continue;
+                    }
+                    const BvhNode& en = nodes[slotNode[e]];
+                    const double   lo = ax == 0 ? en.aabb.min.x : ax == 1 ? en.aabb.min.y : en.aabb.min.z, hi = ax == 0 ? en.aabb.max.x : ax == 1 ? en.aabb.max.y : en.aabb.max.z;
+                    const double   dlo = static_cast<double>(anchor[ax]) + static_cast<double>(pair & 0xFFu) * static_cast<double>(scale[ax]),
+                                 dhi = static_cast<double>(anchor[ax]) + static_cast<double>(pair >> 8) * static_cast<double>(scale[ax]);
+                    if (!(dlo <= lo - margin)) fail(at.rec, "oct record: a lower plane is not below its f32 plane by the margin");
+                    if (!(dhi >= hi + margin)) fail(at.rec, "oct record: an upper plane is not above its f32 plane by the margin");
+                }
+                if (slotNode[e] == kQuadEmpty)
+                {
+                    if (words[e] != kQuadEmpty) fail(at.rec, "oct record: an empty slot names something");
+                    continue;
+                }
+                const BvhNode& en = nodes[slotNode[e]];
+                if (en.triangleCount != 0)
+                {
+                    if ((words[e] & kWideLeafBit) == 0u) fail(at.rec, "oct record: a leaf encoded as an interior entry");
+                    uint32_t first = words[e] & ((1u << kWideIndexBits) - 1u), cnt = ((words[e] >> kWideIndexBits) & 7u) + 1u;
+                    if (cnt == 8u) cnt = wb.bigLeaves[first].y, first = wb.bigLeaves[first].x;
+                    if (first != en.trianglesOffset || cnt != en.triangleCount) fail(at.rec, "oct record: leaf word names other triangles");
+                }
+                else
+                {
+                    if ((words[e] & kWideLeafBit) != 0u || words[e] != wb.octIndexOfNode[slotNode[e]]) fail(at.rec, "oct record: interior entry names another record");
+                    todo.push_back(Item{slotNode[e], words[e]});
+                }
+            }
+            const unsigned long long table = (static_cast<unsigned long long>(o[1].w) << 32) | o[1].z;
+            for (uint32_t signs = 0; signs < 8; ++signs)
+            {
+                std::vector<int>                              want; // slots in the order the reference reaches them
+                const std::function<void(uint32_t, int, int)> walk = [&](uint32_t nd, int depth, int base) {
+                    if (depth == 3 || (depth > 0 && nodes[nd].triangleCount != 0)) { want.push_back(base); return; }
+                    const bool     neg = ((signs >> (nodes[nd].splitAxis & 3u)) & 1u) != 0u;
+                    const uint32_t kid[2] = {nd + 1, nodes[nd].secondChildOffset};
+                    const int      kidBase[2] = {base, base + (4 >> depth)};
+                    for (int k = 0; k < 2; ++k) walk(kid[neg ? 1 - k : k], depth + 1, kidBase[neg ? 1 - k : k]);
+                };
+                walk(at.node, 0, 0);
+                // the kernel's rule (refill + oct step)
+                const uint32_t signXY = signs & 3u, negZ = signs >> 2;
+                const uint32_t octKey = negZ ? ((16u * (3u - signXY)) | (0x7777u << 8)) : 16u * signXY;
+                const uint32_t ord = static_cast<uint32_t>(table >> (octKey & 63u)) ^ (octKey >> 8);
+                int            slotAt[8];
+                for (int& v : slotAt) v = -1;
+                for (int j = 0; j < 4; ++j)
+                {
+                    const uint32_t p0 = (ord >> (4 * j)) & 7u;
+                    if (slotNode[2 * j] != kQuadEmpty) slotAt[p0] = 2 * j;
+                    if (slotNode[2 * j + 1] != kQuadEmpty) slotAt[p0 ^ 1u] = 2 * j + 1;
+                }
+                std::vector<int> got;
+                for (const int v : slotAt)
+                    if (v >= 0) got.push_back(v);
+                if (got != want) fail(at.rec, "oct record: the order table does not reproduce the reference's visit order");
+            }
+        }
+        if (visited != numOct) fail(0, "oct records: not every record is reachable from the root exactly once");
     }
     for (size_t r = 0; r < records; ++r)
     {

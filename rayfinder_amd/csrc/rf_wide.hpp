@@ -53,6 +53,9 @@ constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is i
 // -> closest-hit: half-precision up to kQuadHalfMaxAreaRatio, local grid beyond; shadow: local grid up to kQuadLocalShadowMaxAreaRatio,
 //    exact quad records beyond.
 constexpr float    kQuadHalfMaxAreaRatio = 1.075f, kQuadLocalShadowMaxAreaRatio = 1.10f;
+// Scenes whose quad records + triangle records reach this many bytes read the 128-byte oct records in their closest-hit launches from bounce 2 on
+// (WideBuild::oct): half the 256-MiB Infinity Cache -- below it the tree is served on-die and the 64-byte records' shorter step wins (round 5, profiles/r05_hbm)
+constexpr uint64_t kOctMinTreeBytes = 128ull << 20;
 constexpr uint32_t kQuadEmpty = 0xFFFFFFFFu; // quad records: an entry slot that holds no node (its child is a leaf and fills one slot only)
 #if defined(RF_EXP_WAVES)
 constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment builds: resident workgroups per CU of kTraceWide
@@ -78,6 +81,7 @@ struct WideScene
     const uint4*  quadHalf;  // 4 uint4 per quad record: the same records with CONSERVATIVE half-precision planes, 64 bytes (see buildWide), or nullptr
     float         originBound; // quadHalf / quadLocal: rays whose origin has a coordinate beyond this magnitude take the scalar traversal (margin proofs)
     const uint4*  quadLocal; // 4 uint4 per quad record: conservative 8-bit planes on a per-record grid, 64 bytes (see buildWide), or nullptr
+    const uint4*  oct;       // 8 uint4 per oct record (128-byte aligned, 112 bytes read): THREE levels per fetch, local-grid planes (see WideBuild::oct), or nullptr
     const uint2*  bigLeaves; // {first triangle, count}
     float4        rootLo;    // root box (w unused)
     float4        rootHi;
@@ -153,6 +157,24 @@ struct WideBuild
     // i.e. u (46 R + 6) with originBound = 4 R + 1, and the builder leaves 2^-18 (originBound + R) = u (320 R + 64): 6.9 x that.
     std::vector<uint4>  quadLocal;
     float               quadLocalAreaRatio = 0.0f;
+    // Oct records (kTraceWide<..., COMPACT = 6>, round 5): the local-grid idea one level further -- one 128-byte-aligned record per interior node reachable
+    // from the root in steps of THREE levels holds the boxes of the node's (up to eight) GREAT-GRANDCHILDREN, i.e. three levels of the reference's tree per
+    // dependent fetch.  For scenes whose tree does not fit the Infinity Cache: there the traversal is bound by how many random lines per second the memory
+    // system delivers, and a random 128-byte line costs about what a 64-byte one does (tools/microbench/fetch_calib.hip `wide`, 2-GiB table: 64-byte records
+    // 60 G/s = 3.8 TB/s, 128-byte records 51 G/s = 6.5 TB/s).  Slot e = 4 c + 2 g + k: child c of the node, its child g, that one's child k; a child or
+    // grandchild that is a leaf fills the FIRST slot of its range, the rest of the range is empty.  Layout (uint4 pieces; the eighth is padding):
+    //     {anchor.x anchor.y anchor.z scale.x} {scale.y scale.z orderLo orderHi} {X01 X23 X45 X67} {Y01 Y23 Y45 Y67} {Z01 Z23 Z45 Z67} {word0..3} {word4..7}
+    // planes as in the local-grid quad records (axis word of slots 2 j, 2 j + 1 = {lo hi lo hi} bytes; an EMPTY slot holds lo = 255, hi = 0 on every axis: it fails
+    // the slab test for every ray, so the step has no "is the slot empty" test at all); words = child words without axis bits (a leaf descriptor or the index of
+    // the entry's own oct record; kQuadEmpty in empty slots).
+    // Visit order.  The reference orders the two children of every node by dirNeg[its split axis] (wgsl:409-417); applied at the three levels inside a record
+    // that is a permutation of the eight slots which depends on the record's seven split axes and on the ray's three direction signs only -- so the builder
+    // tabulates it: order{Lo,Hi} = four 16-bit fields, one per sign pattern (negX | negY << 1) with negZ = 0; nibble j = 2 c + g of a field = the POSITION (0 = first)
+    // at which slot (c, g, 0) is visited, slot (c, g, 1) sits at that position ^ 1.  A ray with negZ = 1 reads the field of the opposite sign pattern and flips
+    // every position (^ 7): with all three signs inverted every swap is inverted, i.e. the order is reversed.
+    std::vector<uint4>  oct;
+    std::vector<uint32_t> octIndexOfNode; // per reference node: its oct record (kQuadEmpty: none)
+    float               octAreaRatio = 0.0f; // as quadLocalAreaRatio
     std::vector<uint2>  bigLeaves;
     float4              rootLo, rootHi;
     uint32_t            rootLeaf = kWideNone;
@@ -553,6 +575,142 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
             out.quadLocalAreaRatio = aExact > 0.0 ? static_cast<float>(aLocal / aExact) : 1.0f;
             if (!okL) out.quadLocal.clear();
         }
+    }
+
+    if (!out.quadLocal.empty())
+    {
+        // ---- oct records (see WideBuild::oct): members = the root and every interior great-grandchild of a member, numbered in node order
+        std::vector<uint32_t>& octIndex = out.octIndexOfNode;
+        octIndex.assign(count, kQuadEmpty);
+        struct Slots
+        {
+            uint32_t node[8];   // reference node in the slot, kQuadEmpty: empty
+            uint32_t axis[7];   // split axes: [0] the member's, [1 + c] child c's, [3 + 2 c + g] grandchild (c, g)'s (0 where that node is a leaf / absent)
+        };
+        const auto slotsOf = [&](uint32_t i) {
+            Slots sl;
+            for (uint32_t& v : sl.node) v = kQuadEmpty;
+            for (uint32_t& v : sl.axis) v = 0u;
+            sl.axis[0] = nodes[i].splitAxis & 3u;
+            const size_t kids[2] = {static_cast<size_t>(i) + 1, nodes[i].secondChildOffset};
+            for (int c = 0; c < 2; ++c)
+            {
+                const BvhNode& cn = nodes[kids[c]];
+                if (cn.triangleCount > 0) { sl.node[4 * c] = static_cast<uint32_t>(kids[c]); continue; }
+                sl.axis[1 + c] = cn.splitAxis & 3u;
+                const size_t gk[2] = {kids[c] + 1, cn.secondChildOffset};
+                for (int g = 0; g < 2; ++g)
+                {
+                    const BvhNode& gn = nodes[gk[g]];
+                    if (gn.triangleCount > 0) { sl.node[4 * c + 2 * g] = static_cast<uint32_t>(gk[g]); continue; }
+                    sl.axis[3 + 2 * c + g] = gn.splitAxis & 3u;
+                    sl.node[4 * c + 2 * g] = static_cast<uint32_t>(gk[g] + 1);
+                    sl.node[4 * c + 2 * g + 1] = gn.secondChildOffset;
+                }
+            }
+            return sl;
+        };
+        {
+            std::vector<uint8_t>  member(count, 0);
+            std::vector<uint32_t> todo{0u};
+            while (!todo.empty())
+            {
+                const uint32_t i = todo.back();
+                todo.pop_back();
+                member[i] = 1;
+                const Slots sl = slotsOf(i);
+                for (const uint32_t nd : sl.node)
+                    if (nd != kQuadEmpty && nodes[nd].triangleCount == 0) todo.push_back(nd);
+            }
+            uint32_t numOct = 0;
+            for (size_t i = 0; i < count; ++i)
+                if (member[i]) octIndex[i] = numOct++;
+            out.oct.assign(8 * static_cast<size_t>(numOct), make_uint4(0u, 0u, 0u, 0u));
+        }
+        double R = 0.0;
+        for (const float c : {out.rootLo.x, out.rootLo.y, out.rootLo.z, out.rootHi.x, out.rootHi.y, out.rootHi.z}) R = std::max(R, static_cast<double>(std::fabs(c)));
+        const double marginL = (static_cast<double>(out.originBound) + R) * 3.814697265625e-06; // 2^-18, as for the local-grid quad records
+        const auto   area = [](const double lo[3], const double hi[3]) {
+            const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+            return 2.0 * (ex * ey + ey * ez + ez * ex);
+        };
+        double aExact = 0.0, aLocal = 0.0;
+        bool   okO = true;
+        for (size_t i = 0; i < count && okO; ++i)
+        {
+            if (octIndex[i] == kQuadEmpty) continue;
+            const Slots sl = slotsOf(static_cast<uint32_t>(i));
+            uint32_t    words[8];
+            double      lo[8][3], hi[8][3];
+            for (int e = 0; e < 8; ++e)
+            {
+                words[e] = kQuadEmpty;
+                if (sl.node[e] == kQuadEmpty) continue;
+                const BvhNode& en = nodes[sl.node[e]];
+                words[e] = en.triangleCount > 0 ? leafWord(sl.node[e]) : octIndex[sl.node[e]];
+                if (en.triangleCount == 0 && words[e] >= (1u << kWideIndexBits)) okO = false;
+                lo[e][0] = en.aabb.min.x, lo[e][1] = en.aabb.min.y, lo[e][2] = en.aabb.min.z;
+                hi[e][0] = en.aabb.max.x, hi[e][1] = en.aabb.max.y, hi[e][2] = en.aabb.max.z;
+            }
+            float    anchor[3], scale[3];
+            uint32_t axisWords[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            double   dlo[8][3], dhi[8][3];
+            for (int ax = 0; ax < 3 && okO; ++ax)
+            {
+                double nlo = std::numeric_limits<double>::infinity(), nhi = -nlo;
+                for (int e = 0; e < 8; ++e)
+                    if (words[e] != kQuadEmpty) nlo = std::min(nlo, lo[e][ax]), nhi = std::max(nhi, hi[e][ax]);
+                const double target = nlo - marginL;
+                float        an = static_cast<float>(target);
+                if (static_cast<double>(an) > target) an = std::nextafterf(an, -std::numeric_limits<float>::infinity());
+                const double span = (nhi + marginL) - static_cast<double>(an);
+                int          ex = 0;
+                (void)std::frexp(span / 254.0, &ex); // span / 254 = m * 2^ex, m in [0.5, 1): 2^ex >= span / 254
+                if (!(span > 0.0) || ex < -100 || ex > 100) { okO = false; break; }
+                const double sc = std::ldexp(1.0, ex);
+                anchor[ax] = an, scale[ax] = static_cast<float>(sc);
+                for (int e = 0; e < 8; ++e)
+                {
+                    uint32_t bl = 255u, bh = 0u; // an empty slot: no ray passes lo = 255, hi = 0
+                    if (words[e] != kQuadEmpty)
+                    {
+                        const double fl = std::floor((lo[e][ax] - marginL - static_cast<double>(an)) / sc), ch = std::ceil((hi[e][ax] + marginL - static_cast<double>(an)) / sc);
+                        if (!(fl >= 0.0 && ch <= 255.0 && fl <= ch)) { okO = false; break; }
+                        bl = static_cast<uint32_t>(fl), bh = static_cast<uint32_t>(ch);
+                    }
+                    dlo[e][ax] = static_cast<double>(an) + bl * sc, dhi[e][ax] = static_cast<double>(an) + bh * sc;
+                    axisWords[ax][e / 2] |= (bl | (bh << 8)) << (16 * (e % 2));
+                }
+            }
+            if (!okO) break;
+            // visit positions of the eight slots for the four sign patterns with negZ = 0 (see WideBuild::oct)
+            uint32_t order[2] = {0u, 0u};
+            for (uint32_t pattern = 0; pattern < 4; ++pattern)
+            {
+                const auto     neg = [&](uint32_t axis) -> uint32_t { return axis < 2u ? (pattern >> axis) & 1u : 0u; };
+                const uint32_t sN = neg(sl.axis[0]);
+                uint32_t       field = 0u;
+                for (uint32_t c = 0; c < 2; ++c)
+                    for (uint32_t g = 0; g < 2; ++g)
+                    {
+                        const uint32_t position = ((c ^ sN) << 2) | ((g ^ neg(sl.axis[1 + c])) << 1) | (0u ^ neg(sl.axis[3 + 2 * c + g]));
+                        field |= position << (4 * (2 * c + g));
+                    }
+                order[pattern / 2] |= field << (16 * (pattern % 2));
+            }
+            uint4* o = &out.oct[8 * static_cast<size_t>(octIndex[i])];
+            o[0] = make_uint4(floatBits(anchor[0]), floatBits(anchor[1]), floatBits(anchor[2]), floatBits(scale[0]));
+            o[1] = make_uint4(floatBits(scale[1]), floatBits(scale[2]), order[0], order[1]);
+            o[2] = make_uint4(axisWords[0][0], axisWords[0][1], axisWords[0][2], axisWords[0][3]);
+            o[3] = make_uint4(axisWords[1][0], axisWords[1][1], axisWords[1][2], axisWords[1][3]);
+            o[4] = make_uint4(axisWords[2][0], axisWords[2][1], axisWords[2][2], axisWords[2][3]);
+            o[5] = make_uint4(words[0], words[1], words[2], words[3]);
+            o[6] = make_uint4(words[4], words[5], words[6], words[7]);
+            for (int e = 0; e < 8; ++e)
+                if (words[e] != kQuadEmpty) aExact += area(lo[e], hi[e]), aLocal += area(dlo[e], dhi[e]);
+        }
+        out.octAreaRatio = aExact > 0.0 ? static_cast<float>(aLocal / aExact) : 1.0f;
+        if (!okO) out.oct.clear(), out.octIndexOfNode.clear();
     }
     if (!out.boxesRegular) out.compactUsable = false;
     if (!out.compactUsable || numInterior == 0) out.compact.clear();

@@ -528,11 +528,11 @@ def test_wide_record_layouts_decode_to_the_same_planes(seed, n):
     tris[: n // 4] = np.round(tris[: n // 4] * 2) / 2               # lattice coordinates: shared planes, zero-thickness boxes
     nodes, _, _ = rf.build_bvh(tris.reshape(n, 9))
     got = rf.check_wide_layouts(nodes)
-    assert got == {"regular": True, "compact": n > 1, "hot": n > 1, "quad": n > 1, "quad_half": n > 1, "quad_local": n > 1}   # (a single-leaf tree has no interior record)
+    assert got == {"regular": True, "compact": n > 1, "hot": n > 1, "quad": n > 1, "quad_half": n > 1, "quad_local": n > 1, "oct": n > 1}   # (a single-leaf tree has no interior record)
 
 
 def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(duck_oracle):
-    assert rf.check_wide_layouts(duck_oracle.nodes) == {"regular": True, "compact": True, "hot": True, "quad": True, "quad_half": True, "quad_local": True}
+    assert rf.check_wide_layouts(duck_oracle.nodes) == {"regular": True, "compact": True, "hot": True, "quad": True, "quad_half": True, "quad_local": True, "oct": True}
     # a hand-made tree whose root box is LARGER than the union of its children: the lane cannot carry the node's planes,
     # so the renderer falls back to the plain records
     nodes = np.zeros(3, dtype=rf.NODE_DTYPE)
@@ -541,7 +541,7 @@ def test_wide_record_layouts_of_duck_and_of_a_tree_whose_boxes_are_not_unions(du
         nodes[i]["min"] = (x - 0.5, -0.5, -0.5); nodes[i]["max"] = (x + 0.5, 0.5, 0.5)
         nodes[i]["trianglesOffset"] = i - 1; nodes[i]["triangleCount"] = 1; nodes[i]["splitAxis"] = 0xFFFFFFFF
     # (the quad records skip the level BELOW the node they belong to; here that level holds only leaves, so nothing is skipped)
-    assert rf.check_wide_layouts(nodes) == {"regular": True, "compact": False, "hot": False, "quad": True, "quad_half": True, "quad_local": True}
+    assert rf.check_wide_layouts(nodes) == {"regular": True, "compact": False, "hot": False, "quad": True, "quad_half": True, "quad_local": True, "oct": True}
     # ... but a CHILD whose box is larger than the union of its children cannot be skipped: "a grandchild passes" would no
     # longer imply "the child passes" with the same planes
     deep = np.zeros(5, dtype=rf.NODE_DTYPE)
@@ -594,12 +594,12 @@ def test_occluder_cache_entries_of_a_tree_with_an_orphan_node_and_of_a_tree_that
         if grown[i]["triangleCount"] == 0 and grown[i]["secondChildOffset"] >= S:
             grown[i]["secondChildOffset"] += 3
     got = rf.check_wide_layouts(grown)          # (throws "the leaf is not below the record it names" with the old numbering)
-    assert got["quad"] and got["quad_half"] and got["quad_local"]
+    assert got["quad"] and got["quad_half"] and got["quad_local"] and got["oct"]
     # (ii) the left child of the root pokes out of the root's box
     poke = nodes.copy()
     poke[1]["max"] = tuple(np.asarray(poke[0]["max"]) + np.float32(1.0))
     got = rf.check_wide_layouts(poke)
-    assert got["regular"] and not got["quad"] and not got["quad_half"] and not got["quad_local"]
+    assert got["regular"] and not got["quad"] and not got["quad_half"] and not got["quad_local"] and not got["oct"]
 
 
 # ---------------------------------------------------------------- the product's CPU query (rf_query.cpp): config 1 without a GPU

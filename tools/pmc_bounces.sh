@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$1; SPP=$2; shift; shift
 case $OUT in /*) ;; *) OUT=$PWD/$OUT ;; esac
 mkdir -p $(dirname $OUT); cd /tmp && export TMPDIR=/tmp
-GROUPS_=("TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES")
+GROUPS_=("TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "FETCH_SIZE")
 rm -f $OUT.parts; : > $OUT.parts
 for v in "$@"; do
   g=0
@@ -48,7 +48,7 @@ with open(sys.argv[2], "w") as f:
     for (v, k, b), e in t.items():
         f.write(f'"{v}",{k},{b},{e["rays"]},{e["ms"]:.3f},' + ",".join(repr(e.get(n, 0.0)) for n in names) + "\n")
 # derived per-ray table
-print(f"{'variant':46s} {'kernel':8s} b {'Mrays':>7s} {'L1acc/ray':>9s} {'L1/clk/CU':>9s} {'L2req/ray':>9s} {'Greq/s':>7s} {'VALU/ray':>8s} {'VALUshare':>9s} {'lanes':>5s} {'SALU/ray':>8s} {'VMEM/ray':>8s} {'LDS/ray':>7s} {'L2hit':>5s} {'ms(gui)':>7s}")
+print(f"{'variant':46s} {'kernel':8s} b {'Mrays':>7s} {'L1acc/ray':>9s} {'L1/clk/CU':>9s} {'L2req/ray':>9s} {'Greq/s':>7s} {'VALU/ray':>8s} {'VALUshare':>9s} {'lanes':>5s} {'SALU/ray':>8s} {'VMEM/ray':>8s} {'LDS/ray':>7s} {'L2hit':>5s} {'ms(gui)':>7s} {'fabricB/ray':>11s} {'fabric TB/s':>11s}")
 for (v, k, b), e in t.items():
     rays = max(e["rays"], 1); cyc = (e.get("GRBM_GUI_ACTIVE", 0.0) / 8.0) or 1.0      # the counter is summed over the 8 XCDs
     ms = cyc / 2.4e6
@@ -56,6 +56,6 @@ for (v, k, b), e in t.items():
     print(f"{v[:46]:46s} {k:8s} {b} {rays/1e6:7.1f} {e.get('TCP_TOTAL_CACHE_ACCESSES_sum',0)/rays:9.1f} {e.get('TCP_TOTAL_CACHE_ACCESSES_sum',0)/cyc/256:9.3f} "
           f"{e.get('TCP_TCC_READ_REQ_sum',0)/rays:9.2f} {e.get('TCP_TCC_READ_REQ_sum',0)/(ms*1e-3)/1e9:7.1f} {valu/rays:8.1f} "
           f"{valu*4.0/1024/cyc:9.3f} {e.get('SQ_THREAD_CYCLES_VALU',0)/max(e.get('SQ_ACTIVE_INST_VALU',0)*64,1):5.2f} {e.get('SQ_INSTS_SALU',0)/rays:8.1f} {e.get('SQ_INSTS_VMEM_RD',0)/rays:8.1f} {e.get('SQ_INSTS_LDS',0)/rays:7.1f} "
-          f"{e.get('TCC_HIT_sum',0)/max(e.get('TCC_HIT_sum',0)+e.get('TCC_MISS_sum',0),1):5.2f} {ms:7.2f}")
+          f"{e.get('TCC_HIT_sum',0)/max(e.get('TCC_HIT_sum',0)+e.get('TCC_MISS_sum',0),1):5.2f} {ms:7.2f} {e.get('FETCH_SIZE',0)*1024*0.93/rays:11.1f} {e.get('FETCH_SIZE',0)*1024*0.93/(ms*1e-3)/1e12:11.3f}")
 PY
 rm -f $OUT.parts
