@@ -141,13 +141,29 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     cam = rf.camera_to_array(rf.fly_camera(width, height))
     sky = rf.aligned_sky_state(rf.make_sky())
     rp = orc.make_render_params(width, height, cam, spp, bounces, 0.25, sky)
-    # calibration: 1 thread, a 32x8 patch in the middle, 2 of the frames
+    # calibration: 1 thread PINNED to one of the CPUs this process may use (an unpinned thread migrates between the 256 hardware threads of the box under a
+    # 16-CPU quota: 0.378 Mrays/s on the driver's box against 0.71 in the profile run), three 32x8 patches of 2 frames each, the MEDIAN rate
     cw, ch = 32, 8
     x0, y0 = (width - cw) // 2, (height - ch) // 2
-    t0 = time.time()
-    _, st = orc.render(sc, rp, first_frame, 2, x0, y0, x0 + cw, y0 + ch, accumulated_start=0)
-    dt1 = max(time.time() - t0, 1e-4)
-    single = (st.closestRays + st.shadowRays) / dt1
+    affinity = None
+    try:
+        affinity = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(affinity)[len(affinity) // 2]})
+    except (AttributeError, OSError):
+        affinity = None
+    singles, st = [], None
+    try:
+        for (px, py) in ((x0, y0), (x0 - width // 4, y0), (x0 + width // 4, y0 + height // 8)):
+            t0 = time.perf_counter()
+            _, st_i = orc.render(sc, rp, first_frame, 2, px, py, px + cw, py + ch, accumulated_start=0)
+            dt1 = max(time.perf_counter() - t0, 1e-4)
+            singles.append((st_i.closestRays + st_i.shadowRays) / dt1)
+            if st is None:
+                st = st_i
+    finally:
+        if affinity is not None:
+            os.sched_setaffinity(0, affinity)
+    single = sorted(singles)[1]
     rays_per_pixel = (st.closestRays + st.shadowRays) / (cw * ch * 2) * spp        # at the full sample count
     # crop sized for the budget (assuming ~50 % parallel efficiency up to 64 threads: the loop is memory-latency bound)
     want = seconds_budget * (cores * 0.5 if quota is None else min(cores, quota) * 0.8) * single
@@ -163,6 +179,16 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
     _, st_all, started = orc.render_threads(sc, rp, first_frame, spp, x0, y0, x0 + cw2, y0 + ch2, cores, 1, image=image, accumulated_start=0)
     dt = max(time.time() - t0, 1e-6)
     rays = st_all.closestRays + st_all.shadowRays
+    # ... and once more at cores = floor(CPU quota) (one thread per CPU the container is actually given), on a quarter of the crop
+    quota_leg = None
+    if quota is not None and int(quota) >= 1 and int(quota) != cores:
+        qc = int(quota)
+        qh = max(min(ch2 // 4, ch2), min(ch2, 2 * qc))
+        qy = y0 + (ch2 - qh) // 2
+        t0 = time.time()
+        _, st_q, started_q = orc.render_threads(sc, rp, first_frame, spp, x0, qy, x0 + cw2, qy + qh, qc, 1, accumulated_start=0)
+        dq = max(time.time() - t0, 1e-6)
+        quota_leg = dict(value=round((st_q.closestRays + st_q.shadowRays) / dq * 1e-6, 3), cores=int(started_q), crop=[x0, qy, cw2, qh])
     # parity of the timed GPU frame on that crop
     g, c = gpu_image[y0:y0 + ch2, x0:x0 + cw2, :3], image[y0:y0 + ch2, x0:x0 + cw2, :3]
     same_nan = bool(np.array_equal(np.isnan(g), np.isnan(c)))
@@ -186,10 +212,95 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
                        + (f", the container a CPU quota of {quota:g} CPUs" if quota is not None else "") + f"); 1 thread: {single * 1e-6:.3f} Mrays/s",
                 host_hardware_threads=hw_threads, cpu_quota=quota,
                 single_thread_value=round(single * 1e-6, 3),
+                single_thread=dict(value=round(single * 1e-6, 3), samples=[round(v * 1e-6, 3) for v in singles], pinned=affinity is not None,
+                                   note="one thread pinned to one allowed CPU (sched_setaffinity), three 32x8 patches x 2 frames, the median"),
+                at_quota_cores=quota_leg,
                 bvh_visualizer_primary_rays=dict(unit="Mrays/s", image=f"{vw}x{vh}", one_thread=round(viz_single * 1e-6, 3),
                                                  all_cores=round(vw * vh / vdt * 1e-6, 3), cores=cores,
                                                  note="the reference's only CPU traversal loop (src/bvh-visualizer/main.cpp:60-78, single-threaded there), restated in oracle/rf_oracle.c"))
     return base, parity
+
+
+def parity_of_crop(pt, width, height, bounces, first_frame, spp, gpu_image, crop_w=48, crop_h=32):
+    """The oracle on a small centred crop of exactly the frames `gpu_image` holds -> dict(crop, spp, pixels, bit_identical_pixels, verdict)."""
+    import rayfinder_amd as rf
+    from oracle import orc
+    sc, _ = oracle_scene(pt)
+    hw_threads, quota = host_cpus()
+    cores = hw_threads if quota is None else max(1, min(hw_threads, int(round(2 * quota))))
+    rp = orc.make_render_params(width, height, rf.camera_to_array(rf.fly_camera(width, height)), spp, bounces, 0.25, rf.aligned_sky_state(rf.make_sky()))
+    x0, y0 = (width - crop_w) // 2, (height - crop_h) // 2
+    image = np.zeros((height, width, 4), np.float32)
+    orc.render_threads(sc, rp, first_frame, spp, x0, y0, x0 + crop_w, y0 + crop_h, cores, 1, image=image, accumulated_start=0)
+    g, c = gpu_image[y0:y0 + crop_h, x0:x0 + crop_w, :3], image[y0:y0 + crop_h, x0:x0 + crop_w, :3]
+    same_nan = bool(np.array_equal(np.isnan(g), np.isnan(c)))
+    identical = int(((g.view(np.uint32) == c.view(np.uint32)).all(axis=-1) | np.isnan(c).any(axis=-1)).sum())
+    return dict(crop=[x0, y0, crop_w, crop_h], spp=spp, pixels=crop_w * crop_h, bit_identical_pixels=identical, nan_pixels_match=same_nan,
+                verdict="bit-identical" if identical == crop_w * crop_h and same_nan else "DIFFERENT")
+
+
+def run_regime(name, detail, scale, steps, sps, width, height, bounces, device, with_parity=True, repeats=3):
+    """One of the OTHER stand-ins next to the headline: the same timed-region recipe on a renderer of its own -- warm-up of 2 steps,
+    `repeats` timed regions of `steps` steps (median), one more with the occluder cache off, the oracle on a small crop of the timed frames."""
+    import rayfinder_amd as rf
+    t_all = time.time()
+    pt, info = load_scene("", scale, device, detail)
+    spp, warm = sps * steps, sps * 2
+    cam, sky = rf.fly_camera(width, height), rf.make_sky()
+    r = rf.ReferencePathTracer(rf.make_render_parameters(width, height, cam, spp, bounces, sky, 0.25), pt.scene(), device_ordinal=device)
+    try:
+        r.set_option("reserve_samples", spp)
+        r.render(warm); r.synchronize()
+        r.set_timing(True)
+        runs = []
+        for rep in range(repeats):
+            r.set_render_parameters(rf.make_render_parameters(width, height, cam, spp, bounces, sky, 0.5 + 0.125 * (rep % 2)))
+            r.reset_stats()
+            r.synchronize()
+            t0 = time.perf_counter(); r.render(spp); r.synchronize(); dt = time.perf_counter() - t0
+            runs.append((dt, r.stats()))
+        dt, st = sorted(runs, key=lambda x: x[0])[(repeats - 1) // 2]
+        image = r.read_accumulation()[0]
+        first_frame = warm + (repeats - 1) * spp
+        r.set_option("occluder_cache_bounces", 0)
+        r.set_render_parameters(rf.make_render_parameters(width, height, cam, spp, bounces, sky, 0.375))
+        r.reset_stats()
+        t0 = time.perf_counter(); r.render(spp); r.synchronize(); dt_off = time.perf_counter() - t0
+        st_off = r.stats()
+        img_off = r.read_accumulation()[0]
+        layouts = r.layout_info() if hasattr(r, "layout_info") else None
+    finally:
+        r.close()
+    rays = st["closest_rays"] + st["shadow_rays"]
+    out = dict(workload=f"{info['name']}, {width}x{height}, {bounces} bounces, {sps} spp per step x {steps} steps = {spp} spp", scene_triangles=info.get("triangles"),
+               steps=steps, value=round(rays / dt * 1e-6, 1), unit="Mrays/s", repeats=[round((s_["closest_rays"] + s_["shadow_rays"]) / t_ * 1e-6, 1) for (t_, s_) in runs],
+               ms_per_step=round(dt / steps * 1e3, 3),
+               kernel_ms={k: round(st[k], 3) for k in ("ms_raygen", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")},
+               value_with_cache_off=round((st_off["closest_rays"] + st_off["shadow_rays"]) / dt_off * 1e-6, 1),
+               cache_off_image_bit_identical=bool(np.array_equal(np.asarray(img_off).view(np.uint32), np.asarray(image).view(np.uint32))),
+               record_layouts=layouts)
+    if with_parity:
+        out["parity_crop"] = parity_of_crop(pt, width, height, bounces, first_frame, spp, image)
+    out["wall_s"] = round(time.time() - t_all, 1)
+    log(f"[bench] regime {name}: {out['value']} Mrays/s (cache off {out['value_with_cache_off']}), parity {out.get('parity_crop', {}).get('verdict')}, {out['wall_s']} s")
+    return out
+
+
+def cold_start(pt, width, height, bounces, device, spp=256):
+    """BASELINE.json config 3 as written, on a FRESH renderer: 256 spp in one call, no warm-up steps -- the occluder grid empty, kShadowFirstLook not yet running
+    (it starts with the second batch), caches cold.  Path state is allocated before the clock (hipMalloc is not the hot path)."""
+    import rayfinder_amd as rf
+    cam, sky = rf.fly_camera(width, height), rf.make_sky()
+    r = rf.ReferencePathTracer(rf.make_render_parameters(width, height, cam, spp, bounces, sky, 0.25), pt.scene(), device_ordinal=device)
+    try:
+        r.set_option("reserve_samples", spp)
+        r.set_timing(True); r.reset_stats(); r.synchronize()
+        t0 = time.perf_counter(); r.render(spp); r.synchronize(); dt = time.perf_counter() - t0
+        st = r.stats()
+    finally:
+        r.close()
+    return dict(value=round((st["closest_rays"] + st["shadow_rays"]) / dt * 1e-6, 1), spp=spp, timed_region_s=round(dt, 4), ms_shadow=round(st["ms_shadow"], 3),
+                ms_closest=round(st["ms_closest"], 3), note="fresh renderer, no warm-up steps, one render call of 256 spp (config 3 as written); allocation outside the clock")
 
 
 def find_pmc_profile(workload):
@@ -456,6 +567,8 @@ def main():
     ap.add_argument("--no-live-counters", action="store_true", help="skip the two extra passes under `rocprofv3 --pmc` that measure the roofline's `traffic` in this run "
                     "(the committed per-ray profile x the live ray count is used then)")
     ap.add_argument("--no-occluder-ablation", action="store_true", help="skip the untimed repeat with the occluder cache off")
+    ap.add_argument("--no-regimes", action="store_true", help="skip the `regimes` block (the clutter and out-of-cache stand-ins, each on a renderer of its own after the headline) "
+                    "and the cold-start figure")
     ap.add_argument("--repeat", type=int, default=3, help="timed regions of K steps each; the median one is reported (min / max beside it)")
     args = ap.parse_args()
 
@@ -582,6 +695,7 @@ def main():
     R = max(args.repeat, 1)
     r.set_timing(True)
     runs = []
+    exchange_ms = []
     parts = None
     for rep in range(R):
         r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.5 + 0.125 * (rep % 2)))
@@ -598,6 +712,12 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        ex_ms = comm.last_exchange_ms() if comm is not None else None      # (outside the clock: HIP events around this rank's sends / receives + un-tile)
+        if ex_ms is not None and dist is not None:
+            t = torch.tensor([ex_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ex_ms = float(t.item())
+        exchange_ms.append(None if ex_ms is None else round(ex_ms, 4))
         runs.append((elapsed, r.stats(), r.bounce_stats()))
     order = sorted(range(R), key=lambda i: runs[i][0])
     median_run = order[(R - 1) // 2]          # the lower median for even R: a repeat that was actually measured
@@ -707,6 +827,10 @@ def main():
             "rays": {"closest": int(closest_total), "shadow": int(shadow_total), "abandoned": int(abandoned_total)},
             "kernel_ms_rank0": {k: round(s[k], 3) for k in ("ms_raygen", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")},
             "exchange": exchange,
+            "exchange_ms": ({"per_repeat_max_over_ranks": exchange_ms, "median": sorted(x for x in exchange_ms if x is not None)[(len([x for x in exchange_ms if x is not None]) - 1) // 2]
+                             if any(x is not None for x in exchange_ms) else None,
+                             "what": "HIP events on each rank's stream around its part of the one frame-end exchange (ncclSend / ncclRecv group + the root's un-tile), "
+                                     "max over ranks; inside the timed region"} if multi else None),
             "rccl_ranks": rccl_ranks,      # ncclCommCount of the product's communicator (0: no RCCL exchange in this run -- one GPU, or the fallback)
             "device_memory": r.memory_info(),
             "nan_pixels": nan_pixels,
@@ -726,6 +850,24 @@ def main():
             out["bvh_build"] = {"triangles": int(len(tris)), "nodes": int(len(host_nodes)), "host_ms_1_thread": round(host_ms, 2),
                                 "gpu_ms": round(float(gpu_ms), 3), "node_bytes_identical": bool(host_nodes.tobytes() == gpu_nodes.tobytes()),
                                 "triangle_order_identical": bool(np.array_equal(host_idx, gpu_idx))}
+        if world == 1 and not multi and not args.no_regimes and not scene_path and max(args.scene_scale, 1) == 1 and args.scene_detail == "plain":
+            # (the headline's renderer is done: its 90 GB of path state go back before the others allocate theirs)
+            r.close()
+            try:
+                out["occluder_cache"]["value_cold_start"] = cold_start(pt, W, H, B, local_rank)
+                log(f"[bench] cold start: {out['occluder_cache']['value_cold_start']}")
+            except Exception as e:  # noqa: BLE001  (an extra: it must not take the headline down)
+                out["occluder_cache"]["value_cold_start"] = {"error": str(e)[:300]}
+            regimes = {}
+            for (name, detail, scale, steps) in (("clutter", "clutter", 1, 4), ("out_of_cache_x8", "plain", 8, 2)):
+                try:
+                    regimes[name] = run_regime(name, detail, scale, steps, SPS, W, H, B, local_rank, with_parity=not args.no_cpu_baseline)
+                except Exception as e:  # noqa: BLE001
+                    regimes[name] = {"error": str(e)[:300]}
+                    log(f"[bench] regime {name} FAILED: {e}")
+            regimes["note"] = ("the other stand-ins (DESIGN.md 8.1), each on a renderer of its own after the headline: same recipe (2 warm-up steps, 3 timed regions, the median), "
+                               "one more repeat with the occluder cache off, the oracle on a 48x32 crop of the timed frames; `value` above stays on the plain atrium")
+            out["regimes"] = regimes
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -255,10 +255,34 @@ RF_API int  rf_comm_all_reduce_max(rf_comm* c, rf_renderer* r /* NULL: default s
 /* What RCCL reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice); any pointer may be NULL.
  * A scaling line that says N GPUs carries rccl_ranks == N from here. */
 RF_API int  rf_comm_info(const rf_comm* c, uint32_t* rccl_ranks, uint32_t* rccl_rank, int32_t* device_ordinal);
+/* Device time of this rank's LAST rf_renderer_gather_frame (HIP events on the handle's stream around the sends / receives and, on the root, the un-tile):
+ * what the one exchange of the multi-GPU path costs once the rank's own frame has drained.  Waits for that exchange; -1 before the first.  (No reference
+ * counterpart: the reference is single-device, reference_path_tracer.cpp:565-595.) */
+RF_API int  rf_comm_last_exchange_ms(rf_comm* c, double* ms_out);
 /* Device memory held by a handle: path state + queues (140 B per path slot, allocated on demand for the largest batch traced),
  * the batch depth in use (lowered automatically when the device has less free memory than the default wants: same image,
  * more batches) and the resident scene.  Any pointer may be NULL. */
 RF_API int  rf_renderer_memory_info(const rf_renderer* r, uint64_t* path_state_bytes, uint64_t* paths_allocated, uint64_t* max_paths_per_batch, uint64_t* scene_bytes);
+/* Which BVH record layout the handle reads in the closest-hit / any-hit launch of each bounce -- what it picked BY ITSELF for this scene at upload (from the
+ * binary16 surface-area ratio of the boxes, the tree's size against the Infinity Cache, the median leaf size against the sun disc) plus any option set since.
+ * No reference counterpart (the reference has one node layout, bvh.hpp:14-21); lets a caller -- and the parity tests -- see that a result was produced by the
+ * layouts the renderer would use on its own.  Layout codes: RF_LAYOUT_*. */
+enum { RF_LAYOUT_BINARY = 0, RF_LAYOUT_COMPACT = 1, RF_LAYOUT_HOT = 2, RF_LAYOUT_QUAD = 3, RF_LAYOUT_QUAD_HALF = 4, RF_LAYOUT_QUAD_LOCAL = 5, RF_LAYOUT_OCT = 6,
+       RF_LAYOUT_SCALAR = 7, RF_LAYOUT_PACKET = 8 };
+typedef struct rf_layout_info
+{
+    uint32_t closest_layout[16];      /* bounce 1..16 */
+    uint32_t shadow_layout[16];
+    uint32_t shadow_cached[16];       /* 1: the any-hit launch of that bounce starts at the occluder cache's entries */
+    uint32_t occluder_hint_levels;    /* 0: the cache remembers leaves; n: a record n quad levels above the leaf */
+    uint32_t shadow_first_look_from_bounce;
+    uint32_t dense_leaf_min;          /* leaf phases with a leaf of this many triangles or more run over dense (lane, triangle) pairs; 0: never */
+    uint32_t legacy_layouts_compiled; /* 1: a build with RF_EXP_LEGACY_LAYOUTS (the compact-capable / 32-byte records and the packet kernel exist) */
+    float    quad_half_area_ratio;
+    float    reserved;
+    uint64_t tree_bytes;              /* quad records + triangle records */
+} rf_layout_info;
+RF_API int  rf_renderer_layout_info(const rf_renderer* r, rf_layout_info* out);
 /* Host helpers (no GPU needed). */
 /* The point-to-point operations rank `rank` posts (one RCCL group) for a gather to `root`: exactly the list
  * rf_renderer_gather_frame executes.  Offsets / counts in tiles (1024 float4): a receive lands at offset_tiles of the root's

@@ -391,6 +391,12 @@ class TileComm:
         check(lib.rf_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
         return dict(rccl_ranks=n.value, rccl_rank=r.value, device=d.value)
 
+    def last_exchange_ms(self):
+        """Device time of this rank's last gather_frame (HIP events around the sends / receives + the root's un-tile); -1 before the first."""
+        v = C.c_double(-1.0)
+        check(lib.rf_comm_last_exchange_ms(self._h, C.byref(v)))
+        return v.value
+
     def read_frame(self, renderer, width, height):
         """Root: the gathered row-major (H, W, 4) float image."""
         img = np.zeros((height, width, 4), np.float32)
@@ -484,6 +490,18 @@ class ReferencePathTracer:
         s = _ffi.Stats()
         check(lib.rf_renderer_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    LAYOUT_NAMES = ("binary", "compact", "hot", "quad", "quad_half", "quad_local", "oct", "scalar", "packet")
+
+    def layout_info(self, bounces=8):
+        """rf_renderer_layout_info: the record layout this renderer reads in the closest-hit / any-hit launch of bounce 1..n (what it picked by itself for the
+        scene + any option set since), whether that any-hit launch starts at the occluder cache, and the per-scene parameters behind the choice."""
+        raw = np.zeros(48 + 4 + 2 + 2, np.uint32)      # 3 x 16 words, 4 words, 2 floats, one u64
+        check(lib.rf_renderer_layout_info(self._h, _ptr(raw)))
+        n = min(bounces, 16)
+        return dict(closest=[self.LAYOUT_NAMES[v] for v in raw[:n]], shadow=[self.LAYOUT_NAMES[v] for v in raw[16:16 + n]], shadow_cached=[bool(v) for v in raw[32:32 + n]],
+                    occluder_hint_levels=int(raw[48]), shadow_first_look_from_bounce=int(raw[49]), dense_leaf_min=int(raw[50]), legacy_layouts_compiled=bool(raw[51]),
+                    quad_half_area_ratio=float(raw[52:53].view(np.float32)[0]), tree_bytes=int(raw[54:56].view(np.uint64)[0]))
 
     def memory_info(self):
         """Device memory held by the handle: dict(path_state_bytes, paths_allocated, max_paths_per_batch, scene_bytes)."""

@@ -134,6 +134,7 @@ SIGNATURES = {
     "rf_comm_read_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_comm_all_reduce_max": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "rf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "rf_renderer_layout_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rf_renderer_memory_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4),
     "rf_gather_plan": (C.c_int, [C.c_uint32] * 6 + [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_gather_layout": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -148,6 +149,7 @@ SIGNATURES = {
     "rf_bvh_visualizer_pass": (C.c_int, [C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_build_bvh": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_int32)]),
+    "rf_comm_last_exchange_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "rf_check_wide_layouts": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
     "rf_wide_layout_stats": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "rf_build_bvh_gpu": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -508,6 +508,15 @@ int rf_comm_info(const rf_comm* c, uint32_t* rccl_ranks, uint32_t* rccl_rank, in
     });
 }
 
+int rf_comm_last_exchange_ms(rf_comm* c, double* ms_out)
+{
+    return guarded([&] {
+        require(c && ms_out, "null argument");
+        *ms_out = c->impl->lastExchangeMs();
+        return RF_OK;
+    });
+}
+
 int rf_gather_plan(uint32_t width, uint32_t height, uint32_t world_size, uint32_t rank, uint32_t root, uint32_t flags, rf_gather_op* ops, uint32_t* num_ops)
 {
     return guarded([&] {
@@ -523,6 +532,21 @@ int rf_gather_plan(uint32_t width, uint32_t height, uint32_t world_size, uint32_
             std::memcpy(ops, plan.data(), plan.size() * sizeof(rf::GatherOp));
         }
         *num_ops = static_cast<uint32_t>(plan.size());
+        return RF_OK;
+    });
+}
+
+int rf_renderer_layout_info(const rf_renderer* r, rf_layout_info* out)
+{
+    return guarded([&] {
+        require(r && out, "null argument");
+        uint32_t layouts[48], misc[4];
+        float    ratio = 0.0f;
+        uint64_t tree = 0;
+        r->impl->layoutInfo(layouts, misc, ratio, tree);
+        for (int i = 0; i < 16; ++i) out->closest_layout[i] = layouts[i], out->shadow_layout[i] = layouts[16 + i], out->shadow_cached[i] = layouts[32 + i];
+        out->occluder_hint_levels = misc[0], out->shadow_first_look_from_bounce = misc[1], out->dense_leaf_min = misc[2], out->legacy_layouts_compiled = misc[3];
+        out->quad_half_area_ratio = ratio, out->reserved = 0.0f, out->tree_bytes = tree;
         return RF_OK;
     });
 }

@@ -140,6 +140,10 @@ struct TileComm::Impl
     DevBuf<double>   scalar;
     uint32_t         imageW = 0, imageH = 0;
     bool             firstGatherDone = false;
+    // HIP events around the last exchange on the caller's stream (sends / receives + the root's un-tile): what the frame-end gather costs THIS rank
+    // once its own frame kernels have drained (lastExchangeMs())
+    hipEvent_t       exchangeStart = nullptr, exchangeStop = nullptr;
+    bool             exchangeTimed = false;
 
     // A new frame size: the previous gather's kUntile (on the caller's non-blocking stream) may still be reading the tables and
     // the staging / image buffers that are about to be replaced -- wait for it, then upload on that same stream.
@@ -207,6 +211,11 @@ TileComm::~TileComm()
         (void)hipSetDevice(mImpl->device);
         (void)ncclCommDestroy(mImpl->comm);
     }
+    if (mImpl && mImpl->exchangeStart)
+    {
+        (void)hipEventDestroy(mImpl->exchangeStart);
+        (void)hipEventDestroy(mImpl->exchangeStop);
+    }
 }
 
 uint32_t TileComm::rank() const { return mImpl->rank; }
@@ -264,6 +273,13 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
             if (e) (void)hipEventDestroy(e);
         }
     } eventGuard{queuedBefore};
+    if (m.exchangeStart == nullptr)
+    {
+        RF_HIP(hipEventCreate(&m.exchangeStart));
+        RF_HIP(hipEventCreate(&m.exchangeStop));
+    }
+    m.exchangeTimed = false;
+    RF_HIP(hipEventRecord(m.exchangeStart, stream));
     RF_NCCL(ncclGroupStart());
     try
     {
@@ -334,13 +350,31 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
         }
         m.firstGatherDone = true;
     }
-    if (!isRoot) return nullptr;
+    if (!isRoot)
+    {
+        RF_HIP(hipEventRecord(m.exchangeStop, stream));
+        m.exchangeTimed = true;
+        return nullptr;
+    }
 
     const uint32_t numTiles = g.tilesX * g.tilesY;
     hipLaunchKernelGGL(kUntile, dim3(numTiles), dim3(256), 0, stream, m.staging.p, static_cast<const float4*>(compactDevice), loopback ? 0xFFFFFFFFu : m.rank,
                        g.rankFirstTile[m.rank], m.dTileSlot.p, m.dTileOwner.p, width, height, g.tilesX, m.image.p);
     RF_HIP(hipGetLastError());
+    RF_HIP(hipEventRecord(m.exchangeStop, stream));
+    m.exchangeTimed = true;
     return m.image.p;
+}
+
+double TileComm::lastExchangeMs()
+{
+    Impl& m = *mImpl;
+    if (!m.exchangeTimed) return -1.0;
+    RF_HIP(hipSetDevice(m.device));
+    RF_HIP(hipEventSynchronize(m.exchangeStop));
+    float ms = 0.0f;
+    RF_HIP(hipEventElapsedTime(&ms, m.exchangeStart, m.exchangeStop));
+    return static_cast<double>(ms);
 }
 
 void TileComm::readFrame(float* dstHost, void* streamHandle)

@@ -65,6 +65,9 @@ public:
     // (returned; valid until the next gather); other ranks get nullptr.  loopback: the root's own shard also
     // travels through ncclSend / ncclRecv (to itself) instead of being read in place -- the world-size-1 self-test.
     const void* gatherFrame(const void* compactDevice, uint32_t width, uint32_t height, uint32_t root, void* stream, bool loopback = false);
+    // Device time of the LAST gatherFrame() on the caller's stream, HIP events around it: from the moment the rank's queued frame kernels have drained and the
+    // exchange starts to the end of its sends / receives (+ the un-tile on the root).  Waits for that exchange; -1 before the first one.
+    double lastExchangeMs();
     // Root: wait for the stream and copy the gathered image to the host (width * height * 4 floats, row-major).
     void readFrame(float* dstHost, void* stream);
     // Max over ranks of a host double / barrier (timing plumbing for callers that have no other collective layer).

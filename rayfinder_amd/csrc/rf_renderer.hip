@@ -754,6 +754,8 @@ constexpr uint32_t kLineWords = 16;
 constexpr uint32_t kRefillMin = 40; // refill once this many lanes are idle (r02 sweep: 32 -> 40 = +1 %)
 constexpr uint32_t kLeafVote = 20; // leave the descent loop when fewer lanes than this are descending (16..24 measure the same)
 
+// record layouts (kTraceWide's COMPACT parameter) + the two paths outside kTraceWide
+constexpr int kLayoutBinary = 0, kLayoutCompact = 1, kLayoutHot = 2, kLayoutQuad = 3, kLayoutQuadHalf = 4, kLayoutQuadLocal = 5, kLayoutOct = 6, kLayoutScalar = 7, kLayoutPacket = 8;
 constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
 constexpr uint32_t kFlagUniformTri = 8u;          // the same for the triangles of a leaf phase
 constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path for records that every descending lane shares
@@ -851,6 +853,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     static_assert(!(COMPACT != 0 && COUNT), "the compact-record and quad-record variants have no counting build");
     static_assert(COMPACT >= 0 && COMPACT <= 6, "0: 64-byte records, 1: compact-capable, 2: 32-byte, 3: quad, 4: half-precision quad, 5: local-grid quad, 6: local-grid oct (closest-hit)");
     static_assert(!(COMPACT == 6 && ANY_HIT), "the oct records serve the closest-hit launches (the any-hit launches start at occluder-cache entries that name quad records)");
+#if !defined(RF_EXP_LEGACY_LAYOUTS)
+    static_assert(COMPACT != 1 && COMPACT != 2, "the compact-capable and the 32-byte records are experiment-build layouts (make EXP=RF_EXP_LEGACY_LAYOUTS)");
+#endif
     constexpr bool kConservative = COMPACT == 4 || COMPACT == 5 || COMPACT == 6; // interior tests accept a superset; every leaf's EXACT box is applied at the leaf
     __shared__ uint2 sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
@@ -2223,6 +2228,7 @@ __global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, Wi
 // Rays that are not class A (rf_wide.hpp), and the members of a packet whose shared stack outgrows kPacketDepth, are
 // redone by the scalar reference-ordered traversal, as in kTraceWide.
 // ------------------------------------------------------------------------------------------------
+#if defined(RF_EXP_LEGACY_LAYOUTS) // (round 5: the packet kernel lost to kTraceWide in round 2 and has been off since; `make EXP=RF_EXP_LEGACY_LAYOUTS` builds it, the compact-capable and the 32-byte records)
 constexpr int kPacketDepth = 24; // shared stack entries per wave (<= 64): per-lane tmin [depth][lane] in LDS + one child word per entry
 
 template<bool ANY_HIT>
@@ -2452,6 +2458,7 @@ __global__ __launch_bounds__(kBlock, 6) void kTracePacket(DeviceScene scene, Wid
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
 }
+#endif // RF_EXP_LEGACY_LAYOUTS
 
 // Query path: offset hit points of a hit stream (the render path does this in kShade).
 __global__ void kHitPoints(DeviceScene scene, const float4* hit, P3* rayO, uint32_t n)
@@ -2974,8 +2981,7 @@ struct Renderer::Impl
     uint32_t               optQuadHalfFromBounce = 0, optQuadHalfShadowFromBounce = 0; // quad launches of bounce >= this read the 64-byte half-precision quad records (0: never; set to 1 at upload when the scene suits them)
     float                  quadHalfAreaRatio = 0.0f;
     uint32_t               optQuadLocalFromBounce = 0, optQuadLocalShadowFromBounce = 0; // ... the 64-byte local-grid quad records (0: never; set to 1 at upload when the half-precision ones do not suit the scene)
-    // closest-hit launches of bounce >= this read the 128-byte oct records (three levels per fetch; 0: never).  Set at upload for scenes whose records + triangles
-    // do not fit the Infinity Cache (kOctMinTreeBytes): there a launch is bound by random lines per second, and a 128-byte line costs about what a 64-byte one does
+    // closest-hit launches of bounce >= this read the 128-byte oct records (three levels per fetch; 0: never -- the default: measured slower, see the upload)
     uint32_t               optOctFromBounce = 0;
     uint64_t               treeBytes = 0; // quad records + triangle records: what the traversal launches touch
     uint32_t               optHotFromBounce = 0, optHotShadowFromBounce = 0; // the 32-byte records (all six planes carried) from this bounce on (0: never); takes precedence
@@ -3159,6 +3165,123 @@ struct Renderer::Impl
         pendingBatches.clear();
     }
 
+    // ---- which record layout a launch reads (kTraceWide's COMPACT parameter), and the launch itself
+    struct WideArgs
+    {
+        PathStreams     ps;
+        const uint32_t* queue;
+        const uint32_t* count;
+        uint32_t*       cursor;
+        uint32_t        refillMin, chunk;
+        float           tMax;
+        dim3            grid;
+        uint32_t        extraLds;
+    };
+    template<bool ANY_HIT, bool COUNT, bool NEAREST, int COMPACT>
+    void launchWide(const WideScene& w, const WideArgs& a, uint32_t flags)
+    {
+        hipLaunchKernelGGL((kTraceWide<ANY_HIT, COUNT, NEAREST, COMPACT>), a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr,
+                           a.refillMin, optLeafVote, a.chunk, a.tMax, flags);
+    }
+    // the layout a test asks for, if this scene has it (else the binary records)
+    int layoutIfPresent(int want) const
+    {
+        switch (want)
+        {
+        case kLayoutOct: return wide.oct != nullptr ? want : kLayoutBinary;
+        case kLayoutQuadLocal: return wide.quadLocal != nullptr ? want : kLayoutBinary;
+        case kLayoutQuadHalf: return wide.quadHalf != nullptr ? want : kLayoutBinary;
+        case kLayoutQuad: return wide.quad != nullptr ? want : kLayoutBinary;
+        case kLayoutHot: return wide.hot != nullptr ? want : kLayoutBinary;
+        case kLayoutCompact: return wide.compact != nullptr ? want : kLayoutBinary;
+        default: return kLayoutBinary;
+        }
+    }
+    void launchClosestWide(int layout, bool count, const WideScene& w, const WideArgs& a, uint32_t flags)
+    {
+        if (count) return launchWide<false, true, false, 0>(w, a, flags);
+        switch (layout)
+        {
+        case kLayoutOct: return launchWide<false, false, false, 6>(w, a, flags);
+        case kLayoutQuadLocal: return launchWide<false, false, false, 5>(w, a, flags);
+        case kLayoutQuadHalf: return launchWide<false, false, false, 4>(w, a, flags);
+        case kLayoutQuad: return launchWide<false, false, false, 3>(w, a, flags);
+#if defined(RF_EXP_LEGACY_LAYOUTS)
+        case kLayoutHot: return launchWide<false, false, false, 2>(w, a, flags);
+        case kLayoutCompact: return launchWide<false, false, false, 1>(w, a, flags);
+#endif
+        default: return launchWide<false, false, false, 0>(w, a, flags);
+        }
+    }
+    // nearest: entries ordered by slab distance (NEAREST_FIRST); else record order (the conservative layouts' default: optShadowSignOrder)
+    void launchShadowWide(int layout, bool nearest, bool count, const WideScene& w, const WideArgs& a, uint32_t flags)
+    {
+        if (count) return nearest ? launchWide<true, true, true, 0>(w, a, flags) : launchWide<true, true, false, 0>(w, a, flags);
+        switch (layout)
+        {
+        case kLayoutQuadLocal: return nearest ? launchWide<true, false, true, 5>(w, a, flags) : launchWide<true, false, false, 5>(w, a, flags);
+        case kLayoutQuadHalf: return nearest ? launchWide<true, false, true, 4>(w, a, flags) : launchWide<true, false, false, 4>(w, a, flags);
+        case kLayoutQuad: return nearest ? launchWide<true, false, true, 3>(w, a, flags) : launchWide<true, false, false, 3>(w, a, flags);
+#if defined(RF_EXP_LEGACY_LAYOUTS)
+        case kLayoutHot: return launchWide<true, false, true, 2>(w, a, flags);
+        case kLayoutCompact: return launchWide<true, false, true, 1>(w, a, flags);
+#endif
+        default: return nearest ? launchWide<true, false, true, 0>(w, a, flags) : launchWide<true, false, false, 0>(w, a, flags);
+        }
+    }
+    // The layout the renderer picks BY ITSELF for the closest-hit / any-hit launch of a bounce (the per-scene defaults set at upload + the options; reported by
+    // rf_renderer_layout_info and used by traceBatch): kLayoutScalar = the one-ray-per-thread kernels (trees the packed tests cannot serve), kLayoutPacket = kTracePacket
+    int closestLayoutFor(uint32_t bounce) const
+    {
+        if (traversalVariant == 0) return kLayoutScalar;
+        if (counting) return kLayoutBinary;
+#if defined(RF_EXP_LEGACY_LAYOUTS)
+        if (bounce <= optPacketBounces) return kLayoutPacket;
+#endif
+        const bool  quadNow = wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
+        // A camera that stands outside the conservative records' origin bound (4 R + 1 for a root box within +-R: a turntable shot from far away) would
+        // send EVERY primary ray to the scalar traversal (2 x the launch, tools/gpu_far_camera.py): that launch reads the exact quad records, which have
+        // no such bound.  Later bounces start on surfaces, inside the bound.
+        const float camReach = std::max({std::fabs(params.camera.origin.x), std::fabs(params.camera.origin.y), std::fabs(params.camera.origin.z)}) + (std::fabs(params.camera.lensRadius) * 2.0f);
+        const bool  primaryOutside = bounce == 1u && !(camReach <= wide.originBound);
+        if (quadNow && !primaryOutside)
+        {
+            if (wide.oct != nullptr && optOctFromBounce != 0u && bounce >= optOctFromBounce) return kLayoutOct;
+            if (wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce) return kLayoutQuadHalf;
+            if (wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce) return kLayoutQuadLocal;
+        }
+        if (quadNow) return kLayoutQuad;
+        if (wide.hot != nullptr && optHotFromBounce != 0u && bounce >= optHotFromBounce) return kLayoutHot;
+        if (wide.compact != nullptr && optCompactFromBounce != 0u && bounce >= optCompactFromBounce) return kLayoutCompact;
+        return kLayoutBinary;
+    }
+    int shadowLayoutFor(uint32_t bounce) const
+    {
+        if (traversalVariant == 0) return kLayoutScalar;
+#if defined(RF_EXP_LEGACY_LAYOUTS)
+        if (!counting && bounce <= optPacketBounces) return kLayoutPacket;
+#endif
+        if (counting || !shadowNearestFirst) return kLayoutBinary;
+        const bool quadShadowNow = optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
+        if (quadShadowNow)
+        {
+            if (wide.quadLocal != nullptr && optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce) return kLayoutQuadLocal;
+            if (wide.quadHalf != nullptr && optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce) return kLayoutQuadHalf;
+            if (wide.quad != nullptr) return kLayoutQuad;
+        }
+        if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce) return kLayoutHot;
+        if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce) return kLayoutCompact;
+        return kLayoutBinary;
+    }
+    // does the any-hit launch of this bounce start at the occluder cache's entries? (kTraceWide, kFlagOccluderCache)
+    bool cachedShadowFor(uint32_t bounce) const
+    {
+        const int layout = shadowLayoutFor(bounce);
+        const bool conservative = layout == kLayoutQuadLocal || layout == kLayoutQuadHalf;
+        const bool exactQuad = layout == kLayoutQuad && leafBoxesValid; // (its leaf visits then apply the box in the leaf's triangle record)
+        return !counting && shadowNearestFirst && (conservative || exactQuad) && bounce <= optOccluderCacheBounces && optOccluderGridCells != 0u;
+    }
+
     // Test hook (option query_variant = 2): arbitrary rays through the render path's persistent
     // traversal kernel.  closest: out0 = hit stream {tri, u, v, t}, out1 = rayO stream (offset hit
     // point); shadow: out0 = rad stream, .x != 0 iff the ray is unoccluded.
@@ -3187,6 +3310,7 @@ struct Renderer::Impl
         RF_HIP(hipMemcpyAsync(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice, stream));
         PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
         const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
+        const WideArgs wa{ps, queueA.ptr, queueCounts.ptr, queueCounts.ptr + kLineWords, optRefillMin, optChunk, tMax, grid, 0u};
         if (shadow)
         {
             // rad = 0, pending = 1: rad.x becomes visibility * SOLAR_INV_PDF
@@ -3194,60 +3318,13 @@ struct Renderer::Impl
             RF_HIP(hipMemcpyAsync(sPending.ptr, ones.data(), n * sizeof(P3), hipMemcpyHostToDevice, stream));
             RF_HIP(hipMemsetAsync(sRad.ptr, 0, n * sizeof(float4), stream));
             RF_HIP(hipStreamSynchronize(stream)); // `ones` leaves scope before the launches are waited for
-            if (shadowNearestFirst && optQueryCompact == 5 && wide.quadLocal != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (optQueryCompact == 5 && wide.quadLocal != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (shadowNearestFirst && optQueryCompact == 4 && wide.quadHalf != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (optQueryCompact == 4 && wide.quadHalf != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (shadowNearestFirst && optQueryCompact == 3 && wide.quad != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (optQueryCompact == 3 && wide.quad != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, false, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (shadowNearestFirst && optQueryCompact == 2 && wide.hot != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (shadowNearestFirst && optQueryCompact == 1 && wide.compact != nullptr)
-                hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else if (shadowNearestFirst)
-                hipLaunchKernelGGL((kTraceWide<true, false, true>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
-            else
-                hipLaunchKernelGGL((kTraceWide<true, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, kFlagShadowDirFromStream | denseFlag);
+            // (the ray-query entry points take the layout the test asks for -- query_compact -- where the scene has it; the oct records serve closest-hit rays only)
+            const int layout = layoutIfPresent((optQueryCompact == kLayoutOct || (!shadowNearestFirst && optQueryCompact < kLayoutQuad)) ? kLayoutBinary : optQueryCompact);
+            launchShadowWide(layout, shadowNearestFirst, false, wide, wa, kFlagShadowDirFromStream | denseFlag);
         }
         else
         {
-            if (optQueryCompact == 6 && wide.oct != nullptr)
-                hipLaunchKernelGGL((kTraceWide<false, false, false, 6>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
-            else if (optQueryCompact == 5 && wide.quadLocal != nullptr)
-                hipLaunchKernelGGL((kTraceWide<false, false, false, 5>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
-            else if (optQueryCompact == 4 && wide.quadHalf != nullptr)
-                hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
-            else if (optQueryCompact == 3 && wide.quad != nullptr)
-                hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
-            else if (optQueryCompact == 2 && wide.hot != nullptr)
-                hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
-            else if (optQueryCompact == 1 && wide.compact != nullptr)
-                hipLaunchKernelGGL((kTraceWide<false, false, false, 1>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
-            else
-                hipLaunchKernelGGL((kTraceWide<false, false>), grid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, queueA.ptr, queueCounts.ptr,
-                                   queueCounts.ptr + kLineWords, counters.ptr, optRefillMin, optLeafVote, optChunk, tMax, denseFlag);
+            launchClosestWide(layoutIfPresent(optQueryCompact), false, wide, wa, denseFlag);
             hipLaunchKernelGGL(kHitPoints, dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
         }
         RF_HIP(hipGetLastError());
@@ -3362,52 +3439,25 @@ struct Renderer::Impl
             // ... and the coherent launches of the first bounces, whose rays are short and alike, claim larger chunks (one cursor atomic = one
             // wave-wide stall: bounce 1 -4 % at 256 entries, the deep bounces +0.5 %)
             const uint32_t chunkNow = bounce <= optChunkEarlyBounces ? optChunkEarly : optChunk;
-            const bool     quadNow = wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
-            // A camera that stands outside the conservative records' origin bound (4 R + 1 for a root box within +-R: a turntable shot from far away) would
-            // send EVERY primary ray to the scalar traversal (2 x the launch, tools/gpu_far_camera.py): that launch reads the exact quad records, which have
-            // no such bound.  Later bounces start on surfaces, inside the bound.
-            const float    camReach = std::max({std::fabs(params.camera.origin.x), std::fabs(params.camera.origin.y), std::fabs(params.camera.origin.z)}) +
-                                   (std::fabs(params.camera.lensRadius) * 2.0f);
-            const bool     primaryOutside = bounce == 1u && !(camReach <= wide.originBound);
-            const bool     halfOk = wide.quadHalf != nullptr && optQuadHalfFromBounce != 0u && bounce >= optQuadHalfFromBounce && !primaryOutside;
-            const bool     localOk = wide.quadLocal != nullptr && optQuadLocalFromBounce != 0u && bounce >= optQuadLocalFromBounce && !primaryOutside;
-            const bool     octOk = wide.oct != nullptr && optOctFromBounce != 0u && bounce >= optOctFromBounce && !primaryOutside;
-            const bool     halfNow = quadNow && (halfOk || localOk || octOk);
-            const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (quadNow && !halfNow ? optRefillMinDeepQuad : optRefillMinDeep) : optRefillMin;
+            const int      layoutClosest = closestLayoutFor(bounce);
+            const bool     conservativeClosest = layoutClosest == kLayoutOct || layoutClosest == kLayoutQuadHalf || layoutClosest == kLayoutQuadLocal;
+            const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (layoutClosest == kLayoutQuad ? optRefillMinDeepQuad : optRefillMinDeep) : optRefillMin;
+            (void)conservativeClosest;
             launchTimed(1, [&] {
-                if (traversalVariant == 0)
+                if (layoutClosest == kLayoutScalar)
                 {
                     if (counting)
                         hipLaunchKernelGGL(kTraceClosest<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
                     else
                         hipLaunchKernelGGL(kTraceClosest<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
                 }
-                else if (counting)
-                    hipLaunchKernelGGL((kTraceWide<false, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, uniformFlag);
-                else if (bounce <= optPacketBounces)
+#if defined(RF_EXP_LEGACY_LAYOUTS)
+                else if (layoutClosest == kLayoutPacket)
                     hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
-                else if (quadNow && octOk)
-                    hipLaunchKernelGGL((kTraceWide<false, false, false, 6>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
-                else if (quadNow && halfOk)
-                    hipLaunchKernelGGL((kTraceWide<false, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
-                else if (quadNow && localOk)
-                    hipLaunchKernelGGL((kTraceWide<false, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
-                else if (wide.quad != nullptr && optQuadFromBounce != 0u && bounce >= optQuadFromBounce && !((optQuadExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
-                    hipLaunchKernelGGL((kTraceWide<false, false, false, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
-                else if (wide.hot != nullptr && optHotFromBounce != 0u && bounce >= optHotFromBounce)
-                    hipLaunchKernelGGL((kTraceWide<false, false, false, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
-                else if (wide.compact != nullptr && optCompactFromBounce != 0u && bounce >= optCompactFromBounce)
-                    hipLaunchKernelGGL((kTraceWide<false, false, false, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
+#endif
                 else
-                    hipLaunchKernelGGL((kTraceWide<false, false>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, cursorClosest,
-                                       counters.ptr, refillClosest, optLeafVote, chunkNow, kTMax, uniformFlag);
+                    launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds},
+                                      uniformFlag);
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
             launchTimed(2, [&] {
@@ -3422,11 +3472,8 @@ struct Renderer::Impl
             });
             // occluder cache (kTraceWide, kFlagOccluderCache): the conservative-record any-hit launches of bounces 1..optOccluderCacheBounces; their rays are
             // short (a third of the steps), so the deep launches refill earlier
-            const bool     quadShadowNow = optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u);
-            const bool     conservativeShadowNow = quadShadowNow && ((wide.quadLocal != nullptr && optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce) ||
-                                                                      (wide.quadHalf != nullptr && optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce));
-            const bool     exactQuadShadowNow = quadShadowNow && !conservativeShadowNow && wide.quad != nullptr && leafBoxesValid; // (its leaf visits then apply the box in the leaf's triangle record)
-            const bool     cachedShadow = traversalVariant != 0 && !counting && bounce > optPacketBounces && shadowNearestFirst && (conservativeShadowNow || exactQuadShadowNow) && bounce <= optOccluderCacheBounces;
+            const int      layoutShadow = shadowLayoutFor(bounce);
+            const bool     cachedShadow = layoutShadow != kLayoutScalar && layoutShadow != kLayoutPacket && cachedShadowFor(bounce);
             // ... behind kShadowFirstLook (see there) from the second batch on: the first batch of a renderer fills the grid (the traversal kernel's own first look serves)
             const bool      firstLook = cachedShadow && occluderHintLevels == 0u && optShadowFirstLookFromBounce != 0u && bounce >= optShadowFirstLookFromBounce && bounce <= 64u && occluderGridWarm && firstLookHoldOff == 0u;
             uint32_t* const listCount = listCounts + kLine * (bounce - 1);
@@ -3442,60 +3489,25 @@ struct Renderer::Impl
                     hipLaunchKernelGGL(kShadowFirstLook, lookGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, qIn, listCount, counters.ptr, kTMax, bounce == 1 ? 1u : 0u);
                     wide.rayList = qIn;
                 }
-                if (traversalVariant == 0)
+                if (layoutShadow == kLayoutScalar)
                 {
                     if (counting)
                         hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
                     else
                         hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
                 }
-                else if (!counting && bounce <= optPacketBounces)
+#if defined(RF_EXP_LEGACY_LAYOUTS)
+                else if (layoutShadow == kLayoutPacket)
                     hipLaunchKernelGGL((kTracePacket<true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, counters.ptr, kTMax,
                                        shadowFlags & kFlagFirstBounce);
-                else if (shadowNearestFirst)
-                {
-                    if (counting)
-                        hipLaunchKernelGGL((kTraceWide<true, true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    else if (wide.quadLocal != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
-                             optQuadLocalShadowFromBounce != 0u && bounce >= optQuadLocalShadowFromBounce)
-                    {
-                        if (optShadowSignOrder)
-                            hipLaunchKernelGGL((kTraceWide<true, false, false, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                        else
-                            hipLaunchKernelGGL((kTraceWide<true, false, true, 5>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    }
-                    else if (wide.quadHalf != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u) &&
-                             optQuadHalfShadowFromBounce != 0u && bounce >= optQuadHalfShadowFromBounce)
-                    {
-                        if (optShadowSignOrder)
-                            hipLaunchKernelGGL((kTraceWide<true, false, false, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                        else
-                            hipLaunchKernelGGL((kTraceWide<true, false, true, 4>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                               cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    }
-                    else if (wide.quad != nullptr && optQuadShadowFromBounce != 0u && bounce >= optQuadShadowFromBounce && !((optQuadShadowExceptMask >> std::min(bounce - 1u, 31u)) & 1u))
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 3>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    else if (wide.hot != nullptr && optHotShadowFromBounce != 0u && bounce >= optHotShadowFromBounce)
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 2>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    else if (wide.compact != nullptr && optCompactShadowFromBounce != 0u && bounce >= optCompactShadowFromBounce)
-                        hipLaunchKernelGGL((kTraceWide<true, false, true, 1>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                    else
-                        hipLaunchKernelGGL((kTraceWide<true, false, true>), persistentGrid, dim3(kBlock), optExtraLds, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow,
-                                           cursorShadow, counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
-                }
-                else if (counting)
-                    hipLaunchKernelGGL((kTraceWide<true, true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+#endif
                 else
-                    hipLaunchKernelGGL((kTraceWide<true, false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countShadow, cursorShadow,
-                                       counters.ptr, optRefillMin, optLeafVote, chunkNow, kTMax, shadowFlags);
+                {
+                    // the conservative layouts (VALU bound) visit a record's entries in record order unless asked otherwise; the exact and binary records nearest-first
+                    const bool conservative = layoutShadow == kLayoutQuadLocal || layoutShadow == kLayoutQuadHalf;
+                    const bool nearest = shadowNearestFirst && !(conservative && optShadowSignOrder);
+                    launchShadowWide(layoutShadow, nearest, counting, wide, WideArgs{ps, qOut, countShadow, cursorShadow, optRefillMin, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds}, shadowFlags);
+                }
             }, bounce - 1);
             std::swap(qIn, qOut);
             std::swap(ps.rayD, ps.rayDOut);
@@ -3564,12 +3576,15 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         m.bigLeaves.upload(wb.bigLeaves.data(), wb.bigLeaves.size());
         m.wide.nodes = m.wideNodes.ptr;
         m.wide.compact = nullptr;
+#if defined(RF_EXP_LEGACY_LAYOUTS)
         if (wb.compactUsable && !wb.compact.empty())
         {
             m.wideCompact.upload(wb.compact.data(), wb.compact.size());
             m.wide.compact = m.wideCompact.ptr;
         }
+#endif
         m.wide.hot = m.wide.own = nullptr;
+#if defined(RF_EXP_LEGACY_LAYOUTS)
         if (wb.hotUsable && !wb.hot.empty())
         {
             m.wideHot.upload(wb.hot.data(), wb.hot.size());
@@ -3577,6 +3592,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             m.wide.hot = m.wideHot.ptr;
             m.wide.own = m.wideOwn.ptr;
         }
+#endif
         m.wide.quad = nullptr;
         if (wb.quadUsable && !wb.quad.empty())
         {
@@ -3613,8 +3629,9 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         {
             m.wideOct.upload(wb.oct.data(), wb.oct.size());
             m.wide.oct = m.wideOct.ptr;
-            // from bounce 2, like the local-grid quad records (the coherent launch of bounce 1 gains nothing from fewer, larger fetches)
-            m.optOctFromBounce = m.treeBytes >= kOctMinTreeBytes ? 2u : 0u;
+            // NOT selected by default: measured 17 % SLOWER than the local-grid quad records on the out-of-cache atrium (profiles/r05_hbm: the launch is bound by
+            // L1 -> L2 requests, and a 112-byte record is two of them per step for 0.65 x the steps); option oct_from_bounce turns it on
+            m.optOctFromBounce = 0u;
         }
         m.wide.bigLeaves = m.bigLeaves.ptr;
         m.wide.rootLo = wb.rootLo;
@@ -3946,13 +3963,33 @@ void Renderer::clearAccumulationIfStale()
     m.imageDirty = false;
 }
 
+void Renderer::layoutInfo(uint32_t (&layouts)[48], uint32_t (&misc)[4], float& quadHalfAreaRatio, uint64_t& treeBytes) const
+{
+    const Impl& m = *mImpl;
+    for (uint32_t b = 1; b <= 16; ++b)
+    {
+        const int ls = m.shadowLayoutFor(b);
+        layouts[b - 1] = static_cast<uint32_t>(m.closestLayoutFor(b));
+        layouts[16 + b - 1] = static_cast<uint32_t>(ls);
+        layouts[32 + b - 1] = (ls != kLayoutScalar && ls != kLayoutPacket && m.cachedShadowFor(b)) ? 1u : 0u;
+    }
+    misc[0] = m.occluderHintLevels, misc[1] = m.optShadowFirstLookFromBounce, misc[2] = m.optDenseLeafMin;
+#if defined(RF_EXP_LEGACY_LAYOUTS)
+    misc[3] = 1u;
+#else
+    misc[3] = 0u;
+#endif
+    quadHalfAreaRatio = m.quadHalfAreaRatio;
+    treeBytes = m.treeBytes;
+}
+
 void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, uint64_t& maxPathsPerBatch, uint64_t& sceneBytes) const
 {
     const Impl& m = *mImpl;
     pathsAllocated = m.allocatedPaths;
     pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
     maxPathsPerBatch = m.effectivePaths ? std::min(m.effectivePaths, m.maxPaths) : m.maxPaths;
-    sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.wideQuadLocal.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
+    sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.wideQuadLocal.count + m.wideOct.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
                  m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2) + m.occluderGrid.count * sizeof(uint32_t); // (the occluder grid: allocated by the first batch)
 }
 uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }

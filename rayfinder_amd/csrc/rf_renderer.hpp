@@ -131,6 +131,9 @@ public:
     void     clearAccumulationIfStale();
     // Device memory held: path state + queues (allocated on demand, kBytesPerPath per path slot), the batch depth in use, and
     // the resident scene (BVH layouts, triangles, shading records, textures).
+    // rf_renderer_layout_info: layouts[0..15] = closest-hit, [16..31] = any-hit, [32..47] = any-hit launch starts at the occluder cache; misc = {hint levels, first look from bounce,
+    // dense leaf min, legacy build}
+    void     layoutInfo(uint32_t (&layouts)[48], uint32_t (&misc)[4], float& quadHalfAreaRatio, uint64_t& treeBytes) const;
     void     memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, uint64_t& maxPathsPerBatch, uint64_t& sceneBytes) const;
     uint64_t accumulationBytes() const;
     void     bindAccumulationBuffer(void* devicePtr, uint64_t bytes);

@@ -53,9 +53,6 @@ constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is i
 // -> closest-hit: half-precision up to kQuadHalfMaxAreaRatio, local grid beyond; shadow: local grid up to kQuadLocalShadowMaxAreaRatio,
 //    exact quad records beyond.
 constexpr float    kQuadHalfMaxAreaRatio = 1.075f, kQuadLocalShadowMaxAreaRatio = 1.10f;
-// Scenes whose quad records + triangle records reach this many bytes read the 128-byte oct records in their closest-hit launches from bounce 2 on
-// (WideBuild::oct): half the 256-MiB Infinity Cache -- below it the tree is served on-die and the 64-byte records' shorter step wins (round 5, profiles/r05_hbm)
-constexpr uint64_t kOctMinTreeBytes = 128ull << 20;
 constexpr uint32_t kQuadEmpty = 0xFFFFFFFFu; // quad records: an entry slot that holds no node (its child is a leaf and fills one slot only)
 #if defined(RF_EXP_WAVES)
 constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment builds: resident workgroups per CU of kTraceWide
@@ -159,9 +156,11 @@ struct WideBuild
     float               quadLocalAreaRatio = 0.0f;
     // Oct records (kTraceWide<..., COMPACT = 6>, round 5): the local-grid idea one level further -- one 128-byte-aligned record per interior node reachable
     // from the root in steps of THREE levels holds the boxes of the node's (up to eight) GREAT-GRANDCHILDREN, i.e. three levels of the reference's tree per
-    // dependent fetch.  For scenes whose tree does not fit the Infinity Cache: there the traversal is bound by how many random lines per second the memory
-    // system delivers, and a random 128-byte line costs about what a 64-byte one does (tools/microbench/fetch_calib.hip `wide`, 2-GiB table: 64-byte records
-    // 60 G/s = 3.8 TB/s, 128-byte records 51 G/s = 6.5 TB/s).  Slot e = 4 c + 2 g + k: child c of the node, its child g, that one's child k; a child or
+    // dependent fetch.  Built for scenes whose tree does not fit the Infinity Cache, on the calibration that a random 128-byte line costs the memory system about
+    // what a 64-byte one does (tools/microbench/fetch_calib.hip `wide`, 2-GiB table: 64-byte records 60 G/s = 3.8 TB/s, 128-byte records 51 G/s = 6.5 TB/s) -- and
+    // MEASURED SLOWER in the kernel (out-of-cache atrium, bounces 3-8: +17 %; profiles/r05_hbm): those launches sit on the L1 -> L2 request rate (17.7 requests per ray
+    // at 78 G/s), a 112-byte record is two 64-byte requests where the quad record is one, and 0.65 x the steps x 2 = 1.2 x the requests.  Kept as an option
+    // (oct_from_bounce), bit-identical and tested; not selected by default.  Slot e = 4 c + 2 g + k: child c of the node, its child g, that one's child k; a child or
     // grandchild that is a leaf fills the FIRST slot of its range, the rest of the range is empty.  Layout (uint4 pieces; the eighth is padding):
     //     {anchor.x anchor.y anchor.z scale.x} {scale.y scale.z orderLo orderHi} {X01 X23 X45 X67} {Y01 Y23 Y45 Y67} {Z01 Z23 Z45 Z67} {word0..3} {word4..7}
     // planes as in the local-grid quad records (axis word of slots 2 j, 2 j + 1 = {lo hi lo hi} bytes; an EMPTY slot holds lo = 255, hi = 0 on every axis: it fails

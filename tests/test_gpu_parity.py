@@ -485,7 +485,11 @@ def test_occluder_cache_engages_on_the_atrium(atrium):
     assert np.array_equal(np.asarray(res["on"][1]["shadow_rays"]), np.asarray(res["off"][1]["shadow_rays"]))
     assert off["shadow_rays_hint_answered"] == 0
     assert on["shadow_rays_hint_answered"] > 0.6 * deep, (on["shadow_rays_hint_answered"], deep)
-    assert on["ms_shadow"] < 0.85 * off["ms_shadow"], (on["ms_shadow"], off["ms_shadow"])
+    # (the TIME the cache saves is bench.py's business -- `occluder_cache.ms_shadow` against `ms_shadow_with_cache_off` in the line: a timing assertion in the parity suite
+    # turns a perf wobble of a shared or throttled box into a red run that hides every later test under `pytest -x`, VERDICT r4 -- here it is a warning)
+    if not on["ms_shadow"] < 0.85 * off["ms_shadow"]:
+        import warnings
+        warnings.warn(f"occluder cache: shadow launches {on['ms_shadow']:.2f} ms with the cache against {off['ms_shadow']:.2f} ms without (expected < 85 %)")
     assert np.array_equal(bits(res["on"][2]), bits(res["off"][2]))
 
 
@@ -874,6 +878,52 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
     assert np.array_equal(np.isnan(g), np.isnan(c)), (kind, "NaN pixels differ")
     same = (bits(g) == bits(c)) | np.isnan(g)
     assert same.all(), (kind, W, H, spp, bounces, int((~same).sum()), float(np.nanmax(np.abs(g - c))))
+
+
+# ------------------------------------------------------------------ round 5: the renderer's OWN layout choice on a finely tessellated scene, under the oracle's eye
+def test_fine_scene_renderer_picks_its_layouts_itself_and_matches_the_oracle():
+    """VERDICT r4 item 3.  Until now the driver-run suite forced the record layouts (query_compact on Duck, option sets in the fuzz): the selector -- exact quad
+    records for the primary launch, the local-grid records from bounce 2, exact quad records for the any-hit launches, occluder-cache entries that name a record
+    above the leaf -- only ever ran in builder-run bench commands.  Here the atrium at 4 x tessellation (4.2 M triangles of 4.5 cm: binary16 area ratio 1.117, beyond both
+    thresholds of rf_wide.hpp) is rendered with NO option set; rf_renderer_layout_info says what the renderer took, and 1080p crops at 8 spp / 8 bounces equal the
+    oracle bit for bit -- with the occluder cache warm (second batch) and with it off."""
+    from rayfinder_amd import scenes
+    rf.set_bake_bvh_builder(0)                                        # the GPU builder: same node bytes as the host's (tests/test_gpu_bvh_build.py), seconds at this size
+    try:
+        pt, info = scenes.atrium(4)
+    finally:
+        rf.set_bake_bvh_builder(None)
+    assert info["triangles"] > 4_000_000
+    W, H, spp, bounces = 1920, 1080, 8, 8
+    r, params = _renderer(pt, W, H, spp, bounces)
+    li = r.layout_info(bounces)
+    assert li["quad_half_area_ratio"] > 1.10 and not li["legacy_layouts_compiled"], li
+    assert li["closest"][0] == "quad" and all(x == "quad_local" for x in li["closest"][1:]), li        # binary16 too coarse: exact records for the coherent primary launch, the local grid from bounce 2
+    assert all(x == "quad" for x in li["shadow"]) and all(li["shadow_cached"]), li                     # a shadow ray crosses the whole scene: exact boxes, started at the occluder cache
+    assert li["occluder_hint_levels"] >= 1 and li["dense_leaf_min"] >= 1, li                           # 4.5-cm leaves against the sun disc's footprint: the cache remembers records, not leaves
+    for _ in range(2):                                                 # two batches of 4 spp: the second starts on a warm occluder grid
+        r.render(spp // 2)
+    img, acc = r.read_accumulation()
+    assert acc == spp
+    sc, _ = oracle_scene_from_pt(pt)
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    for (x0, y0) in [(944, 524), (200, 860), (1500, 300)]:            # centre, floor at the lower left, upper storey
+        ref, _ = orc.render(sc, rp, 0, spp, x0, y0, x0 + 32, y0 + 32)
+        g, c = img[y0:y0 + 32, x0:x0 + 32, :3], ref[y0:y0 + 32, x0:x0 + 32, :3]
+        assert np.array_equal(np.isnan(g), np.isnan(c))
+        assert ((bits(g) == bits(c)) | np.isnan(g)).all(), (x0, y0, int((bits(g) != bits(c)).sum()))
+    s = r.stats()
+    assert s["abandoned_rays"] == 0
+    # the same frames without the cache: the selector's other choices stay, the image does not move
+    r.set_option("occluder_cache_bounces", 0)
+    assert not any(r.layout_info(bounces)["shadow_cached"])
+    r.set_render_parameters(rf.make_render_parameters(W, H, params.camera, spp, bounces, params.sky, 0.3))
+    r.render(spp)
+    off, _ = r.read_accumulation()
+    r.close()
+    # (frameCount went on counting: sample indices n = frameCount % spp are the same eight, so the sums are the same sums in another order of batches -- per pixel the
+    # k-ordered accumulation makes them bit-identical, kAccumulateRuns)
+    assert np.array_equal(bits(off[..., :3]), bits(img[..., :3]))
 
 
 # ------------------------------------------------------------------ round 2: stack overflow is counted, hostile scenes are refused
