@@ -153,13 +153,14 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
         affinity = None
     singles, st = [], None
     try:
-        for (px, py) in ((x0, y0), (x0 - width // 4, y0), (x0 + width // 4, y0 + height // 8)):
+        # (one untimed pass first: the first touch of the oracle's scene arrays -- 150 MB of nodes, triangles and texels -- is page faults and cold caches,
+        # the 0.35-against-0.73 spread of the earlier single-thread figures)
+        orc.render(sc, rp, first_frame, 2, x0, y0, x0 + cw, y0 + ch, accumulated_start=0)
+        for _ in range(3):
             t0 = time.perf_counter()
-            _, st_i = orc.render(sc, rp, first_frame, 2, px, py, px + cw, py + ch, accumulated_start=0)
+            _, st = orc.render(sc, rp, first_frame, 2, x0, y0, x0 + cw, y0 + ch, accumulated_start=0)
             dt1 = max(time.perf_counter() - t0, 1e-4)
-            singles.append((st_i.closestRays + st_i.shadowRays) / dt1)
-            if st is None:
-                st = st_i
+            singles.append((st.closestRays + st.shadowRays) / dt1)
     finally:
         if affinity is not None:
             os.sched_setaffinity(0, affinity)
@@ -213,7 +214,7 @@ def cpu_baseline(pt, width, height, bounces, first_frame, spp, seconds_budget, g
                 host_hardware_threads=hw_threads, cpu_quota=quota,
                 single_thread_value=round(single * 1e-6, 3),
                 single_thread=dict(value=round(single * 1e-6, 3), samples=[round(v * 1e-6, 3) for v in singles], pinned=affinity is not None,
-                                   note="one thread pinned to one allowed CPU (sched_setaffinity), three 32x8 patches x 2 frames, the median"),
+                                   note="one thread pinned to one allowed CPU (sched_setaffinity), the centred 32x8 patch x 2 frames three times after one untimed pass, the median"),
                 at_quota_cores=quota_leg,
                 bvh_visualizer_primary_rays=dict(unit="Mrays/s", image=f"{vw}x{vh}", one_thread=round(viz_single * 1e-6, 3),
                                                  all_cores=round(vw * vh / vdt * 1e-6, 3), cores=cores,
@@ -262,13 +263,13 @@ def run_regime(name, detail, scale, steps, sps, width, height, bounces, device, 
         dt, st = sorted(runs, key=lambda x: x[0])[(repeats - 1) // 2]
         image = r.read_accumulation()[0]
         first_frame = warm + (repeats - 1) * spp
+        layouts = r.layout_info(bounces)          # what the renderer picked by itself for this scene (rf_renderer_layout_info)
         r.set_option("occluder_cache_bounces", 0)
         r.set_render_parameters(rf.make_render_parameters(width, height, cam, spp, bounces, sky, 0.375))
         r.reset_stats()
         t0 = time.perf_counter(); r.render(spp); r.synchronize(); dt_off = time.perf_counter() - t0
         st_off = r.stats()
         img_off = r.read_accumulation()[0]
-        layouts = r.layout_info() if hasattr(r, "layout_info") else None
     finally:
         r.close()
     rays = st["closest_rays"] + st["shadow_rays"]
@@ -330,7 +331,7 @@ def live_traffic(argv_scene, steps, sps, width, height, bounces, timeout_s=90):
         return None
     out = {}
     child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "0", "--repeat", "1", "--spp-per-step", str(sps), "--width", str(width),
-             "--height", str(height), "--bounces", str(bounces), "--no-cpu-baseline", "--no-counting", "--no-live-counters"] + argv_scene
+             "--height", str(height), "--bounces", str(bounces), "--no-cpu-baseline", "--no-counting", "--no-live-counters", "--no-regimes"] + argv_scene
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["TMPDIR"] = "/tmp"
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -646,7 +647,7 @@ def main():
         err = "" if comm is not None else "no communicator"
         try:
             if comm is not None:
-                r.gather_frame(comm, 0)      # the first exchange is watched: an error after RF_COMM_TIMEOUT_S instead of a hang
+                r.gather_frame(comm, 0, loopback=(world == 1))      # the first exchange is watched: an error after RF_COMM_TIMEOUT_S instead of a hang
                 r.synchronize()
         except Exception as e:  # noqa: BLE001
             err = str(e)
@@ -664,7 +665,7 @@ def main():
 
     def exchange_frame():
         if comm is not None:
-            r.gather_frame(comm, 0)
+            r.gather_frame(comm, 0, loopback=(world == 1))
             return None
         if accum is not None:
             from rayfinder_amd.sharding import gather_device

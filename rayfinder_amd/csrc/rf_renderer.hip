@@ -1731,7 +1731,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         // owner's own walk over the hits, in the same order with the same comparison.  Any-hit: a leaf with a hit among its pairs stops the ray.
         // The block is self-contained (its own leaf decode and exact box test) so that the loop below keeps its registers to itself: what it needs of a leaf's
         // first triangle record is live only inside its own branch.
-        unsigned long long denseDone = 0ull; // lanes whose leaf this block has dealt with
+        bool denseDone = false; // this lane's leaf has been dealt with by this block
         if constexpr (!COUNT)
         {
             const uint32_t     kDenseMin = (flags >> kFlagDenseLeafShift) & 15u;
@@ -1857,10 +1857,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     }
                     else popNext();
                 }
-                denseDone = __ballot(dealt);
+                denseDone = dealt;
             }
         }
-        if (node - kWideLeafBit < kNodeDone - kWideLeafBit && ((denseDone >> lane) & 1ull) == 0ull) // (a lane the dense phase has moved on may hold its NEXT leaf by now: that one waits for the next phase)
+        if (node - kWideLeafBit < kNodeDone - kWideLeafBit && !denseDone) // (a lane the dense phase has moved on may hold its NEXT leaf by now: that one waits for the next phase)
         {
             uint32_t first = node & ((1u << kWideIndexBits) - 1u), n = ((node >> kWideIndexBits) & 7u) + 1u;
             if (n == 8u)
@@ -2964,7 +2964,7 @@ struct Renderer::Impl
     bool     optShadowSignOrder = true; // the half-precision / local-grid shadow launches (VALU bound) visit entries in record order: a cheaper step beats the shorter walks of nearest-first there
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     // leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (kTraceWide; 0: never), from this bounce on
-    uint32_t optDenseLeafMin = 3, optDenseLeafFromBounce = 1;
+    uint32_t optDenseLeafMin = 5, optDenseLeafFromBounce = 1; // (5: the plain atrium's leaves of up to 4 triangles keep the loop -- 3 measured +1 % there; the clutter scene gains the same with 2 .. 5)
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
     uint32_t optRefillMinDeep = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at another count: 22 idle lanes on the 64-byte and the

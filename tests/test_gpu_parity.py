@@ -1320,6 +1320,10 @@ def test_bench_line_shape_is_the_same_however_the_rank_was_started(tmp_path):
     assert plain["rays"] == launched["rays"] == looped["rays"]
     assert plain["rccl_ranks"] == 0 and plain["exchange"] == "none"
     assert looped["rccl_ranks"] == 1 and "C++ RCCL exchange" in looped["exchange"] and "FALLBACK" not in looped["exchange"]
+    # the exchange is priced in every line that runs it (round 5): HIP events around the rank's sends / receives + un-tile, one figure per repeat
+    assert plain["exchange_ms"] is None and launched["exchange_ms"] is None
+    ex = looped["exchange_ms"]
+    assert len(ex["per_repeat_max_over_ranks"]) == 3 and all(0.0 < v < 1000.0 for v in ex["per_repeat_max_over_ranks"]) and ex["median"] == sorted(ex["per_repeat_max_over_ranks"])[1]
 
 
 def test_product_computed_checker_inputs_equal_the_oracles_own():
