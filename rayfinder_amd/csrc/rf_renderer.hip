@@ -842,7 +842,7 @@ constexpr int wideStackDepth()
     return (COUNT && !NEAREST_FIRST) ? 28 : kWideLdsStack;
 }
 
-template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, int COMPACT = 0>
+template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, int COMPACT = 0, bool DENSE_LEAVES = false>
 __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
                                                                                         const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
                                                                                         DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
@@ -1730,9 +1730,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         // moment <= the entry value, so it is among the hits here; a hit here that the walk would reject (t >= the rayTMax an earlier triangle left) is rejected by the
         // owner's own walk over the hits, in the same order with the same comparison.  Any-hit: a leaf with a hit among its pairs stops the ray.
         // The block is self-contained (its own leaf decode and exact box test) so that the loop below keeps its registers to itself: what it needs of a leaf's
-        // first triangle record is live only inside its own branch.
+        // first triangle record is live only inside its own branch.  And it is a template parameter (DENSE_LEAVES): its mere presence costs the closest-hit launches
+        // of a scene that never uses it 2.5 % (profiles/r05_leaf/ab_presence.log), so scenes without long leaves run the instantiations without it.
         bool denseDone = false; // this lane's leaf has been dealt with by this block
-        if constexpr (!COUNT)
+        if constexpr (!COUNT && DENSE_LEAVES)
         {
             const uint32_t     kDenseMin = (flags >> kFlagDenseLeafShift) & 15u;
             constexpr uint32_t kDenseMaxLeaf = 16u; // (longer leaves keep the loop below)
@@ -2965,6 +2966,7 @@ struct Renderer::Impl
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
     // leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (kTraceWide; 0: never), from this bounce on
     uint32_t optDenseLeafMin = 5, optDenseLeafFromBounce = 1; // (5: the plain atrium's leaves of up to 4 triangles keep the loop -- 3 measured +1 % there; the clutter scene gains the same with 2 .. 5)
+    uint32_t maxLeafTriangles = 0; // of the scene (upload): scenes without a leaf as long as the threshold run the instantiations WITHOUT the dense block
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
     uint32_t optRefillMinDeep = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at another count: 22 idle lanes on the 64-byte and the
@@ -3177,10 +3179,10 @@ struct Renderer::Impl
         dim3            grid;
         uint32_t        extraLds;
     };
-    template<bool ANY_HIT, bool COUNT, bool NEAREST, int COMPACT>
+    template<bool ANY_HIT, bool COUNT, bool NEAREST, int COMPACT, bool DENSE = false>
     void launchWide(const WideScene& w, const WideArgs& a, uint32_t flags)
     {
-        hipLaunchKernelGGL((kTraceWide<ANY_HIT, COUNT, NEAREST, COMPACT>), a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr,
+        hipLaunchKernelGGL((kTraceWide<ANY_HIT, COUNT, NEAREST, COMPACT, DENSE>), a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr,
                            a.refillMin, optLeafVote, a.chunk, a.tMax, flags);
     }
     // the layout a test asks for, if this scene has it (else the binary records)
@@ -3197,9 +3199,24 @@ struct Renderer::Impl
         default: return kLayoutBinary;
         }
     }
+    // does a launch with these flags want the dense leaf phase?  (the scene has a leaf as long as the threshold the flags carry: the instantiations that
+    // contain the block -- the layouts the renderer picks by itself -- are used only then)
+    bool denseWanted(uint32_t flags) const
+    {
+        const uint32_t threshold = (flags >> kFlagDenseLeafShift) & 15u;
+        return threshold != 0u && maxLeafTriangles >= threshold;
+    }
     void launchClosestWide(int layout, bool count, const WideScene& w, const WideArgs& a, uint32_t flags)
     {
         if (count) return launchWide<false, true, false, 0>(w, a, flags);
+        if (denseWanted(flags))
+            switch (layout)
+            {
+            case kLayoutQuadLocal: return launchWide<false, false, false, 5, true>(w, a, flags);
+            case kLayoutQuadHalf: return launchWide<false, false, false, 4, true>(w, a, flags);
+            case kLayoutQuad: return launchWide<false, false, false, 3, true>(w, a, flags);
+            default: break;
+            }
         switch (layout)
         {
         case kLayoutOct: return launchWide<false, false, false, 6>(w, a, flags);
@@ -3217,6 +3234,12 @@ struct Renderer::Impl
     void launchShadowWide(int layout, bool nearest, bool count, const WideScene& w, const WideArgs& a, uint32_t flags)
     {
         if (count) return nearest ? launchWide<true, true, true, 0>(w, a, flags) : launchWide<true, true, false, 0>(w, a, flags);
+        if (denseWanted(flags))
+        {
+            if (layout == kLayoutQuadLocal && !nearest) return launchWide<true, false, false, 5, true>(w, a, flags);
+            if (layout == kLayoutQuadHalf && !nearest) return launchWide<true, false, false, 4, true>(w, a, flags);
+            if (layout == kLayoutQuad && nearest) return launchWide<true, false, true, 3, true>(w, a, flags);
+        }
         switch (layout)
         {
         case kLayoutQuadLocal: return nearest ? launchWide<true, false, true, 5>(w, a, flags) : launchWide<true, false, false, 5>(w, a, flags);
@@ -3662,6 +3685,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             for (const BvhNode& nd : sceneView.bvhNodes)
                 if (nd.triangleCount != 0)
                 {
+                    m.maxLeafTriangles = std::max(m.maxLeafTriangles, nd.triangleCount);
                     const float dx = nd.aabb.max.x - nd.aabb.min.x, dy = nd.aabb.max.y - nd.aabb.min.y, dz = nd.aabb.max.z - nd.aabb.min.z;
                     diag.push_back(std::sqrt(dx * dx + dy * dy + dz * dz));
                 }

@@ -170,6 +170,7 @@ def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tm
     # step; 2: 32-byte records, two loads, all six planes carried): the same planes and products, so the same bits on the same
     # hostile rays
     r.set_option("shadow_nearest_first", 1)
+    r.set_option("dense_leaf_min", 2)                     # Duck's leaves hold up to 4 triangles: with the threshold at 2 the leaf phases of modes 3 / 4 / 5 run over dense pairs (round 5)
     for mode in (1, 2, 3, 4, 5, 6):                       # (6: the 128-byte oct records, THREE levels per fetch, closest-hit only; 5: the local-grid quad records; 3: the 128-byte quad records, two levels of the tree per fetch; 4: their
                                                           # half-precision form -- conservative interior tests, exact boxes at the leaves)
         r.set_option("query_compact", mode)
@@ -859,6 +860,8 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
         r.set_option("occluder_cache_bounces", 0)
     if seed % 5 in (2, 4):                                      # kShadowFirstLook from bounce 1 / never (default: from bounce 2, once the grid is warm)
         r.set_option("shadow_first_look_from_bounce", 1 if seed % 5 == 2 else 0)
+    if seed % 5 in (0, 3) or os.environ.get("RF_FUZZ_DENSE"):   # leaf phases over dense (lane, triangle) pairs from 2 / 3 triangles per leaf on (default: 5; "duplicates" scenes have leaves of dozens)
+        r.set_option("dense_leaf_min", 2 + seed % 2)
     if seed % 8 in (2, 6) or os.environ.get("RF_FUZZ_OCT"):     # closest-hit launches on the 128-byte oct records (three levels per fetch) from bounce 1 / 2
         if os.environ.get("RF_FUZZ_OCT"):
             r.set_option("quad_from_bounce", 1)
