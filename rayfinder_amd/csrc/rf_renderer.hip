@@ -1,4 +1,5 @@
-// rf_renderer.hip -- wavefront path tracer for MI355X (gfx950): kernels + host driver.
+// rf_renderer.hip -- wavefront path tracer for MI355X (gfx950): the host driver (the kernels live in rf_trace.hip and rf_shade.hip, what the three
+// units share in rf_kernels.hpp).
 //
 // The reference traces one full path per fragment-shader invocation
 // (src/pt/reference_path_tracer.wgsl:34-64,180-234).  Here the same per-path arithmetic is cut
@@ -20,15 +21,7 @@
 //
 // Kernel grids are sized for the worst case (all paths alive) and read the live count from
 // device memory, so a whole batch is enqueued without any host round trip.
-#include "rf_renderer.hpp"
-
-#include "rf_bvh.hpp"
-#include "rf_camera.hpp"
-#include "rf_data.hpp"
-#include "rf_device.hpp"
-#include "rf_wide.hpp"
-
-#include <hip/hip_runtime.h>
+#include "rf_kernels.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -51,2764 +44,6 @@ bool operator==(const RenderParameters& a, const RenderParameters& b)
 
 namespace
 {
-#define RF_HIP(expr)                                                                                          \
-    do                                                                                                        \
-    {                                                                                                         \
-        const hipError_t _e = (expr);                                                                         \
-        if (_e != hipSuccess)                                                                                 \
-            throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " in " #expr);      \
-    } while (0)
-
-struct __attribute__((packed, aligned(4))) P3
-{
-    float x, y, z;
-};
-
-// Path state.  What one launch writes for the NEXT launch to stream through lives at QUEUE positions: entry q of a
-// bounce's ray queue has its origin, direction, throughput, hit record and pending NEE term at index q of these arrays, so
-// that every launch reads and writes them densely, in queue order (coalesced), however few of the batch's paths are still
-// alive (by bounce 3 half of the slots are dead: slot-indexed, each surviving path cost a 64-byte line per stream).
-// Direction and throughput are double-buffered: kShade reads entry q of the bounce's arrays while other workgroups already
-// write entries of the next queue.  What belongs to the PATH for its whole life stays at its slot: the radiance sum
-// (read by the accumulation in sample order) and the blue-noise pair.
-struct PathStreams
-{
-    P3*     rayO;    // [queue position] origin.xyz of the ray to trace (kRaygen / kShade: the offset hit point)
-    P3*     rayD;    // [queue position] direction.xyz, this bounce's
-    P3*     thr;     // [queue position] throughput.rgb, this bounce's
-    float4* rad;     // [slot] radiance.rgb
-    float4* hit;     // [queue position] {triangle bits, u, v, t}
-    P3*     pending; // [queue position] (throughput * solar radiance) * reflectance, waiting for visibility
-    P3*     noise;   // [queue position] {u.x, cos(2 pi u.y), sin(2 pi u.y)}: the path's one blue-noise pair, this bounce's copy
-    P3*     rayDOut; // [position in the NEXT queue] written by kShade
-    P3*     thrOut;  // [position in the NEXT queue]
-    P3*     noiseOut; // [position in the NEXT queue]: kShade copies the triple along; the shadow launch of the bounce reads it here
-};
-
-// 12-byte load of the xyz part of a float4 stream element (global_load_dwordx3): the L1 -> VGPR return path
-// bounds the traversal kernels, so the unused .w lanes are not fetched
-typedef float v3f __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ Vec3 load3(const float4* p)
-{
-    const v3f v = *reinterpret_cast<const v3f*>(p);
-    return vec3(v.x, v.y, v.z);
-}
-// The queue-position arrays hold PACKED xyz triples (12-byte stride, global_load/store_dwordx3 at 4-byte alignment): they are
-// streamed densely by every launch, so a quarter of their bytes would be padding otherwise.
-__device__ __forceinline__ Vec3 load3(const P3* p)
-{
-    const P3 v = *p;
-    return vec3(v.x, v.y, v.z);
-}
-__device__ __forceinline__ void store3(P3* p, Vec3 v)
-{
-    P3 o;
-    o.x = v.x, o.y = v.y, o.z = v.z;
-    *p = o;
-}
-// The same with the non-temporal hint, for kShade's streams: 100 B per hit written once and read once by the next launches -- tens of GB per bounce that would
-// otherwise push what IS reused (shading records, texels, BVH records, the occluder grid) out of L2 / Infinity Cache: kShade -4.4 % (profiles/r04_occluder/
-// nt_shade2.log).  The hint on kRaygen's stores, kShadowFirstLook's loads and the traversal kernels' hit records as well measured nothing more; on the traversal
-// kernels' own path-state accesses it measured 1 % slower (round 2) -- those stay plain.
-typedef float v3fu __attribute__((ext_vector_type(3), aligned(4)));
-__device__ __forceinline__ void store3nt(P3* p, Vec3 v)
-{
-    v3fu o;
-    o.x = v.x, o.y = v.y, o.z = v.z;
-    __builtin_nontemporal_store(o, reinterpret_cast<v3fu*>(p));
-}
-__device__ __forceinline__ Vec3 load3nt(const P3* p)
-{
-    const v3fu v = __builtin_nontemporal_load(reinterpret_cast<const v3fu*>(p));
-    return vec3(v.x, v.y, v.z);
-}
-
-// Path-state accesses of the traversal kernels (queue entry, origin, direction, result: touched once per ray).  A build with
-// the non-temporal hint on them measured 1 % slower (shadow kernel 32.2 -> 33.3 ms per 32 spp), so they are plain.
-__device__ __forceinline__ Vec3     load3s(const float4* p) { return load3(p); }
-__device__ __forceinline__ Vec3     load3s(const P3* p) { return load3(p); }
-__device__ __forceinline__ uint32_t loadQ(const uint32_t* p) { return *p; }
-__device__ __forceinline__ void     store4s(float4* p, float x, float y, float z, float w) { *p = make_float4(x, y, z, w); }
-
-struct DeviceCounters
-{
-    unsigned long long primaryRays, closestRays, shadowRays;
-    unsigned long long closestNodeVisits, closestTriangleTests, shadowNodeVisits, shadowTriangleTests;
-    unsigned int       stackHigh;
-    unsigned int       pad;
-    unsigned long long closestRecordFetches, shadowRecordFetches; // 64-byte wide records actually fetched (counting build)
-    // wave-level trip counts of kTraceWide's loops (counting build): lane utilisation = lane work / (64 * trips)
-    unsigned long long descendTrips[2], leafTrips[2], leafPhases[2], refillTrips[2], popLaneTrips[2], outerTrips[2];
-    unsigned long long scalarRedo[2]; // rays redone by the scalar traversal (irregular or stack overflow), all builds
-    unsigned long long abandonedRays; // rays whose traversal stack outgrew 96 entries (result = what was found until then), all builds
-    unsigned long long occluderTried, occluderHit, occludedRays; // RF_EXP_PHASE builds: the any-hit launches' occluder cache
-};
-
-struct FrameParams
-{
-    uint32_t width, height;
-    Camera   camera;
-    uint32_t samplesPerPixel, numBounces;
-    uint32_t firstFrame; // frameCount of sample 0 of this batch
-    uint32_t numSamples; // samples traced in this batch
-    uint32_t numTiles;
-    uint32_t pixelsPadded; // numTiles * 1024
-    // Path slot <-> (sample k of the batch, local pixel lp).  Groups of 2^g consecutive local pixels (g = 0: one pixel,
-    // 6: one 8x8 block, 10: one tile) keep all their samples together:
-    //     slot = (((lp >> g) * numSamples + k) << g) + (lp & (2^g - 1)),
-    // so that neighbours in the ray queues (= in a wave, on a CU) are the same few pixels' other samples rather than the
-    // same sample's other pixels.  kSlotSampleMajor: the round-1 order, slot = k * pixelsPadded + lp.
-    uint32_t slotGroupShift;
-    // Order of a pixel group's samples inside its run of slots: position p holds sample samplePerm[p] (inverse:
-    // sampleInvPerm).  nullptr = identity.  kSamplePermutation sorts the batch's samples along a Z-order curve through their
-    // R2 points, so that a wave's rays (a few neighbouring pixels x consecutive positions) leave the same surface in similar
-    // directions (u = fract(blueNoise(pixel) + r2(sample)): the same pair drives every bounce, wgsl:52-55,194,209).
-    const uint32_t* samplePerm;
-    const uint32_t* sampleInvPerm;
-    uint32_t tilesX;
-};
-
-constexpr uint32_t kSlotSampleMajor = 31u;
-
-__device__ __forceinline__ void slotToSamplePixel(const FrameParams& fp, uint32_t slot, uint32_t& k, uint32_t& lp)
-{
-    if (fp.slotGroupShift == kSlotSampleMajor)
-    {
-        k = slot / fp.pixelsPadded;
-        lp = slot % fp.pixelsPadded;
-    }
-    else
-    {
-        const uint32_t g = fp.slotGroupShift, chunk = slot >> g;
-        k = chunk % fp.numSamples;
-        lp = ((chunk / fp.numSamples) << g) + (slot & ((1u << g) - 1u));
-    }
-}
-__device__ __forceinline__ size_t samplePixelToSlot(const FrameParams& fp, uint32_t k, uint32_t lp)
-{
-    if (fp.slotGroupShift == kSlotSampleMajor) return static_cast<size_t>(k) * fp.pixelsPadded + lp;
-    const uint32_t g = fp.slotGroupShift;
-    return ((static_cast<size_t>(lp >> g) * fp.numSamples + k) << g) + (lp & ((1u << g) - 1u));
-}
-
-// local pixel index (tile-major, 8x8 pixel blocks = one wave) -> image coordinates
-__device__ __forceinline__ bool localPixelToXY(const FrameParams& fp, const uint32_t* tileIds, uint32_t lp, uint32_t& x, uint32_t& y)
-{
-    const uint32_t tile = tileIds[lp >> 10];
-    const uint32_t w = lp & 1023u;
-    const uint32_t block = w >> 6, lane = w & 63u;
-    x = (tile % fp.tilesX) * kTileSize + (block & 3u) * 8u + (lane & 7u);
-    y = (tile / fp.tilesX) * kTileSize + (block >> 2) * 8u + (lane >> 3);
-    return x < fp.width && y < fp.height;
-}
-
-// Block-wide append of up to ITEMS candidates per thread with ONE atomic per block.  A single
-// device-scope counter saturates near 90 atomics/us (MI355X_MICROARCH.md "dequeue"), so a
-// one-atomic-per-wave append made the shade and raygen launches atomic-bound (130 k waves per
-// launch = 1.5 ms); per block of 1024 entries it is 8 k atomics.  Must be reached by every thread of
-// the block.  Output order: wave-major, then item, then lane (stays local to the block's entries).
-constexpr int kItems = 4; // queue entries per thread in the per-entry kernels
-
-template<int ITEMS>
-__device__ __forceinline__ void blockAppend(const bool (&keep)[ITEMS], const uint32_t (&slot)[ITEMS], uint32_t* queue, uint32_t* count, uint32_t* sScratch,
-                                            uint32_t (*position)[ITEMS] = nullptr)
-{
-    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
-    uint32_t       offs[ITEMS];
-    uint32_t       waveTotal = 0;
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k)
-    {
-        const unsigned long long mask = __ballot(keep[k]);
-        offs[k] = waveTotal + __popcll(mask & ((1ull << lane) - 1ull));
-        waveTotal += __popcll(mask);
-    }
-    if (lane == 0) sScratch[wave] = waveTotal;
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        const uint32_t total = sScratch[0] + sScratch[1] + sScratch[2] + sScratch[3];
-        sScratch[4] = total ? atomicAdd(count, total) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = sScratch[4];
-    for (uint32_t w = 0; w < wave; ++w) base += sScratch[w];
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k)
-    {
-        if (keep[k]) queue[base + offs[k]] = slot[k];
-        if (position) (*position)[k] = base + offs[k]; // where the entry went (meaningful where keep[k])
-    }
-    __syncthreads(); // sScratch may be reused by the next append
-}
-
-__device__ __forceinline__ unsigned long long waveSum(unsigned long long v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;
-}
-__device__ __forceinline__ uint32_t waveMax(uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = max(v, static_cast<uint32_t>(__shfl_down(v, off)));
-    return v;
-}
-
-// Inclusive scan over the 64 lanes of a wave, DPP only (no LDS): row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 / 31 across them.
-// Must run with all 64 lanes enabled.  MAX: running maximum (of unsigned values; identity 0), else running sum.
-template<bool MAX>
-__device__ __forceinline__ uint32_t waveScanInclusive(uint32_t x)
-{
-    const auto step = [&](auto ctrl, auto rowMask) {
-        const uint32_t y = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), decltype(ctrl)::value, decltype(rowMask)::value, 0xF, true));
-        x = MAX ? max(x, y) : x + y;
-    };
-    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{}); // row_shr:1
-    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{}); // row_shr:2
-    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{}); // row_shr:4
-    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{}); // row_shr:8
-    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}); // row_bcast:15 into rows 1 and 3
-    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{}); // row_bcast:31 into rows 2 and 3
-    return x;
-}
-__device__ __forceinline__ uint32_t laneGather(uint32_t value, uint32_t srcLane) { return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(srcLane << 2), static_cast<int>(value))); }
-__device__ __forceinline__ float    laneGather(float value, uint32_t srcLane) { return __uint_as_float(laneGather(__float_as_uint(value), srcLane)); }
-
-// Z-order key of sample k's R2 point (the temporal part of animatedBlueNoise, wgsl:606-615; only the ORDER matters)
-__device__ __forceinline__ uint32_t sampleKey(uint32_t firstFrame, uint32_t spp, uint32_t k)
-{
-    const uint32_t n = (firstFrame + k) % spp;
-    const float    rx = wFract(0.7548776662466927f * static_cast<float>(n)), ry = wFract(0.5698402909980532f * static_cast<float>(n));
-    uint32_t       x = static_cast<uint32_t>(rx * 65536.0f) & 0xFFFFu, y = static_cast<uint32_t>(ry * 65536.0f) & 0xFFFFu;
-    const auto     spread = [](uint32_t v) {
-        v = (v | (v << 8)) & 0x00FF00FFu;
-        v = (v | (v << 4)) & 0x0F0F0F0Fu;
-        v = (v | (v << 2)) & 0x33333333u;
-        v = (v | (v << 1)) & 0x55555555u;
-        return v;
-    };
-    return spread(x) | (spread(y) << 1);
-}
-
-// perm / inverse of the batch's samples by (key, k): S is at most a few thousand, one thread per sample counts its rank
-__global__ void kSamplePermutation(uint32_t firstFrame, uint32_t spp, uint32_t numSamples, uint32_t* perm, uint32_t* inv)
-{
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= numSamples) return;
-    const uint32_t mine = sampleKey(firstFrame, spp, k);
-    uint32_t       rank = 0;
-    for (uint32_t j = 0; j < numSamples; ++j)
-    {
-        const uint32_t other = sampleKey(firstFrame, spp, j);
-        rank += (other < mine || (other == mine && j < k)) ? 1u : 0u;
-    }
-    perm[rank] = k;
-    inv[k] = rank;
-}
-
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene scene, const uint32_t* tileIds, PathStreams ps,
-                                                   uint32_t* queue, uint32_t* queueCount, DeviceCounters* counters)
-{
-    __shared__ uint32_t sScratch[8];
-    const uint32_t      total = fp.numSamples * fp.pixelsPadded;
-    bool                keep[kItems];
-    uint32_t            slots[kItems], pos[kItems], px[kItems], py[kItems], sample[kItems];
-    // pass 1: which slots are pixels of the image -> their positions in the first queue
-#pragma unroll
-    for (int k = 0; k < kItems; ++k)
-    {
-        const uint32_t slot = (blockIdx.x * kItems + k) * kBlock + threadIdx.x;
-        bool           valid = slot < total;
-        uint32_t       x = 0, y = 0, sampleIdx = 0, lp = 0;
-        if (valid) slotToSamplePixel(fp, slot, sampleIdx, lp);
-        if (valid) valid = localPixelToXY(fp, tileIds, lp, x, y);
-        keep[k] = valid;
-        slots[k] = slot;
-        px[k] = x, py[k] = y, sample[k] = sampleIdx;
-    }
-    blockAppend<kItems>(keep, slots, queue, queueCount, sScratch, &pos);
-    // pass 2: the rays, written at their queue positions
-#pragma unroll
-    for (int k = 0; k < kItems; ++k)
-    {
-        if (!keep[k]) continue;
-        const uint32_t x = px[k], y = py[k];
-        const uint32_t frame = fp.firstFrame + (fp.samplePerm ? fp.samplePerm[sample[k]] : sample[k]);
-        float          nx, ny;
-        animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
-
-        // fragment centre (wgsl:36-43); v runs down the image
-        const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(fp.width);
-        const float v = (static_cast<float>(y) + 0.5f) / static_cast<float>(fp.height);
-        const float s = u + nx / static_cast<float>(fp.width);
-        const float t = (1.0f - v) + ny / static_cast<float>(fp.height);
-
-        const float phi = 2.0f * kPi * ny;
-        const float cosPhi = wCos(phi), sinPhi = wSin(phi);
-        const float r = rf_sqrt(nx);
-        const float lensX = fp.camera.lensRadius * (r * cosPhi);
-        const float lensY = fp.camera.lensRadius * (r * sinPhi);
-        const Vec3  origin = fp.camera.origin + (lensX * fp.camera.right + lensY * fp.camera.up);
-        const Vec3  dir = normalize(fp.camera.lowerLeftCorner + s * fp.camera.horizontal + t * fp.camera.vertical - origin);
-
-        // throughput = 1 and radiance = 0 (wgsl:183-184) are not stored: bounce 1 knows them (kFlagFirstBounce, kSky's
-        // first-bounce flag), which saves 32 of the 80 bytes a path costs here and the reads back
-        store3(ps.rayO + pos[k], origin);
-        store3(ps.rayD + pos[k], dir);
-        store3(ps.noise + pos[k], vec3(nx, cosPhi, sinPhi));
-    }
-    // primary rays are counted on the host (samples x valid pixels of the shard): one atomic per wave on a single counter
-    // was what bound this kernel -- 261 k waves at ~90 same-address atomics/us = 2.9 of its 3.2 ms (MI355X_MICROARCH.md "dequeue")
-    (void)counters;
-}
-
-template<bool COUNT>
-__global__ __launch_bounds__(kBlock) void kTraceClosest(DeviceScene scene, PathStreams ps, const uint32_t* queue,
-                                                         const uint32_t* queueCount, DeviceCounters* counters)
-{
-    __shared__ uint32_t sStack[kLdsStack * kBlock];
-    const uint32_t      i = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t      count = *queueCount;
-    if (blockIdx.x * kBlock >= count) return;
-    TraversalCounters tc;
-    if (i < count)
-    {
-        const Vec3 o = load3(ps.rayO + i); // path state of the ray sits at its queue position
-        const Vec3 d = load3(ps.rayD + i);
-        ClosestHit h;
-        traverse<false, COUNT>(scene, o, d, kTMax, &sStack[threadIdx.x], h, tc);
-        if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-        ps.hit[i] = make_float4(__uint_as_float(h.triangle), h.u, h.v, 0.0f); // (kShade rebuilds the offset hit point from it)
-    }
-    if (COUNT)
-    {
-        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
-        const uint32_t           sh = waveMax(tc.stackHigh);
-        if (__lane_id() == 0)
-        {
-            atomicAdd(&counters->closestNodeVisits, nv);
-            atomicAdd(&counters->closestTriangleTests, tt);
-            atomicMax(&counters->stackHigh, sh);
-        }
-    }
-    if (i == 0) atomicAdd(&counters->closestRays, static_cast<unsigned long long>(count));
-}
-
-// p = p0 + u*e1 + v*e2 offset along normalize(e1 x e2) (wgsl:511-519,523-544)
-__device__ __forceinline__ Vec3 hitPoint(const DeviceScene& scene, uint32_t tri, float u, float v)
-{
-    const Vec3 p0 = load3(scene.triangles + kTriStride * tri), p1 = load3(scene.triangles + kTriStride * tri + 1),
-               p2 = load3(scene.triangles + kTriStride * tri + 2);
-    const Vec3   e1 = p1 - p0, e2 = p2 - p0;
-    const Vec3   p = p0 + u * e1 + v * e2;
-    return offsetRay(p, normalize(cross(e1, e2)));
-}
-
-// Sun direction sample for this path (wgsl:194,287-292,568-579): cone about sunDirection.
-// The orthonormal basis about the sun direction (wgsl:309-319 applied to sunDirection) is the same for
-// every sample of a frame: computed once on the host with the same f32 expressions and passed as kernel
-// arguments (SGPRs) instead of ~15 VALU instructions per sample.
-struct SunBasis
-{
-    Vec3 u, v;
-};
-
-__device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, const SunBasis& basis, float nx, float cosPhi, float sinPhi)
-{
-    const float cosThetaMax = __uint_as_float(kSolarCosThetaMaxBits);
-    const float cosTheta = 1.0f - nx * (1.0f - cosThetaMax);
-    const float sinTheta = rf_sqrt(1.0f - cosTheta * cosTheta);
-    const Vec3  local = vec3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
-    const Vec3  sun = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
-    return basisTimes(basis.u, basis.v, sun, local);
-}
-
-constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
-
-
-// SORTED (option shade_sort_from_bounce): a tile's surviving paths are appended to the next queue in the order of the triangles they hit
-// (counting sort over kSortBins ranges of triangle ids in LDS; triangles are in BVH leaf order, so that is an order by region of the
-// scene) instead of input order: the 64 rays a wave of the next launches picks up then start close to each other.  The tile still
-// occupies ONE contiguous run of the queue, so queue order stays slot order at the scale of 1024 entries (what is indexed by slot --
-// the blue-noise triple, the radiance sum -- is touched by the same workgroups as before).  `sortScale`: bin of triangle t =
-// (t * sortScale) >> 32.
-constexpr uint32_t kSortBins = 256;
-#if defined(RF_EXP_SHADE_WAVES)
-#define RF_SHADE_BOUNDS __launch_bounds__(kBlock, RF_EXP_SHADE_WAVES)
-#else
-#define RF_SHADE_BOUNDS __launch_bounds__(kBlock) // (SORTED: 137 registers, three waves per SIMD; forced into 128 for four it is 2.5 % slower)
-#endif
-template<bool SORTED>
-__global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
-                                                  const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
-                                                  uint32_t* missCount, uint32_t bounceFlags, uint32_t sortScale)
-{
-    static_assert(kSortBins == kBlock, "one bin per thread");
-    __shared__ uint32_t sScratch[8];
-    __shared__ uint32_t sHist[SORTED ? kSortBins : 1], sStart[SORTED ? kSortBins : 1], sPerm[SORTED ? kItems * kBlock : 1];
-    __shared__ float    sLut[256];
-    constexpr uint32_t  kTile = kItems * kBlock;
-    __shared__ float    sIn[SORTED ? 10 * kTile : 1]; // SORTED: throughput, blue-noise triple, {triangle, u, v} and slot of the tile's hits, [component][entry of the tile]
-    const uint32_t      count = *queueCount;
-    // grid-stride over tiles of kItems * kBlock queue entries: the grid is capped (kShadeMaxBlocks), so late bounces, whose
-    // queues hold a sixth of the paths, do not pay for hundreds of thousands of empty workgroups
-    const uint32_t tiles = (count + kItems * kBlock - 1) / (kItems * kBlock);
-    if (blockIdx.x >= tiles) return; // whole block out of range (uniform)
-    static_assert(kBlock == 256, "one table entry per thread");
-    sLut[threadIdx.x] = scene.albedoLut[threadIdx.x];
-    __syncthreads();
-    const bool isLastBounce = (bounceFlags & kShadeLastBounce) != 0u, isFirstBounce = (bounceFlags & kShadeFirstBounce) != 0u;
-  for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
-  {
-    // Pass 1: which entries hit, which left the scene -> both output queues are appended FIRST, so that every surviving path
-    // knows its position in the next queue before it is shaded: what only the next two launches read (the NEE term) is
-    // written there, densely, instead of at the path's slot (whose neighbours are mostly dead by bounce 3).
-    bool       isHit[kItems], isMiss[kItems];
-    uint32_t   slots[kItems], missEntries[kItems], outPos[kItems], hitTri[kItems];
-#pragma unroll
-    for (int k = 0; k < kItems; ++k)
-    {
-        const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
-        isHit[k] = isMiss[k] = false;
-        slots[k] = missEntries[k] = 0;
-        hitTri[k] = kMiss;
-        if (i >= count) continue;
-        slots[k] = queue[i];
-        missEntries[k] = i; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there
-        const Vec3     hitRec = SORTED ? load3(ps.hit + i) : vec3(ps.hit[i].x, 0.0f, 0.0f); // hit records sit at QUEUE positions (dense)
-        const uint32_t tri = __float_as_uint(hitRec.x);
-        hitTri[k] = tri;
-        isMiss[k] = tri == kMiss; // the path ends in the sky: evaluated densely by this bounce's kSky launch
-        isHit[k] = tri != kMiss;
-        if constexpr (SORTED)
-        {
-            if (isHit[k])
-            {
-                // what pass 2 needs of this entry, read here in INPUT order (coalesced) and handed over in LDS: pass 2 works in the
-                // tile's sorted order, where the 64 lanes of a wave would gather from ~57 different lines per stream
-                const uint32_t l = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
-                const Vec3     t = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3nt(ps.thr + i), z = load3nt(ps.noise + i);
-                sIn[l] = t.x, sIn[kTile + l] = t.y, sIn[2 * kTile + l] = t.z;
-                sIn[3 * kTile + l] = z.x, sIn[4 * kTile + l] = z.y, sIn[5 * kTile + l] = z.z;
-                sIn[6 * kTile + l] = hitRec.x, sIn[7 * kTile + l] = hitRec.y, sIn[8 * kTile + l] = hitRec.z;
-                sIn[9 * kTile + l] = __uint_as_float(slots[k]);
-            }
-        }
-    }
-    uint32_t sortedHits = 0, sortedBase = 0; // SORTED: hits of the tile, and where its run starts in the next queue
-    if constexpr (SORTED)
-    {
-        // counting sort of the tile's hits by triangle range: rank inside the bin from an LDS counter, bin starts from a block scan
-        uint32_t bin[kItems], rank[kItems];
-        sHist[threadIdx.x] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kItems; ++k)
-        {
-            bin[k] = rank[k] = 0u;
-            if (!isHit[k]) continue;
-            bin[k] = min(__umulhi(hitTri[k], sortScale), kSortBins - 1u);
-            rank[k] = atomicAdd(&sHist[bin[k]], 1u);
-        }
-        __syncthreads();
-        {
-            const uint32_t n = sHist[threadIdx.x], lane = __lane_id(), wave = threadIdx.x >> 6;
-            uint32_t       incl = n;
-            for (int off = 1; off < 64; off <<= 1)
-            {
-                const uint32_t up = __shfl_up(incl, off);
-                if (static_cast<int>(lane) >= off) incl += up;
-            }
-            if (lane == 63) sScratch[wave] = incl;
-            __syncthreads();
-            uint32_t before = 0;
-            for (uint32_t w = 0; w < wave; ++w) before += sScratch[w];
-            sStart[threadIdx.x] = before + incl - n;
-            if (threadIdx.x == 0)
-            {
-                const uint32_t total = sScratch[0] + sScratch[1] + sScratch[2] + sScratch[3];
-                sScratch[5] = total;
-                sScratch[4] = total ? atomicAdd(hitCount, total) : 0u; // the tile's run in the next queue
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kItems; ++k)
-            if (isHit[k]) sPerm[sStart[bin[k]] + rank[k]] = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
-        __syncthreads();
-        // the thread's work from here on: entries k * 256 + tid of the SORTED order
-        const uint32_t tileHits = sScratch[5], base = sScratch[4];
-        sortedHits = tileHits, sortedBase = base;
-#pragma unroll
-        for (int k = 0; k < kItems; ++k)
-        {
-            const uint32_t p = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
-            isHit[k] = p < tileHits;
-            outPos[k] = base + p;
-            if (!isHit[k]) continue;
-            const uint32_t local = sPerm[p];
-            hitTri[k] = local; // (reused: which entry of the tile)
-            slots[k] = __float_as_uint(sIn[9 * kTile + local]);
-            hitQueue[outPos[k]] = slots[k];
-        }
-        __syncthreads(); // LDS is reused by the miss append and the next tile
-    }
-    else
-        blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch, &outPos);
-    blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
-
-    // Pass 2: shade the hits.  An entry is a chain of dependent gathers -- hit record -> shading record -> texture descriptor -> texel --
-    // and four entries one after the other were four such chains end to end: the kernel waited.  Now the hit records of all
-    // four entries are requested up front, and the shading record of entry k + 1 while entry k is shaded (its texel fetch included).
-    // (SORTED only: bounce 1 -- coherent records, no sort -- streams at its memory rate as one entry at a time with fewer registers)
-    constexpr bool kPipelined = SORTED;
-    Vec3           hits[kPipelined ? kItems : 1]; // {triangle, u, v} of the hit records (t is not needed here)
-    const auto     entryIndex = [&](int k) -> uint32_t {
-        return SORTED ? (tile * kItems + hitTri[k] / kBlock) * kBlock + (hitTri[k] % kBlock) : (tile * kItems + static_cast<uint32_t>(k)) * kBlock + threadIdx.x;
-    };
-    if constexpr (kPipelined)
-    {
-#pragma unroll
-        for (int k = 0; k < kItems; ++k) hits[k] = isHit[k] ? vec3(sIn[6 * kTile + hitTri[k]], sIn[7 * kTile + hitTri[k]], sIn[8 * kTile + hitTri[k]]) : Vec3{};
-    }
-    // everything this stage needs of the triangle sits in ONE 128-byte record (positions + packed attributes): one L2 line
-    // per shaded hit instead of a triangle line and an attribute line (kShade 56.1 -> 53.0 ms per 128 spp)
-    struct ShadeRecord
-    {
-        Vec3   p0, p1, p2;
-        float4 a0, a1, a2, a3; // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
-    };
-    const auto fetchRecord = [&](uint32_t tri) {
-        ShadeRecord   r;
-        const float4* rec = scene.shadeRecords + 8 * static_cast<size_t>(tri);
-#if defined(RF_EXP_SHADE_ABLATE) && RF_EXP_SHADE_ABLATE >= 3
-        if constexpr (SORTED) rec = scene.shadeRecords + 8 * static_cast<size_t>(tri & 63u); // ablation (timing only): 64 records, all L1 hits
-#endif
-        r.p0 = load3(rec), r.p1 = load3(rec + 1), r.p2 = load3(rec + 2);
-        r.a0 = rec[3], r.a1 = rec[4], r.a2 = rec[5], r.a3 = rec[6];
-        return r;
-    };
-    const auto shade = [&](int k, float hu, float hv, const ShadeRecord& cur, uint32_t out) {
-        const uint32_t i = entryIndex(k);
-        (void)i;
-        {
-            // hit point pushed off the surface along the geometric normal (wgsl:511-519,523-544): origin of
-            // the shadow ray and of the next bounce; same arithmetic as the scalar traversal (rf_device.hpp)
-            const Vec3 p0 = cur.p0, p1 = cur.p1, p2 = cur.p2;
-            const Vec3 e1 = p1 - p0, e2 = p2 - p0;
-            const Vec3 hp = offsetRay(p0 + hu * e1 + hv * e2, normalize(cross(e1, e2)));
-            store3nt(ps.rayO + out, hp); // (this bounce's origins have been consumed by the closest-hit launch)
-        }
-        // SORTED: this thread's entry is the tile's `local`-th in input order; its throughput and blue-noise triple were read in input
-        // order (coalesced) by pass 1 and wait in LDS -- gathered from memory, the 64 lanes of a wave would touch ~57 different lines of
-        // the tile's 12 KB per stream
-        Vec3 throughput, nz;
-        if constexpr (SORTED)
-        {
-            const uint32_t local = hitTri[k];
-            throughput = vec3(sIn[local], sIn[kTile + local], sIn[2 * kTile + local]);
-            nz = vec3(sIn[3 * kTile + local], sIn[4 * kTile + local], sIn[5 * kTile + local]);
-        }
-        else
-        {
-            throughput = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3nt(ps.thr + i); // wgsl:184
-            nz = load3nt(ps.noise + i);
-        }
-        const float nx = nz.x, cosPhi = nz.y, sinPhi = nz.z;
-        store3nt(ps.noiseOut + out, nz); // travels with the path: dense for this bounce's shadow launch and for the next kShade
-        const float4  a0 = cur.a0, a1 = cur.a1, a2 = cur.a2, a3 = cur.a3;
-        const Vec3    n0 = vec3(a0.x, a0.y, a0.z), n1 = vec3(a0.w, a1.x, a1.y), n2 = vec3(a1.z, a1.w, a2.x);
-        const float   b0 = 1.0f - hu - hv, b1 = hu, b2 = hv; // wgsl:515
-        const Vec3    n = (b0 * n0 + b1 * n1) + b2 * n2;         // not normalised, wgsl:396
-        const float   uvx = (b0 * a2.y + b1 * a2.w) + b2 * a3.y;
-        const float   uvy = (b0 * a2.z + b1 * a3.x) + b2 * a3.z;
-#if defined(RF_EXP_SHADE_ABLATE) && (RF_EXP_SHADE_ABLATE == 1 || RF_EXP_SHADE_ABLATE == 4)
-        const Vec3    albedo = SORTED ? vec3(sLut[__float_as_uint(a3.w) & 255u], uvx - floorf(uvx), uvy - floorf(uvy)) : evalTexture(scene, sLut, __float_as_uint(a3.w), uvx, uvy); // ablation (timing only): no texel fetch
-#else
-        const Vec3    albedo = evalTexture(scene, sLut, __float_as_uint(a3.w), uvx, uvy);
-#endif
-
-        // next-event estimation towards the sun, wgsl:194-203 (cosine is not clamped)
-        const Vec3 lightDirection = sunSample(sky, sunBasis, nx, cosPhi, sinPhi);
-        const Vec3 lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
-        const Vec3 brdf = albedo * kFrac1Pi;
-        const Vec3 reflectance = brdf * dot(n, lightDirection);
-        const Vec3 pend = (throughput * lightIntensity) * reflectance;
-        store3nt(ps.pending + out, pend); // read by the shadow launch at the same queue position
-
-        if (!isLastBounce)
-        {
-            // cosine-weighted bounce about the interpolated normal, wgsl:209-211,294-301,582-592
-            const float sinTheta = rf_sqrt(1.0f - nx);
-            const Vec3  local = vec3(cosPhi * sinTheta, sinPhi * sinTheta, rf_sqrt(nx));
-            Vec3        bu, bv;
-            pixarOnb(n, bu, bv);
-            const Vec3 wi = basisTimes(bu, bv, n, local); // not renormalised
-            const Vec3 t2 = throughput * albedo;
-            store3nt(ps.rayDOut + out, wi);
-            store3nt(ps.thrOut + out, t2);
-        }
-    };
-    if constexpr (kPipelined)
-    {
-        const uint32_t tileHits = sortedHits, base = sortedBase;
-        ShadeRecord    cur{};
-        if (threadIdx.x < tileHits) cur = fetchRecord(__float_as_uint(hits[0].x));
-#pragma unroll
-        for (int k = 0; k < kItems; ++k)
-        {
-            const uint32_t p = static_cast<uint32_t>(k) * kBlock + threadIdx.x, pNext = p + kBlock; // positions in the tile's sorted order
-            ShadeRecord    next{};
-            if (k + 1 < kItems && pNext < tileHits) next = fetchRecord(__float_as_uint(hits[k + 1 < kItems ? k + 1 : k].x));
-            if (p < tileHits) shade(k, hits[k].y, hits[k].z, cur, base + p);
-            cur = next;
-        }
-    }
-    else
-    {
-#pragma unroll 1
-        for (int k = 0; k < kItems; ++k)
-        {
-            if (!isHit[k]) continue;
-            const Vec3 h = load3(ps.hit + entryIndex(k));
-            shade(k, h.y, h.z, fetchRecord(__float_as_uint(h.x)), outPos[k]);
-        }
-    }
-    if constexpr (SORTED) __syncthreads(); // (a block that takes another tile refills sIn)
-  }
-}
-
-// Paths that left the scene at this bounce: radiance += throughput * sky (wgsl:212-228,247-275).  One dense launch per
-// bounce over that bounce's miss list (queue positions) instead of a divergent f64 branch inside kShade; it runs right
-// after kShade, while the bounce's direction / throughput arrays and its queue are still intact.  All NEE terms of the path
-// have been added by then (the shadow launch of the previous bounce is complete).  Grid-stride: the list length is only
-// known on the device, and a worst-case grid of empty workgroups per bounce would cost more than the work.
-__global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, const uint32_t* queue, const uint32_t* missQueue, const uint32_t* missCount,
-                                                uint32_t firstBounce)
-{
-    const uint32_t n = *missCount;
-    const bool     first = firstBounce != 0u; // left the scene at bounce 1: throughput 1, radiance 0, neither in memory
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-    {
-        const uint32_t q = missQueue[i];
-        const uint32_t slot = queue[q];
-        const Vec3     v = load3(ps.rayD + q);
-        const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + q);
-        const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot);
-        const Vec3     s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
-        const float    theta = wAcos(v.y);
-        const float    gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
-        // cos(gamma) and |cos(theta)| do not depend on the channel: evaluated once instead of three times (same values)
-        const float cosGamma = wCos(gamma), cosTheta = fabsf(wCos(theta));
-        const Vec3  dome = vec3(skyRadiance(sky, cosTheta, gamma, cosGamma, 0), skyRadiance(sky, cosTheta, gamma, cosGamma, 1), skyRadiance(sky, cosTheta, gamma, cosGamma, 2));
-        const Vec3  radiance = rad + thr * dome;
-        ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-    }
-}
-
-template<bool COUNT>
-__global__ __launch_bounds__(kBlock) void kTraceShadow(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
-                                                        const uint32_t* queueCount, DeviceCounters* counters, uint32_t firstBounce)
-{
-    __shared__ uint32_t sStack[kLdsStack * kBlock];
-    const uint32_t      i = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t      count = *queueCount;
-    if (blockIdx.x * kBlock >= count) return;
-    TraversalCounters tc;
-    if (i < count)
-    {
-        const uint32_t slot = queue[i];
-        const Vec3     o = load3(ps.rayO + i);
-        const Vec3     nz = load3(ps.noiseOut + i);
-        const Vec3     l = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
-        ClosestHit     h;
-        const bool     occluded = traverse<true, COUNT>(scene, o, l, kTMax, &sStack[threadIdx.x], h, tc);
-        if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-        const float    visibility = occluded ? 0.0f : 1.0f;
-        const Vec3     pend = load3(ps.pending + i); // by queue position (written there by kShade)
-        const Vec3     rad0 = firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot); // bounce 1: radiance is still 0 (wgsl:183)
-        // wgsl:203  radiance += ((throughput*L)*reflectance) * visibility * SOLAR_INV_PDF
-        const Vec3 add = (pend * visibility) * __uint_as_float(kSolarInvPdfBits);
-        const Vec3 radiance = rad0 + add;
-        ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-    }
-    if (COUNT)
-    {
-        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
-        if (__lane_id() == 0)
-        {
-            atomicAdd(&counters->shadowNodeVisits, nv);
-            atomicAdd(&counters->shadowTriangleTests, tt);
-        }
-    }
-    if (i == 0) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
-}
-
-// ------------------------------------------------------------------------------------------------
-// Scheduling constants of the persistent traversal kernel (tuned on the atrium, tools/gpu_ab.py).
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t kChunk = 128;   // queue entries claimed per atomic (small enough that the tail stays balanced)
-constexpr uint32_t kShards = 16;   // work cursors per launch, one 64-byte line each: a single cursor
-                                   // saturates near 90 claims/us (8 M rays / 64 per 1.2 ms = 100/us)
-constexpr uint32_t kLineWords = 16;
-constexpr uint32_t kRefillMin = 40; // refill once this many lanes are idle (r02 sweep: 32 -> 40 = +1 %)
-constexpr uint32_t kLeafVote = 20; // leave the descent loop when fewer lanes than this are descending (16..24 measure the same)
-
-// record layouts (kTraceWide's COMPACT parameter) + the two paths outside kTraceWide
-constexpr int kLayoutBinary = 0, kLayoutCompact = 1, kLayoutHot = 2, kLayoutQuad = 3, kLayoutQuadHalf = 4, kLayoutQuadLocal = 5, kLayoutOct = 6, kLayoutScalar = 7, kLayoutPacket = 8;
-constexpr uint32_t kFlagShadowDirFromStream = 1u; // any-hit: direction from ps.rayD instead of the sun sample
-constexpr uint32_t kFlagUniformTri = 8u;          // the same for the triangles of a leaf phase
-constexpr uint32_t kFlagUniformFetch = 4u;        // try the scalar-cache path for records that every descending lane shares
-constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is 0 and not in memory yet (kRaygen does not store it)
-constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaves that stopped the last rays from its cell of the scene (see kTraceWide)
-constexpr uint32_t kFlagOccluderNoTry = 32u;      // ... the launch runs behind kShadowFirstLook: its rays have had their first look, it only records what stopped them
-constexpr uint32_t kFlagNoRayCount = 64u;
-constexpr uint32_t kFlagDenseLeafShift = 8u;       // bits 11..8: leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (0: never; see kTraceWide)         // the launch's rays are counted elsewhere (kShadowFirstLook counted the whole queue)
-#if defined(RF_EXP_OCC_SLOTS)
-constexpr int kOccSlots = RF_EXP_OCC_SLOTS;
-#else
-constexpr int kOccSlots = 4; // entries per cell of the occluder grid (1, 2 or 4: shadow launches of the atrium -19 / -29 / -34 %, profiles/r04_occluder)
-#endif
-static_assert(kOccSlots == 1 || kOccSlots == 2 || kOccSlots == 4, "one aligned load per cell");
-// cell of a point -> table index.  (Blocks of 4 x 4 x 4 neighbouring cells sharing 1 KB of the table -- the block hashed, the cell's place inside it from its low
-// coordinate bits, so that a wave's rays read neighbouring lines -- measured -0.7 %: profiles/r04_occluder/occ_blocks.log.)
-__device__ __forceinline__ uint32_t occluderCellIndex(const WideScene& wide, float ox, float oy, float oz)
-{
-    const uint32_t cx = static_cast<uint32_t>(__float2int_rd((ox - wide.rootLo.x) * wide.occScale)), cy = static_cast<uint32_t>(__float2int_rd((oy - wide.rootLo.y) * wide.occScale)),
-                   cz = static_cast<uint32_t>(__float2int_rd((oz - wide.rootLo.z) * wide.occScale));
-    return ((cx * 73856093u) ^ (cy * 19349663u) ^ (cz * 83492791u)) & wide.occMask;
-}
-__device__ __forceinline__ void loadOccluderCell(const uint32_t* cell, uint32_t (&e)[kOccSlots])
-{
-    if constexpr (kOccSlots == 1) e[0] = *cell;
-    else if constexpr (kOccSlots == 2)
-    {
-        const uint2 v = *reinterpret_cast<const uint2*>(cell);
-        e[0] = v.x, e[1] = v.y;
-    }
-    else
-    {
-        const uint4 v = *reinterpret_cast<const uint4*>(cell);
-        e[0] = v.x, e[1] = v.y, e[kOccSlots > 2 ? 2 : 0] = v.z, e[kOccSlots > 3 ? 3 : 0] = v.w;
-    }
-}
-__device__ __forceinline__ void storeOccluderCell(uint32_t* cell, const uint32_t (&e)[kOccSlots])
-{
-    if constexpr (kOccSlots == 1) *cell = e[0];
-    else if constexpr (kOccSlots == 2) *reinterpret_cast<uint2*>(cell) = make_uint2(e[0], e[1]);
-    else *reinterpret_cast<uint4*>(cell) = make_uint4(e[0], e[1], e[kOccSlots > 2 ? 2 : 0], e[kOccSlots > 3 ? 3 : 0]);
-}
-
-// Lane state of kTraceWide lives in ONE register, the next thing to visit: a child word of
-// rf_wide.hpp (bit 31 clear: interior record index; set: leaf descriptor) or one of two sentinels
-// (no leaf word reaches them: that would take count field 7 with big-leaf index 0x0FFFFFFE).
-constexpr uint32_t kNodeIdle = 0xFFFFFFFFu; // no ray
-constexpr uint32_t kNodeDone = 0xFFFFFFFEu; // ray finished, result not yet written
-
-// ------------------------------------------------------------------------------------------------
-// kTraceWide: persistent traversal over the 64-byte children-in-parent layout (rf_wide.hpp).
-// Scheduling: a wave is 64 independent rays whose trip counts differ by an order of magnitude, and
-// most visits are interior nodes.  Waves are persistent (grid = resident blocks), claim `chunk`
-// queue entries per atomic, refill lanes whose ray has finished, and park lanes that reach a leaf
-// until fewer than `leafVote` lanes are still descending, so that the Moller-Trumbore code runs for
-// many lanes at once.  None of this changes any ray's own visit order.
-//
-// One step = one record = both children of an accepted interior node.  With hit(c) = P(c) &&
-// tmin(c) < rayTMax (rf_wide.hpp), near/far in the reference's order (dirNeg[splitAxis]):
-//     near hit, far hit : go to near, push (far, tmin(far))     reference: push far, visit near
-//     near hit only     : go to near                             far would be popped and rejected later:
-//                                                                rayTMax only ever shrinks
-//     far hit only      : go to far, no stack traffic            reference: near rejected, far popped at once
-//                                                                and tested against the same rayTMax
-//     none              : pop until an entry passes tmin < rayTMax (the reference's test at pop time)
-// The stack holds (child word, tmin) pairs, kWideLdsStack per lane in LDS ([depth][lane], ds_*_b64).
-// A ray that would need more, and any ray that is not "regular" (axis-parallel / denormal / NaN,
-// rf_wide.hpp), is redone whole by the reference-ordered scalar traversal over the 32-byte nodes
-// (rf_device.hpp) -- same result by construction, and rare enough not to matter.
-// ------------------------------------------------------------------------------------------------
-// NEAREST_FIRST (any-hit only): visit the child with the smaller slab tmin first instead of the
-// reference's split-axis order.  A shadow ray's answer is "does ANY triangle of any reachable leaf
-// intersect", and with the fixed rayTMax of shadowRay (wgsl:323-368) the set of reachable leaves
-// does not depend on the visit order, so the visibility bit is identical while occluded rays
-// terminate after fewer fetches.  (Closest-hit keeps the reference order: ties in t are resolved
-// by visit order.)
-//
-// COUNT && !NEAREST_FIRST is the reference-bookkeeping build: every far child is pushed (tmin = +inf
-// when its box is missed) and counted when popped, so nodesVisited and the stack high-water mark
-// equal the reference's exactly; it trades occupancy for a deeper LDS stack.
-template<bool COUNT, bool NEAREST_FIRST>
-constexpr int wideStackDepth()
-{
-    return (COUNT && !NEAREST_FIRST) ? 28 : kWideLdsStack;
-}
-
-template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, int COMPACT = 0, bool DENSE_LEAVES = false>
-__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
-                                                                                        const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
-                                                                                        DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
-                                                                                        uint32_t chunkMax, float tMax, uint32_t flags)
-{
-    constexpr int  kDepth = wideStackDepth<COUNT, NEAREST_FIRST>();
-    constexpr bool kRefCount = COUNT && !NEAREST_FIRST;
-    static_assert(!(COMPACT != 0 && COUNT), "the compact-record and quad-record variants have no counting build");
-    static_assert(COMPACT >= 0 && COMPACT <= 6, "0: 64-byte records, 1: compact-capable, 2: 32-byte, 3: quad, 4: half-precision quad, 5: local-grid quad, 6: local-grid oct (closest-hit)");
-    static_assert(!(COMPACT == 6 && ANY_HIT), "the oct records serve the closest-hit launches (the any-hit launches start at occluder-cache entries that name quad records)");
-#if !defined(RF_EXP_LEGACY_LAYOUTS)
-    static_assert(COMPACT != 1 && COMPACT != 2, "the compact-capable and the 32-byte records are experiment-build layouts (make EXP=RF_EXP_LEGACY_LAYOUTS)");
-#endif
-    constexpr bool kConservative = COMPACT == 4 || COMPACT == 5 || COMPACT == 6; // interior tests accept a superset; every leaf's EXACT box is applied at the leaf
-    __shared__ uint2 sStack[kDepth * kBlock];
-    const uint32_t   count = *queueCount;
-    const uint32_t   lane = __lane_id();
-    const bool       shadowDirFromStream = flags & kFlagShadowDirFromStream;
-    const bool       firstBounce = flags & kFlagFirstBounce;
-    const bool       uniformFetch = flags & kFlagUniformFetch, uniformTri = flags & kFlagUniformTri;
-    // Occluder cache (any-hit launches on the conservative records).  A shadow ray is answered as soon as ONE triangle stops it, and the rays that leave the
-    // same few centimetres of the scene towards the 0.27-degree sun disc are stopped by the same few triangles.  The launch therefore keeps a hash grid over
-    // cells of the scene's space (WideScene::occGrid; kOccSlots leaf words per cell, most recent first): a finished ray records the leaf in which it found its
-    // occluder, and a NEW ray visits the leaves of its origin's cell FIRST, with the root waiting below them on its stack -- if one of them stops it, it is done
-    // after a leaf visit or two instead of a walk from the root (atrium: 11.2 -> 0.8 interior steps per shadow ray).  A ray that tried its cell's leaves and reached the sun
-    // drops the cell's first entry, so lit regions stop paying for stale entries.
-    // The visibility bit is the reference's by the argument that lets an any-hit ray choose its visit order (NEAREST_FIRST above): a leaf visit here applies the
-    // leaf's EXACT box with the reference's formula before any triangle is tested (the COMPACT 4 / 5 leaf phase below); a leaf whose own box passes is reached by
-    // the reference too, because its ancestors' boxes contain it and the slab arithmetic is monotone in the planes (rf_wide.hpp) -- so the reference either tests
-    // the same triangle or has found another one before: occluded either way; and a leaf visited a second time in the regular walk answers as it did the first
-    // time.  Entries are hints only: any leaf word of this scene is a valid first visit, so racing writers, hash collisions and entries left from another sun
-    // position cost time, never the result (tests: test_occluder_cache_is_invisible).
-    constexpr bool kOccluderCache = ANY_HIT && !COUNT && (COMPACT == 3 || COMPACT == 4 || COMPACT == 5);
-    // (the exact quad records test a leaf's box at its parent's step, not at the leaf: a launch of theirs that uses the cache applies the box at the leaf too, as
-    // the conservative layouts always do -- a second, identical test for the leaves reached by the walk, THE test for the ones visited first)
-    const bool     leafBoxAtLeaf = kConservative || (COMPACT == 3 && kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr);
-    const bool     occluderCache = kOccluderCache && (flags & kFlagOccluderCache) != 0u && wide.occGrid != nullptr;
-    const auto occluderCell = [&](float ox, float oy, float oz) -> uint32_t { return occluderCellIndex(wide, ox, oy, oz); };
-    constexpr uint32_t kNegTriedHint = 16u; // negMask: the ray started at a hint
-
-    // The queue is cut into kShards contiguous ranges with one cursor each; a wave starts on the
-    // shard of its block and moves on round-robin when a shard is dry.
-    // entries per cursor claim: `chunkMax`, halved until every wave gets at least 8 claims (a short queue -- a small frame, a deep
-    // bounce of one rank's shard -- ends in a tail of half-empty waves otherwise), but not below 64: a claim is a wave-wide stall
-    // of a few microseconds, so fewer, larger claims win as long as the tail stays balanced
-    uint32_t chunk = chunkMax;
-    while (chunk > 64u && static_cast<unsigned long long>(chunk) * 8ull * gridDim.x * (kBlock / 64) > count) chunk >>= 1;
-    const uint32_t shardLen = ((count + kShards - 1) / kShards + chunk - 1) / chunk * chunk;
-    uint32_t       shard = blockIdx.x % kShards, shardsTried = 0;
-    uint32_t       chunkPos = 0, chunkEnd = 0;
-    bool           exhausted = count == 0;
-
-    uint32_t  node = kNodeIdle;
-    uint32_t  slot = 0;
-    uint32_t  resultIndex = 0; // queue position of the lane's ray
-    Vec3      pendingTerm{};   // ANY_HIT: the ray's NEE term (pending[resultIndex])
-    // COMPACT: t-values of the x planes of the node the lane is about to visit, in hand when it enters the node straight from its
-    // parent's step (rf_wide.hpp, compact-capable records); a lane that arrives from the stack or starts at the root reads them
-    float tOuterLo = 0.0f, tOuterHi = 0.0f;
-    bool  haveOuter = false;
-    // COMPACT == 2 (32-byte records): the t-values of all six planes of that node's box
-    BoxT  own{};
-    // COMPACT == 4 (half-precision quad records): b = -(o / d) per axis, the addend of t' = fma(plane', 1/d, b)
-    float hbx = 0.0f, hby = 0.0f, hbz = 0.0f;
-    uint32_t lselX = 0u, lselY = 0u, lselZ = 0u; // COMPACT == 5 (local-grid quad records): per-axis v_perm_b32 selectors (see localEntryBounds)
-    uint32_t octKey = 0u; // COMPACT == 6 (oct records): bits 5..0 = 16 x the field of the record's order table this ray reads, bits 8.. = 0x7777 when its positions are flipped (WideBuild::oct)
-    uint32_t hrot = 0u; // ... and (1/d.x < 0) << 4 | (1/d.y < 0) << 12 | (1/d.z < 0) << 20: rotate amounts that bring a plane word's NEAR plane into its low half
-    PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
-    Vec3      rayDir{};    // for the triangle tests
-    uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
-    float     rayTMax = tMax;
-    // Closest-hit launches keep the stack top as a BYTE offset into sStack (lane * 8 + depth * kBlock * 8): a push is one ds_write + one add, no
-    // shift-or for the address, and -- in the quad steps -- one bound check per step instead of one per push: closest-hit launches -1.5 % (round 4,
-    // gpurun_out A/B in profiles/r04_lanes).  The any-hit launches measured +2.5 % with it and keep the plain depth, as do the counting builds
-    // (they report it).
-    constexpr bool kPtrStack = !COUNT && !ANY_HIT;
-    const int     spBase = kPtrStack ? static_cast<int>(threadIdx.x * sizeof(uint2)) : 0;
-    constexpr int kSpStep = kPtrStack ? static_cast<int>(kBlock * sizeof(uint2)) : 1;
-    constexpr int kSpLimit = kPtrStack ? kDepth * static_cast<int>(kBlock * sizeof(uint2)) : kDepth; // (depth == kDepth <=> offset >= this: lane * 8 < kBlock * 8)
-    int       stackSize = spBase;
-    const auto stackAt = [&](int s) -> uint2& {
-        if constexpr (kPtrStack) return *reinterpret_cast<uint2*>(reinterpret_cast<char*>(sStack) + s);
-        else return sStack[s * kBlock + threadIdx.x];
-    };
-    bool      needScalar = false; // irregular ray or stack overflow: redo with the scalar traversal
-    // An any-hit ray's rayTMax never changes, so an entry that passed `tmin < rayTMax` when it was pushed passes it when it is popped: such a
-    // kernel keeps only the words on its stack (no tmin to select, store and compare) -- except the reference-bookkeeping build, which
-    // pushes missed children with tmin = +inf to count them.
-    constexpr bool kStackWordsOnly = ANY_HIT && !kRefCount;
-    // ---- Rays that need more than the LDS stack holds.  Until round 4 such a ray was redone whole by the scalar traversal (one lane, the
-    // reference-ordered kernel over the 32-byte nodes): fine at 0.01 % of the rays (the plain atrium), a cliff at 2.6 % (the atrium with clutter, whose
-    // long diagonal boxes keep many candidates alive: closest-hit launches 3.2 x longer than with the binary records, which push at most one entry per
-    // step).  Now a full LDS stack EVICTS its kEvict oldest entries -- the ones needed last -- to a per-lane scratch array and moves the rest down; when the
-    // LDS stack runs empty the youngest evicted block comes back.  Same entries, same order, nothing recomputed; only a ray that would need more than
-    // kDepth + kEvict * kSpillBlocks pending entries still takes the scalar traversal.  The number of evicted entries rides in bits 8.. of negMask.
-    constexpr bool kSpill = !kRefCount;
-    constexpr int  kEvict = kDepth >= 9 ? 6 : (kDepth > 4 ? kDepth - 3 : 1), kSpillBlocks = 36 / kEvict; // (6 x 6 by default; the stress build with a 6-entry LDS stack -- make EXP=RF_EXP_STACK=6 -- evicts 3 at a time, all the time)
-    static_assert(kEvict >= 3 && kEvict <= kDepth - 2, "a quad step checks the bound once (depth < kDepth - 2) and then pushes up to three entries: an eviction must make room for all three");
-    using SpillEntry = std::conditional_t<kStackWordsOnly, uint32_t, uint2>;
-    SpillEntry spillBuf[kSpill ? kEvict * kSpillBlocks : 1];
-    const auto slotS = [&](int i) -> int { return kPtrStack ? spBase + i * kSpStep : i; };
-    const auto evict = [&]() -> bool {
-        if constexpr (!kSpill) return false;
-        const uint32_t spilled = negMask >> 8;
-        if (spilled + kEvict > static_cast<uint32_t>(kEvict * kSpillBlocks)) return false;
-        for (int i = 0; i < kEvict; ++i)
-        {
-            if constexpr (kStackWordsOnly) spillBuf[spilled + i] = stackAt(slotS(i)).x;
-            else spillBuf[spilled + i] = stackAt(slotS(i));
-        }
-        const int depth = kPtrStack ? (stackSize - spBase) / kSpStep : stackSize;
-        for (int i = kEvict; i < depth; ++i)
-        {
-            if constexpr (kStackWordsOnly) stackAt(slotS(i - kEvict)).x = stackAt(slotS(i)).x;
-            else stackAt(slotS(i - kEvict)) = stackAt(slotS(i));
-        }
-        stackSize -= kEvict * kSpStep;
-        negMask += static_cast<uint32_t>(kEvict) << 8;
-        return true;
-    };
-    // (the LDS stack is empty and entries are waiting in scratch: the youngest block comes back.  popNext() does not look at the scratch area -- it is the
-    // hot path -- so a lane whose LDS stack ran dry reports "done"; the write-back block below, which every finished lane passes once, sends a lane with
-    // evicted entries back to work instead)
-    const auto unspill = [&]() {
-        negMask -= static_cast<uint32_t>(kEvict) << 8;
-        const uint32_t spilled = negMask >> 8;
-        for (int i = 0; i < kEvict; ++i)
-        {
-            if constexpr (kStackWordsOnly) stackAt(slotS(i)).x = spillBuf[spilled + i];
-            else stackAt(slotS(i)) = spillBuf[spilled + i];
-        }
-        stackSize = slotS(kEvict);
-    };
-    auto      push = [&](uint32_t word, float tmin) -> bool {
-        if (stackSize >= kSpLimit && !evict()) return false;
-        if constexpr (kStackWordsOnly) stackAt(stackSize).x = word;
-        else stackAt(stackSize) = make_uint2(word, __float_as_uint(tmin));
-        stackSize += kSpStep;
-        return true;
-    };
-    auto      pushUnchecked = [&](uint32_t word, float tmin) {
-        if constexpr (kStackWordsOnly) stackAt(stackSize).x = word;
-        else stackAt(stackSize) = make_uint2(word, __float_as_uint(tmin));
-        stackSize += kSpStep;
-    };
-    ClosestHit        best{};
-    bool              occluded = false;
-    TraversalCounters tc;                                           // COUNT: totals of this lane's finished rays
-    uint32_t          rayNodes = 0, rayTris = 0, rayStackHigh = 0;  // COUNT: the ray in flight
-    uint32_t          recordFetches = 0;
-    uint32_t          wDescend = 0, wLeaf = 0, wLeafPhase = 0, wRefill = 0, wPop = 0, wOuter = 0; // COUNT: loop trips
-#if defined(RF_EXP_PHASE)
-    constexpr bool kPhase = true; // experiment build: the wave-trip / lane-trip counters of the COUNT build in EVERY kTraceWide (RF_DEBUG_COUNTERS prints them)
-    uint32_t       phaseTris = 0, phaseLeafWave = 0, phaseOccTried = 0, phaseOccHit = 0, phaseOccluded = 0;
-    bool           phaseFromCache = false;
-#else
-    constexpr bool kPhase = COUNT;
-#endif
-
-    // Pop entries until one passes `tmin < rayTMax` (the reference's box test at pop time).
-    auto popNext = [&]() {
-        if (COMPACT != 0) haveOuter = false;
-        node = kNodeDone;
-        if constexpr (kStackWordsOnly)
-        {
-            if (stackSize > spBase)
-            {
-                stackSize -= kSpStep;
-                node = stackAt(stackSize).x;
-                if (COUNT) ++wPop;
-            }
-            return;
-        }
-        while (stackSize > spBase)
-        {
-            stackSize -= kSpStep;
-            uint2 e = stackAt(stackSize);
-            asm volatile("" : "+v"(e.x), "+v"(e.y)); // one ds_read_b64 (not tmin first, word after the loop)
-            if (COUNT) ++wPop;
-            if (kRefCount) ++rayNodes;
-            if (__uint_as_float(e.y) < rayTMax)
-            {
-                node = e.x;
-                break;
-            }
-        }
-    };
-
-    for (;;)
-    {
-        if (kPhase) ++wOuter;
-        // ---- refill idle lanes from the wave's chunk
-        const unsigned long long idleMask = __ballot(node == kNodeIdle);
-        const uint32_t           idleCount = __popcll(idleMask);
-        if (!exhausted && idleCount >= refillMin)
-        {
-            if (kPhase) ++wRefill;
-            // queue positions for the idle lanes, in lane order; a refill that reaches the end of the wave's chunk goes on in the
-            // next one (it used to stop there and leave the remaining lanes idle until the next refill: one refill in three)
-            const uint32_t rankInIdle = __popcll(idleMask & ((1ull << lane) - 1ull));
-            uint32_t       assigned = 0, myPos = 0xFFFFFFFFu;
-            while (assigned < idleCount)
-            {
-                while (chunkPos == chunkEnd && !exhausted)
-                {
-                    const uint32_t shardBegin = shard * shardLen, shardEnd = min(shardBegin + shardLen, count);
-                    uint32_t       base = 0;
-                    if (lane == 0) base = shardBegin < count ? atomicAdd(cursor + shard * kLineWords, chunk) : shardLen;
-                    base = shardBegin + __shfl(base, 0);
-                    if (base >= shardEnd)
-                    {
-                        shard = (shard + 1) % kShards;
-                        if (++shardsTried == kShards) exhausted = true;
-                    }
-                    else
-                    {
-                        chunkPos = base;
-                        chunkEnd = min(base + chunk, shardEnd);
-                    }
-                }
-                if (chunkPos == chunkEnd) break; // the queue is dry
-                const uint32_t take = min(idleCount - assigned, chunkEnd - chunkPos);
-                if (rankInIdle - assigned < take) myPos = chunkPos + (rankInIdle - assigned); // (unsigned: false for ranks below `assigned`)
-                chunkPos += take;
-                assigned += take;
-            }
-            if (node == kNodeIdle && myPos != 0xFFFFFFFFu)
-            {
-                // the ray's state sits at its QUEUE position: the lanes of a refill read consecutive elements (coalesced), and
-                // the closest-hit launch does not read the queue itself at all
-                resultIndex = myPos;
-                bool triedCell = false;
-                if constexpr (kOccluderCache)
-                {
-                    if (wide.rayList != nullptr)
-                    {
-                        const uint32_t e = wide.rayList[myPos]; // behind kShadowFirstLook: the rays it could not answer, by queue position
-                        resultIndex = e & 0x7FFFFFFFu;
-                        triedCell = (e >> 31) != 0u;
-                    }
-                }
-                if (ANY_HIT) slot = loadQ(queue + resultIndex); // the radiance sum and the blue-noise pair are the path's: by slot
-                // the NEE term this ray decides about: read with the rest of the ray (consecutive queue positions: coalesced) instead of
-                // at write-back, where every finishing lane gathered its own 12 bytes and the wave waited for them
-                if (ANY_HIT) pendingTerm = load3s(ps.pending + resultIndex);
-                const Vec3 o = load3s(ps.rayO + resultIndex);
-                Vec3       dir;
-                if (ANY_HIT && !shadowDirFromStream)
-                {
-                    const Vec3 nz = load3s(ps.noiseOut + resultIndex);
-                    dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
-                }
-                else dir = load3s(ps.rayD + resultIndex);
-                const RayPrep ray = prepareRay(o, dir);
-                pr = packRay(ray);
-                rayDir = dir;
-                const uint32_t rayClass = classifyRay(ray);
-                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u) | (triedCell ? 16u : 0u);
-                rayTMax = tMax;
-                stackSize = spBase;
-#if defined(RF_EXP_PHASE)
-                phaseFromCache = false;
-#endif
-                best.triangle = kMiss;
-                occluded = false;
-                if (COMPACT == 1) haveOuter = false;
-                if (COMPACT == 2)
-                {
-                    // the root's own box is a kernel argument: no fetch for it
-                    own = boxPlaneT(pr, make_float4(wide.rootLo.x, wide.rootLo.y, wide.rootHi.x, wide.rootHi.y), wide.rootLo.z, wide.rootHi.z);
-                    haveOuter = true;
-                }
-                rayNodes = 1; // the root visit (wgsl:379-382)
-                rayTris = 0;
-                rayStackHigh = 0;
-                needScalar = rayClass == kRayIrregular;
-                if constexpr (kConservative)
-                {
-                    // the margin of the half-precision / local-grid planes covers origins within wide.originBound and 1/direction components of
-                    // ordinary magnitude (or +-inf: those axes drop out as NaNs): anything else takes the scalar traversal
-                    const auto ordinary = [](float inv) { const float a = fabsf(inv); return (a >= 1e-18f && a <= 1e18f) || a == __uint_as_float(0x7F800000u); };
-                    const bool inside = fabsf(o.x) <= wide.originBound && fabsf(o.y) <= wide.originBound && fabsf(o.z) <= wide.originBound;
-                    if (!(inside && ordinary(ray.invDir.x) && ordinary(ray.invDir.y) && ordinary(ray.invDir.z))) needScalar = true;
-                    // An infinite 1/d (axis-parallel ray, class B) is replaced by +-1e30 IN THE CONSERVATIVE TESTS: the margin argument
-                    // does not depend on the size of 1/d, so the ray is still accepted wherever the reference accepts it (strictly inside
-                    // the slab: [-huge, +huge]; within the margin of a plane: accepted as well) and rejected when it is outside the
-                    // conservative slab by more than rounding -- instead of being left unconstrained on that axis, which sent such rays
-                    // through whole slices of the scene (and over the 12-entry stack: 150 x the scalar redos).  The leaf phase puts the
-                    // infinity back for its exact test (a genuine |1/d| of 1e30 never gets here: see `ordinary`).
-                    const float inf = __uint_as_float(0x7F800000u);
-                    if (fabsf(pr.iXY.x) == inf) pr.iXY.x = __builtin_copysignf(1e30f, pr.iXY.x);
-                    if (fabsf(pr.iXY.y) == inf) pr.iXY.y = __builtin_copysignf(1e30f, pr.iXY.y);
-                    if (fabsf(pr.iZ) == inf) pr.iZ = __builtin_copysignf(1e30f, pr.iZ);
-                    hbx = -(o.x * pr.iXY.x);
-                    hby = -(o.y * pr.iXY.y);
-                    hbz = -(o.z * pr.iZ);
-                    hrot = (ray.negX << 4) | (ray.negY << 12) | (ray.negZ << 20);
-                    lselX = ray.negX ? 0x00040005u : 0x00050004u, lselY = ray.negY ? 0x00040005u : 0x00050004u, lselZ = ray.negZ ? 0x00040005u : 0x00050004u;
-                    const uint32_t signXY = ray.negX | (ray.negY << 1);
-                    octKey = ray.negZ ? ((16u * (3u - signXY)) | (0x7777u << 8)) : 16u * signXY;
-                }
-                float      rootTMin;
-                const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
-                node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
-                if constexpr (kOccluderCache)
-                {
-                    uint32_t hint = 0u;
-                    uint32_t later[kOccSlots > 1 ? kOccSlots - 1 : 1] = {};
-                    if (occluderCache && (flags & kFlagOccluderNoTry) == 0u)
-                    {
-                        uint32_t e[kOccSlots];
-                        loadOccluderCell(wide.occGrid + kOccSlots * static_cast<size_t>(occluderCell(o.x, o.y, o.z)), e);
-                        if (e[0] != 0u)
-                        {
-                            hint = e[0];
-#pragma unroll
-                            for (int k = 1; k < kOccSlots; ++k) later[k - 1] = e[k];
-                        }
-                    }
-                    if (occluderCache && hint != 0u && node == 0u)
-                    {
-                        push(0u, 0.0f); // the root waits (an empty stack: always room for it and the cell's entries)
-#pragma unroll
-                        for (int k = kOccSlots - 1; k >= 1; --k)
-                            if (later[k - 1] != 0u) push(later[k - 1], 0.0f);
-                        node = hint;
-                        negMask |= kNegTriedHint;
-#if defined(RF_EXP_PHASE)
-                        ++phaseOccTried, phaseFromCache = true;
-#endif
-                    }
-                }
-            }
-        }
-        if (__ballot(node != kNodeIdle) == 0ull)
-        {
-            if (exhausted) break;
-            continue;
-        }
-
-        // ---- descend: one 64-byte record = both children of an accepted interior node
-        do
-        {
-            if (kPhase) ++wDescend;
-            if (static_cast<int32_t>(node) >= 0)
-            {
-                if (kPhase) ++recordFetches;
-                if constexpr (COMPACT == 6)
-                {
-                    // ---- oct records (rf_wide.hpp, WideBuild::oct): the boxes of the node's (up to) eight GREAT-GRANDCHILDREN as 8-bit planes on the record's own
-                    // grid -- three levels of the reference's tree per dependent fetch, seven loads from one 128-byte line.  CONSERVATIVE tests (the leaf phase
-                    // applies the exact boxes).  No ordering network: the record tabulates the position at which each slot is visited for the ray's sign pattern;
-                    // the slots that can still be hit go onto the stack AT THEIR PLACE in that order (a slot's place = the number of hit slots visited after it:
-                    // one popcount of the hit mask in visit order), and the first one comes straight back off the top.
-                    const uint4* n = wide.oct + 8 * static_cast<size_t>(node);
-                    const uint4  v0 = n[0], v1 = n[1], vx = n[2], vy = n[3], vz = n[4], wa = n[5], wb = n[6];
-                    const float  ax = __uint_as_float(v0.w) * pr.iXY.x, ay = __uint_as_float(v1.x) * pr.iXY.y, az = __uint_as_float(v1.y) * pr.iZ;
-                    const float  bx = __builtin_fmaf(-1024.0f, ax, (__uint_as_float(v0.x) - pr.oXY.x) * pr.iXY.x), by = __builtin_fmaf(-1024.0f, ay, (__uint_as_float(v0.y) - pr.oXY.y) * pr.iXY.y),
-                                bz = __builtin_fmaf(-1024.0f, az, (__uint_as_float(v0.z) - pr.oZ) * pr.iZ);
-                    float tq[8], fq[8];
-                    localEntryBounds<0>(vx.x, vy.x, vz.x, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[0], fq[0]);
-                    localEntryBounds<1>(vx.x, vy.x, vz.x, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[1], fq[1]);
-                    localEntryBounds<0>(vx.y, vy.y, vz.y, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[2], fq[2]);
-                    localEntryBounds<1>(vx.y, vy.y, vz.y, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[3], fq[3]);
-                    localEntryBounds<0>(vx.z, vy.z, vz.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[4], fq[4]);
-                    localEntryBounds<1>(vx.z, vy.z, vz.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[5], fq[5]);
-                    localEntryBounds<0>(vx.w, vy.w, vz.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[6], fq[6]);
-                    localEntryBounds<1>(vx.w, vy.w, vz.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq[7], fq[7]);
-                    const uint32_t words[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-                    // visit positions of the eight slots for this ray's direction signs: four nibbles, slot (c, g, 0) at nibble 2 c + g, slot (c, g, 1) at that ^ 1
-                    const unsigned long long table = (static_cast<unsigned long long>(v1.w) << 32) | v1.z;
-                    const uint32_t           ord = static_cast<uint32_t>(table >> (octKey & 63u)) ^ (octKey >> 8);
-                    // slot e can still be hit  <=>  near <= far && far > 0 && near < rayTMax  <=>  max(near, tiny) <= min(far, pred(rayTMax)): one subtraction whose SIGN
-                    // is the answer (x - y of two different floats is never zero, denormals are kept), shifted straight into the miss mask at the slot's position
-                    const float tiny = __uint_as_float(1u), predTMax = __uint_as_float(__float_as_uint(rayTMax) - 1u); // (rayTMax > 1e-5: a positive normal number)
-                    uint32_t    pos[8], miss = 0u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                    {
-                        pos[2 * j] = (ord >> (4 * j)) & 7u;
-                        pos[2 * j + 1] = pos[2 * j] ^ 1u;
-                    }
-                    float gap[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                    {
-                        gap[e] = isaMin(fq[e], predTMax) - isaMax(tq[e], tiny);
-                        miss |= (__float_as_uint(gap[e]) >> 31) << pos[e];
-                    }
-                    const uint32_t hits = ~miss & 0xFFu; // bit p: the slot visited p-th can still be hit
-                    if (hits != 0u)
-                    {
-                        const int need = __popc(hits);
-                        bool      room = true;
-                        if constexpr (kPtrStack)
-                        {
-                            while (room && stackSize + need * kSpStep > kSpLimit + spBase) room = (stackSize - spBase) >= kEvict * kSpStep && evict();
-                        }
-                        else
-                        {
-                            while (room && stackSize + need > kSpLimit) room = stackSize >= kEvict && evict();
-                        }
-                        if (__builtin_expect(room, 1))
-                        {
-                            const uint32_t later = hits >> 1;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e)
-                                if (!(__float_as_uint(gap[e]) >> 31))
-                                {
-                                    const int rank = __popc(later >> pos[e]); // hit slots visited after this one: they lie below it
-                                    if constexpr (kStackWordsOnly) stackAt(stackSize + rank * kSpStep).x = words[e];
-                                    else stackAt(stackSize + rank * kSpStep) = make_uint2(words[e], __float_as_uint(tq[e]));
-                                }
-                            stackSize += need * kSpStep;
-                            popNext();
-                        }
-                        else
-                        {
-                            needScalar = true;
-                            node = kNodeDone;
-                        }
-                    }
-                    else popNext();
-                }
-                else if constexpr (COMPACT == 3 || COMPACT == 4 || COMPACT == 5)
-                {
-                    // ---- quad records (rf_wide.hpp): the boxes of the node's (up to) four grandchildren in ONE 128-byte record --
-                    // two levels of the reference's tree per dependent fetch.  Entries 0,1 belong to the first child, 2,3 to the
-                    // second; an entry passes iff P(entry) && tmin(entry) < rayTMax, which implies the same for the skipped child.
-                    float    tq0, tq1, tq2, tq3;
-                    bool     okq0, okq1, okq2, okq3, hasNaN = false;
-                    uint32_t w0, w1, w2, w3;
-                    if constexpr (COMPACT == 3)
-                    {
-                        const auto quadStep = [&](float4 a0, float4 a1, float4 a2, float4 a3, float4 a4, float4 a5) {
-                            float f0, f1, f2, f3;
-                            slabPairBounds(pr, a0, a1, a2, tq0, f0, tq1, f1);
-                            slabPairBounds(pr, a3, a4, a5, tq2, f2, tq3, f3);
-                            asm volatile("" : "+v"(tq0), "+v"(f0), "+v"(tq1), "+v"(f1), "+v"(tq2), "+v"(f2), "+v"(tq3), "+v"(f3)); // (min/max chains stay with their products: see slabStep)
-                            if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2) || slabPairHasNaN(pr, a3, a4, a5);
-                            okq0 = tq0 <= f0 && f0 > 0.0f;
-                            okq1 = tq1 <= f1 && f1 > 0.0f;
-                            okq2 = tq2 <= f2 && f2 > 0.0f;
-                            okq3 = tq3 <= f3 && f3 > 0.0f;
-                        };
-                        const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
-                        if (uniformFetch && __ballot(node != uNode) == 0ull)
-                        {
-                            typedef uint32_t u16v __attribute__((ext_vector_type(16)));
-                            typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                            const float4* un = wide.quad + 8 * static_cast<size_t>(uNode);
-                            u16v          a;
-                            u8v           b;
-                            u4v           c;
-                            asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60\n\ts_waitcnt lgkmcnt(0)"
-                                         : "=&s"(a), "=&s"(b), "=&s"(c)
-                                         : "s"(un)
-                                         : "memory");
-                            const auto f4 = [](uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w)); };
-                            quadStep(f4(a.s0, a.s1, a.s2, a.s3), f4(a.s4, a.s5, a.s6, a.s7), f4(a.s8, a.s9, a.sa, a.sb), f4(a.sc, a.sd, a.se, a.sf), f4(b.s0, b.s1, b.s2, b.s3),
-                                     f4(b.s4, b.s5, b.s6, b.s7));
-                            w0 = c.x, w1 = c.y, w2 = c.z, w3 = c.w;
-                        }
-                        else
-                        {
-                            const float4* n = wide.quad + 8 * static_cast<size_t>(node);
-                            const float4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3], v4 = n[4], v5 = n[5], v6 = n[6];
-                            w0 = __float_as_uint(v6.x), w1 = __float_as_uint(v6.y), w2 = __float_as_uint(v6.z), w3 = __float_as_uint(v6.w);
-                            quadStep(v0, v1, v2, v3, v4, v5);
-                        }
-                    }
-                    else if constexpr (COMPACT == 5)
-                    {
-                        // ---- local-grid quad records (rf_wide.hpp, WideBuild::quadLocal): 8-bit planes on the record's own power-of-two grid,
-                        // 64 bytes -- four loads.  CONSERVATIVE tests, as with the half-precision records; the leaf phase applies the exact boxes.
-                        float          f0, f1, f2, f3;
-                        const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
-                        uint4          v0, v1, v2, v3;
-                        if (uniformFetch && __ballot(node != uNode) == 0ull)
-                        {
-                            typedef uint32_t u16v __attribute__((ext_vector_type(16)));
-                            const uint4*     un = wide.quadLocal + 4 * static_cast<size_t>(uNode);
-                            u16v             a;
-                            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(un) : "memory");
-                            v0 = make_uint4(a.s0, a.s1, a.s2, a.s3), v1 = make_uint4(a.s4, a.s5, a.s6, a.s7), v2 = make_uint4(a.s8, a.s9, a.sa, a.sb), v3 = make_uint4(a.sc, a.sd, a.se, a.sf);
-                        }
-                        else
-                        {
-                            const uint4* n = wide.quadLocal + 4 * static_cast<size_t>(node);
-                            v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3];
-                        }
-                        // A = scale / d (exact: a power of two times 1/d), B = (anchor - o) / d - 1024 A (one FMA)
-                        const float ax = __uint_as_float(v0.w) * pr.iXY.x, ay = __uint_as_float(v1.x) * pr.iXY.y, az = __uint_as_float(v1.y) * pr.iZ;
-                        const float bx = __builtin_fmaf(-1024.0f, ax, (__uint_as_float(v0.x) - pr.oXY.x) * pr.iXY.x), by = __builtin_fmaf(-1024.0f, ay, (__uint_as_float(v0.y) - pr.oXY.y) * pr.iXY.y),
-                                    bz = __builtin_fmaf(-1024.0f, az, (__uint_as_float(v0.z) - pr.oZ) * pr.iZ);
-                        localEntryBounds<0>(v1.z, v2.x, v2.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq0, f0);
-                        localEntryBounds<1>(v1.z, v2.x, v2.z, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq1, f1);
-                        localEntryBounds<0>(v1.w, v2.y, v2.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq2, f2);
-                        localEntryBounds<1>(v1.w, v2.y, v2.w, lselX, lselY, lselZ, ax, ay, az, bx, by, bz, tq3, f3);
-                        w0 = v3.x, w1 = v3.y, w2 = v3.z, w3 = v3.w;
-                        okq0 = tq0 <= f0 && f0 > 0.0f;
-                        okq1 = tq1 <= f1 && f1 > 0.0f;
-                        okq2 = tq2 <= f2 && f2 > 0.0f;
-                        okq3 = tq3 <= f3 && f3 > 0.0f;
-                    }
-                    else
-                    {
-                        // ---- half-precision quad records (rf_wide.hpp, WideBuild::quadHalf): the same four entries, planes as binary16,
-                        // 64 bytes -- four loads.  CONSERVATIVE tests (a superset passes; the leaf phase applies the exact boxes).
-                        const float    bx = hbx, by = hby, bz = hbz;
-                        const uint32_t rx = hrot, ry = hrot >> 8, rz = hrot >> 16;
-                        float       f0, f1, f2, f3;
-                        const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
-                        if (uniformFetch && __ballot(node != uNode) == 0ull)
-                        {
-                            typedef uint32_t u16v __attribute__((ext_vector_type(16)));
-                            const uint4*     un = wide.quadHalf + 4 * static_cast<size_t>(uNode);
-                            u16v             a;
-                            asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(un) : "memory");
-                            halfEntryBounds<true>(a.s0, a.s1, a.s2, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
-                            halfEntryBounds<true>(a.s3, a.s4, a.s5, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
-                            halfEntryBounds<true>(a.s6, a.s7, a.s8, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
-                            halfEntryBounds<true>(a.s9, a.sa, a.sb, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
-                            // (the four words reach the lanes HERE: left to the compiler, the SGPR -> VGPR copies sit in the join block and the per-lane
-                            // path pays for them on every step too: closest-hit launches -1 %)
-                            asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7" : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3) : "s"(a.sc), "s"(a.sd), "s"(a.se), "s"(a.sf));
-                        }
-                        else
-                        {
-                            const uint4* n = wide.quadHalf + 4 * static_cast<size_t>(node);
-                            const uint4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3];
-                            halfEntryBounds<false>(v0.x, v0.y, v0.z, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
-                            halfEntryBounds<false>(v0.w, v1.x, v1.y, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
-                            halfEntryBounds<false>(v1.z, v1.w, v2.x, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq2, f2);
-                            halfEntryBounds<false>(v2.y, v2.z, v2.w, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq3, f3);
-                            w0 = v3.x, w1 = v3.y, w2 = v3.z, w3 = v3.w;
-                        }
-                        okq0 = tq0 <= f0 && f0 > 0.0f;
-                        okq1 = tq1 <= f1 && f1 > 0.0f;
-                        okq2 = tq2 <= f2 && f2 > 0.0f;
-                        okq3 = tq3 <= f3 && f3 > 0.0f;
-                    }
-                    if (__builtin_expect(hasNaN, 0))
-                    {
-                        // class B ray: a 0 * inf product means the packed test is not the reference's here
-                        needScalar = true;
-                        okq0 = okq1 = okq2 = okq3 = false;
-                        stackSize = spBase, negMask &= 0xFFu; // -> popNext() ends the ray; it is redone below
-                    }
-                    const uint32_t axN = (w0 >> kWideAxisShift) & 3u, axA = (w1 >> kWideAxisShift) & 3u, axB = (w3 >> kWideAxisShift) & 3u;
-                    // (an any-hit ray on the conservative layouts leaves `tmin < rayTMax` to the exact leaf test: its rayTMax is the constant
-                    // tMax of the launch, which no box of a real scene lies beyond, and a superset is all these steps have to accept)
-                    constexpr bool kSkipTMax = ANY_HIT && (COMPACT == 4 || COMPACT == 5);
-                    const bool     h0 = okq0 && (kSkipTMax || tq0 < rayTMax), h1 = okq1 && (kSkipTMax || tq1 < rayTMax) && w1 != kQuadEmpty,
-                                   h2 = okq2 && (kSkipTMax || tq2 < rayTMax), h3 = okq3 && (kSkipTMax || tq3 < rayTMax) && w3 != kQuadEmpty;
-                    constexpr uint32_t kAxisMask = ~(3u << kWideAxisShift);
-                    // an entry that cannot be hit any more carries kQuadEmpty from here on
-                    const uint32_t e0 = h0 ? (w0 & kAxisMask) : kQuadEmpty, e1 = h1 ? (w1 & kAxisMask) : kQuadEmpty, e2 = h2 ? w2 : kQuadEmpty, e3 = h3 ? (w3 & kAxisMask) : kQuadEmpty;
-                    // visit order.  Closest hit: the reference's -- inside each child by dirNeg[the child's split axis], the two children by
-                    // dirNeg[the node's] (wgsl:409-417 applied at both levels).  Any hit: nearer slab entry first at both levels (the
-                    // visibility bit does not depend on the order: see NEAREST_FIRST above).
-                    bool swapA, swapB, swapN;
-                    if (NEAREST_FIRST)
-                    {
-                        const float inf = __uint_as_float(0x7F800000u);
-                        const float k0 = h0 ? tq0 : inf, k1 = h1 ? tq1 : inf, k2 = h2 ? tq2 : inf, k3 = h3 ? tq3 : inf;
-                        swapA = k1 < k0, swapB = k3 < k2;
-                        swapN = __builtin_fminf(k2, k3) < __builtin_fminf(k0, k1);
-                    }
-                    else
-                    {
-                        // (an any-hit ray that is not asked for nearest-first visits the entries in RECORD order: its answer does not depend on the
-                        // order, and on the VALU-bound 64-byte layouts the step without the ordering network -- 17 instructions -- beats the
-                        // shorter walks of any ordering: shadow launches -8 %)
-                        if (ANY_HIT) swapA = swapB = swapN = false;
-                        else swapA = ((negMask >> axA) & 1u) != 0u, swapB = ((negMask >> axB) & 1u) != 0u, swapN = ((negMask >> axN) & 1u) != 0u;
-                    }
-                    const uint32_t a0w = swapA ? e1 : e0, a1w = swapA ? e0 : e1, b0w = swapB ? e3 : e2, b1w = swapB ? e2 : e3;
-                    const float    a0t = swapA ? tq1 : tq0, a1t = swapA ? tq0 : tq1, b0t = swapB ? tq3 : tq2, b1t = swapB ? tq2 : tq3;
-                    const uint32_t s0w = swapN ? b0w : a0w, s1w = swapN ? b1w : a1w, s2w = swapN ? a0w : b0w, s3w = swapN ? a1w : b1w;
-                    const float    s1t = swapN ? b1t : a1t, s2t = swapN ? a0t : b0t, s3t = swapN ? a1t : b1t;
-                    const bool     x0 = s0w != kQuadEmpty, x1 = s1w != kQuadEmpty, x2 = s2w != kQuadEmpty, x3 = s3w != kQuadEmpty;
-                    if (x0 || x1 || x2 || x3)
-                    {
-                        // enter the first entry that can be hit; the later ones wait on the stack with their tmin, last first
-                        bool pushed = true;
-                        if constexpr (kPtrStack || kSpill)
-                        {
-                            // one bound check per step: room for the three entries a step can leave behind (a stack this full that does not
-                            // need all three evicts its oldest entries a little earlier than necessary: same entries, same order)
-                            pushed = stackSize < kSpLimit - 2 * kSpStep;
-                            if (__builtin_expect(!pushed, 0)) pushed = evict();
-                            if (pushed)
-                            {
-                                if (x3 && (x0 || x1 || x2)) pushUnchecked(s3w, s3t);
-                                if (x2 && (x0 || x1)) pushUnchecked(s2w, s2t);
-                                if (x1 && x0) pushUnchecked(s1w, s1t);
-                            }
-                        }
-                        else
-                        {
-                            if (x3 && (x0 || x1 || x2)) pushed = push(s3w, s3t);
-                            if (x2 && (x0 || x1)) pushed = push(s2w, s2t) && pushed;
-                            if (x1 && x0) pushed = push(s1w, s1t) && pushed;
-                        }
-                        node = x0 ? s0w : (x1 ? s1w : (x2 ? s2w : s3w));
-                        if (!pushed)
-                        {
-                            needScalar = true;
-                            node = kNodeDone;
-                        }
-                    }
-                    else popNext();
-                }
-                else
-                {
-                uint2 words;
-                float t0, t1;
-                bool  ok0, ok1, hasNaN = false;
-#if defined(RF_ABLATE)
-                float4 q0, q1, q2;
-#endif
-                // both boxes of the record against the lane's ray; class B rays (0 * inf possible) also check that the packed
-                // test is the reference's here (rf_wide.hpp)
-                const auto slabStep = [&](float4 a0, float4 a1, float4 a2) {
-                    float far0, far1;
-                    slabPairBounds(pr, a0, a1, a2, t0, far0, t1, far1);
-                    // (the four results are pinned here so that the min/max chains stay in the basic block of their products:
-                    // behind the rare branch below, the compiler no longer knows the products to be canonical and spends twelve
-                    // v_max x,x on quieting them)
-                    asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1));
-                    if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2);
-                    ok0 = t0 <= far0 && far0 > 0.0f;
-                    ok1 = t1 <= far1 && far1 > 0.0f;
-#if defined(RF_ABLATE)
-                    q0 = a0, q1 = a1, q2 = a2;
-#endif
-                };
-                float c0LoX = 0.0f, c0HiX = 0.0f, c1LoX = 0.0f, c1HiX = 0.0f; // COMPACT: the children's x-plane t-values
-                BoxT  c0b{}, c1b{};                                             // COMPACT == 2: all six
-                if constexpr (COMPACT == 2)
-                {
-                    // 32-byte records: two dwordx4 per step; the node's own box (second array) only for lanes that arrive from the stack
-                    const auto hotStep = [&](float4 h0, float4 h1) {
-                        words = make_uint2(__float_as_uint(h1.z), __float_as_uint(h1.w));
-                        float far0, far1;
-                        slabPairHotBounds(pr, h0, h1.x, h1.y, words.x, words.y, own, t0, far0, t1, far1, c0b, c1b);
-                        asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1)); // (min/max chains stay with their products: see slabStep)
-                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = boxPairHasNaN(c0b, c1b);
-                        ok0 = t0 <= far0 && far0 > 0.0f;
-                        ok1 = t1 <= far1 && far1 > 0.0f;
-                        words.x &= ~(3u << 24);
-                        words.y &= ~((3u << 24) | (3u << kWideAxisShift));
-                    };
-                    const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
-                    if (uniformFetch && __ballot(node != uNode) == 0ull)
-                    {
-                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                        const float4* un = wide.hot + 2 * static_cast<size_t>(uNode);
-                        const float4* uo = wide.own + 2 * static_cast<size_t>(uNode);
-                        u8v           a, b;
-                        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(un), "s"(uo) : "memory");
-                        if (!haveOuter)
-                            own = boxPlaneT(pr, make_float4(__uint_as_float(b.s0), __uint_as_float(b.s1), __uint_as_float(b.s2), __uint_as_float(b.s3)), __uint_as_float(b.s4),
-                                            __uint_as_float(b.s5));
-                        hotStep(make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
-                                make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)));
-                    }
-                    else
-                    {
-                        const float4* n = wide.hot + 2 * static_cast<size_t>(node);
-                        const float4  v0 = n[0], v1 = n[1];
-                        if (!haveOuter)
-                        {
-                            const float4* o = wide.own + 2 * static_cast<size_t>(node);
-                            const float4  o0 = o[0];
-                            const uint2*  zPtr = reinterpret_cast<const uint2*>(o + 1);
-                            asm volatile("" : "+v"(zPtr)); // (an 8-byte global load, not widened: see the words load of the plain layout below)
-                            typedef const unsigned long long __attribute__((address_space(1)))* GlobalWordPtr;
-                            const unsigned long long both = *(GlobalWordPtr)(zPtr);
-                            own = boxPlaneT(pr, o0, __uint_as_float(static_cast<uint32_t>(both)), __uint_as_float(static_cast<uint32_t>(both >> 32)));
-                        }
-                        hotStep(v0, v1);
-                    }
-                }
-                else if constexpr (COMPACT == 1)
-                {
-                    // Compact-capable records: three dwordx4 per step; the fourth piece (the node's own x planes) only for lanes that
-                    // do not carry them -- 11 % of the steps (after a pop, at the root).
-                    const auto compactStep = [&](float4 a0, float4 a1, float4 a2) {
-                        words = make_uint2(__float_as_uint(a2.x), __float_as_uint(a2.z));
-                        float far0, far1;
-                        slabPairCompactBounds(pr, a0, a1, a2, tOuterLo, tOuterHi, words.y, t0, far0, t1, far1, c0LoX, c0HiX, c1LoX, c1HiX);
-                        words.y &= ~(3u << kWideAxisShift);
-                        asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1)); // (min/max chains stay with their products: see slabStep)
-                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairCompactHasNaN(pr, a0, a1, a2, c0LoX, c0HiX, c1LoX, c1HiX);
-                        ok0 = t0 <= far0 && far0 > 0.0f;
-                        ok1 = t1 <= far1 && far1 > 0.0f;
-                    };
-                    const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
-                    if (uniformFetch && __ballot(node != uNode) == 0ull)
-                    {
-                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-                        // a wave-uniform step costs no vector-L1 access whatever the layout: it reads the PLAIN record through the scalar
-                        // cache and pays nothing for the selects -- the children's x-plane t-values are four of its twelve products
-                        const float4* un = wide.nodes + 4 * static_cast<size_t>(uNode);
-                        u8v           a;
-                        u4v           b;
-                        u2v           c;
-                        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&s"(a), "=&s"(b), "=&s"(c)
-                                     : "s"(un)
-                                     : "memory");
-                        const float4 a0 = make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
-                                     a1 = make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)),
-                                     a2 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
-                        float        far0, far1;
-                        slabPairBoundsX(pr, a0, a1, a2, t0, far0, t1, far1, c0LoX, c0HiX, c1LoX, c1HiX);
-                        asm volatile("" : "+v"(t0), "+v"(far0), "+v"(t1), "+v"(far1)); // (min/max chains stay with their products: see slabStep)
-                        if (__builtin_expect((negMask & 8u) != 0u, 0)) hasNaN = slabPairHasNaN(pr, a0, a1, a2);
-                        ok0 = t0 <= far0 && far0 > 0.0f;
-                        ok1 = t1 <= far1 && far1 > 0.0f;
-                        words = make_uint2(c.x, c.y);
-                    }
-                    else
-                    {
-                        const float4* n = wide.compact + 4 * static_cast<size_t>(node);
-                        const float4  v0 = n[0], v1 = n[1], v2 = n[2];
-                        if (!haveOuter)
-                        {
-                            const uint2* outerPtr = reinterpret_cast<const uint2*>(n + 3);
-                            asm volatile("" : "+v"(outerPtr)); // (see the words load of the plain layout below: an 8-byte global load, not widened)
-                            typedef const unsigned long long __attribute__((address_space(1)))* GlobalWordPtr;
-                            const unsigned long long both = *(GlobalWordPtr)(outerPtr);
-                            tOuterLo = (__uint_as_float(static_cast<uint32_t>(both)) - pr.oXY.x) * pr.iXY.x;
-                            tOuterHi = (__uint_as_float(static_cast<uint32_t>(both >> 32)) - pr.oXY.x) * pr.iXY.x;
-                        }
-                        compactStep(v0, v1, v2);
-                    }
-                }
-                else
-                {
-                // With the pixel-major, direction-sorted slot order the 64 rays of a wave are one pixel's samples, and at
-                // bounce 1 (and for the first steps of any freshly filled wave) every descending lane sits at the SAME
-                // record.  Then the record comes through the scalar cache with three s_load instructions instead of
-                // 4 x 64 per-lane vector loads of one line: no vector-L1 traffic at all for that step.  Same bytes, same
-                // arithmetic -- only the path the record takes to the registers differs.  The slab arithmetic is issued
-                // inside each branch, so that on this one its box operands stay in SGPRs (bounce 1 is VALU-issue bound:
-                // copying the 14 dwords into VGPRs first cost 14 of the ~85 VALU instructions of a step).
-                const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
-                if (uniformFetch && __ballot(node != uNode) == 0ull)
-                {
-                    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-                    const float4* un = wide.nodes + 4 * static_cast<size_t>(uNode);
-                    u8v           a;
-                    u4v           b;
-                    u2v           c;
-                    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&s"(a), "=&s"(b), "=&s"(c)
-                                 : "s"(un)
-                                 : "memory");
-                    slabStep(make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3)),
-                             make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7)),
-                             make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)));
-                    words = make_uint2(c.x, c.y);
-                }
-                else
-                {
-                    const float4* n = wide.nodes + 4 * static_cast<size_t>(node);
-                    // 56 of the record's 64 bytes: nothing is loaded that is not used
-                    const float4 v0 = n[0], v1 = n[1], v2 = n[2];
-                    // (the pointer goes through an empty asm so that the compiler forgets its 16-byte alignment and
-                    // cannot widen the 8-byte load back to a dwordx4; it comes back as a GLOBAL pointer -- a generic one
-                    // makes the load a flat_load, which also counts against lgkmcnt)
-                    const uint2* wordPtr = reinterpret_cast<const uint2*>(n + 3);
-                    asm volatile("" : "+v"(wordPtr));
-                    typedef const unsigned long long __attribute__((address_space(1)))* GlobalWordPtr;
-                    const unsigned long long both = *(GlobalWordPtr)(wordPtr);
-                    words = make_uint2(static_cast<uint32_t>(both), static_cast<uint32_t>(both >> 32));
-                    slabStep(v0, v1, v2);
-                }
-                }
-                const uint32_t axis = (words.x >> kWideAxisShift) & 3u;
-                const uint32_t word0 = words.x & ~(3u << kWideAxisShift), word1 = words.y;
-                if (__builtin_expect(hasNaN, 0))
-                {
-                    // class B ray: a 0 * inf product means the packed test is not the reference's here
-                    needScalar = true;
-                    ok0 = ok1 = false;
-                    stackSize = spBase, negMask &= 0xFFu; // -> popNext() ends the ray; it is redone below
-                }
-#if defined(RF_ABLATE) && RF_ABLATE == 1
-                {   // ablation: the slab arithmetic twice more (result kept alive, never different)
-                    float4 z0 = q0, z1 = q1, z2 = q2;
-                    for (int rep = 0; rep < 2; ++rep)
-                    {
-                        asm volatile("" : "+v"(z0.x), "+v"(z0.y), "+v"(z0.z), "+v"(z0.w), "+v"(z1.x), "+v"(z1.y), "+v"(z1.z), "+v"(z1.w), "+v"(z2.x), "+v"(z2.y), "+v"(z2.z), "+v"(z2.w));
-                        float a0, a1; bool b0, b1;
-                        slabPair(pr, z0, z1, z2, b0, a0, b1, a1);
-                        if (a0 != t0 || a1 != t1 || b0 != ok0 || b1 != ok1) t0 = __uint_as_float(0x7FC00000u);
-                    }
-                }
-#elif defined(RF_ABLATE) && RF_ABLATE == 2
-                {   // ablation: one more 64-byte record fetch per step, from an unrelated place
-                    const uint32_t other = (node * 2654435761u) % wide.numRecords;
-                    const float4*  m = wide.nodes + 4 * static_cast<size_t>(other);
-                    const float4   y0 = m[0], y1 = m[1], y2 = m[2], y3 = m[3];
-                    const float sum = ((y0.x + y0.y) + (y0.z + y0.w)) + ((y1.x + y1.y) + (y1.z + y1.w)) + ((y2.x + y2.y) + (y2.z + y2.w)) + ((y3.x + y3.y) + (y3.z + y3.w));
-                    if (sum == 1.2345e-33f) t0 = __uint_as_float(0x7FC00000u);
-                }
-#endif
-                // reference order: dirNeg[axis] ? second child first : first child first
-                const bool neg = NEAREST_FIRST ? (t1 < t0) : (((negMask >> axis) & 1u) != 0u);
-                if constexpr (kRefCount)
-                {
-                    const uint32_t nearWord = neg ? word1 : word0, farWord = neg ? word0 : word1;
-                    const bool     okNear = neg ? ok1 : ok0, okFar = neg ? ok0 : ok1;
-                    const float    tNear = neg ? t1 : t0, tFar = neg ? t0 : t1;
-                    const bool     pushed = push(farWord, okFar ? tFar : __uint_as_float(0x7F800000u));
-                    rayStackHigh = max(rayStackHigh, static_cast<uint32_t>(stackSize)); // (kRefCount => COUNT => plain depth)
-                    ++rayNodes; // the near child
-                    if (!pushed)
-                    {
-                        needScalar = true;
-                        node = kNodeDone;
-                    }
-                    else if (okNear && tNear < rayTMax) node = nearWord;
-                    else popNext();
-                }
-                else
-                {
-                    if (COUNT) rayNodes += 2; // this build counts box tests
-                    // which child is entered first: the near one if both can still be hit, else the one that can
-                    const bool     hit0 = ok0 && t0 < rayTMax, hit1 = ok1 && t1 < rayTMax;
-                    const bool     both = hit0 && hit1;
-                    const bool     second = both ? neg : hit1;
-                    const uint32_t firstWord = second ? word1 : word0, otherWord = second ? word0 : word1;
-                    const float    otherT = second ? t0 : t1;
-                    if (hit0 || hit1)
-                    {
-                        node = firstWord;
-                        if (COMPACT == 1)
-                        {
-                            // the child entered straight from this step: its own x-plane t-values travel with the lane
-                            tOuterLo = second ? c1LoX : c0LoX;
-                            tOuterHi = second ? c1HiX : c0HiX;
-                            haveOuter = true;
-                        }
-                        if (COMPACT == 2)
-                        {
-                            // ... all six of them with the 32-byte records
-                            own.loX = second ? c1b.loX : c0b.loX, own.loY = second ? c1b.loY : c0b.loY;
-                            own.hiX = second ? c1b.hiX : c0b.hiX, own.hiY = second ? c1b.hiY : c0b.hiY;
-                            own.loZ = second ? c1b.loZ : c0b.loZ, own.hiZ = second ? c1b.hiZ : c0b.hiZ;
-                            haveOuter = true;
-                        }
-                        if (both && !push(otherWord, otherT))
-                        {
-                            needScalar = true;
-                            node = kNodeDone;
-                        }
-                    }
-                    else popNext();
-                }
-                }
-            }
-        } while (__popcll(__ballot(static_cast<int32_t>(node) >= 0)) >= leafVote);
-
-        // ---- leaves
-#if defined(RF_EXP_PHASE)
-        if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull) ++phaseLeafWave;
-#endif
-        uint32_t occluderWord = 0u; // kOccluderCache: the leaf in which this lane has just found an occluder
-        // ---- Leaf phase over dense (lane, triangle) pairs (round 5).  The loop further down tests triangle i of every parked lane's leaf in trip i: a phase lasts as
-        // long as its LONGEST leaf, and on a scene whose leaves differ in length (the atrium with clutter: 1 ... 12 triangles, 7.2 tests per closest-hit ray) most trips
-        // run for a handful of lanes.  When a parked lane's leaf holds kDenseMin triangles or more, the phase runs over PAIRS instead: the lanes' triangle counts are
-        // prefix-summed, pair p = (owner lane, triangle p - offset[owner]) goes to lane p mod 64 of trip p / 64 (whole leaves per trip), which fetches the owner's ray
-        // through ds_bpermute and tests that one triangle against the owner's rayTMax AT ENTRY; the owner then walks through the hits among its own pairs in triangle
-        // order with the reference's `t < rayTMax` (wgsl:385-402).  Same result as the sequential walk: a triangle the walk accepts has t below the rayTMax of that
-        // moment <= the entry value, so it is among the hits here; a hit here that the walk would reject (t >= the rayTMax an earlier triangle left) is rejected by the
-        // owner's own walk over the hits, in the same order with the same comparison.  Any-hit: a leaf with a hit among its pairs stops the ray.
-        // The block is self-contained (its own leaf decode and exact box test) so that the loop below keeps its registers to itself: what it needs of a leaf's
-        // first triangle record is live only inside its own branch.  And it is a template parameter (DENSE_LEAVES): its mere presence costs the closest-hit launches
-        // of a scene that never uses it 2.5 % (profiles/r05_leaf/ab_presence.log), so scenes without long leaves run the instantiations without it.
-        bool denseDone = false; // this lane's leaf has been dealt with by this block
-        if constexpr (!COUNT && DENSE_LEAVES)
-        {
-            const uint32_t     kDenseMin = (flags >> kFlagDenseLeafShift) & 15u;
-            constexpr uint32_t kDenseMaxLeaf = 16u; // (longer leaves keep the loop below)
-            const bool         atLeafD = node - kWideLeafBit < kNodeDone - kWideLeafBit;
-            // (decided on the count field of the leaf word alone: 7 = a big leaf of 8 or more)
-            if (kDenseMin != 0u && __ballot(atLeafD && ((node >> kWideIndexBits) & 7u) + 1u >= kDenseMin) != 0ull)
-            {
-                uint32_t firstD = 0u, cnt = 0u, hintD = 0u;
-                bool     rejected = false;
-                if (atLeafD)
-                {
-                    firstD = node & ((1u << kWideIndexBits) - 1u), cnt = ((node >> kWideIndexBits) & 7u) + 1u;
-                    if (cnt == 8u)
-                    {
-                        const uint2 big = wide.bigLeaves[firstD];
-                        firstD = big.x;
-                        cnt = big.y;
-                    }
-                    if (cnt > kDenseMaxLeaf) cnt = 0u; // not taken here
-                    else if (leafBoxAtLeaf)
-                    {
-                        // the leaf's exact box, as the loop below applies it (the reference's test at the leaf: same formula, the rayTMax of this moment)
-                        const float* t0 = reinterpret_cast<const float*>(scene.triangles + kTriStride * static_cast<size_t>(firstD));
-                        const float  loX = t0[3], loY = t0[7], loZ = t0[11];
-                        const float4 hi = *reinterpret_cast<const float4*>(t0 + 12);
-                        if constexpr (kOccluderCache) hintD = __float_as_uint(hi.w);
-                        PackedRay exact = pr;
-                        if (kConservative && __builtin_expect((negMask & 8u) != 0u, 0))
-                        {
-                            const float inf = __uint_as_float(0x7F800000u);
-                            if (fabsf(exact.iXY.x) == 1e30f) exact.iXY.x = __builtin_copysignf(inf, exact.iXY.x);
-                            if (fabsf(exact.iXY.y) == 1e30f) exact.iXY.y = __builtin_copysignf(inf, exact.iXY.y);
-                            if (fabsf(exact.iZ) == 1e30f) exact.iZ = __builtin_copysignf(inf, exact.iZ);
-                        }
-                        float bn, bf;
-                        bool  boxNaN;
-                        slabSingleBounds(exact, loX, loY, loZ, hi.x, hi.y, hi.z, bn, bf, boxNaN);
-                        if (__builtin_expect((negMask & 8u) != 0u && boxNaN, 0)) cnt = 0u; // (class B ray with a 0 * inf product: left to the loop below, which sends it to the scalar traversal)
-                        else if (!(bn <= bf && bf > 0.0f && bn < rayTMax))
-                        {
-                            cnt = 0u; // the reference rejects this leaf: no triangle is tested
-                            rejected = true;
-                        }
-                    }
-                }
-                bool dealt = rejected; // this lane's leaf is finished with (rejected by its box, or its pairs have been tested)
-                bool stopped = false;                    // ANY_HIT: a pair of this lane's leaf was hit
-                const uint32_t incl = waveScanInclusive<false>(cnt), off = incl - cnt;
-                const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
-                // (worth it when the pairs need fewer trips than the longest leaf has triangles: a pair trip costs about one and a half triangle trips)
-                const uint32_t pairTrips = (total + 63u) / 64u;
-                const bool     goDense = (pairTrips <= 1u) || (pairTrips <= 2u && __ballot(cnt >= 5u) != 0ull) || (pairTrips <= 4u && __ballot(cnt >= 9u) != 0ull);
-                if (goDense)
-                {
-                    const float oX = pr.oXY.x, oY = pr.oXY.y, oZ = pr.oZ;
-                    uint32_t    base = 0u;
-                    while (base < total) // (wave-uniform)
-                    {
-                        // this trip: the leaves that start at or behind `base` and END within the next 64 pairs
-                        const unsigned long long over = __ballot(cnt != 0u && off >= base && off + cnt > base + 64u);
-                        const uint32_t           next = over != 0ull ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(off), __builtin_ctzll(over))) : total;
-                        const bool               inTrip = cnt != 0u && off >= base && off < next;
-                        const uint32_t           segLo = off - base; // (meaningful for inTrip lanes)
-                        // owner of pair slot q: every leaf of the trip drops lane + 1 at the slot of its first pair (ds_permute_b32; the other lanes drop a 0 at a slot
-                        // that starts no leaf -- the highest lane wins a slot, and only zeros compete there), then a running maximum fills the leaf's other slots
-                        const uint32_t           pairs = next - base;
-                        const unsigned long long longer = __ballot(inTrip && cnt >= 2u);
-                        const uint32_t           dump = (pairs < 64u || longer == 0ull) ? (pairs & 63u) : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(segLo), __builtin_ctzll(longer))) + 1u; // (64 one-triangle leaves: every lane sends)
-                        const uint32_t           mark = static_cast<uint32_t>(__builtin_amdgcn_ds_permute(static_cast<int>((inTrip ? segLo : dump) << 2), static_cast<int>(inTrip ? lane + 1u : 0u)));
-                        const uint32_t           owner = waveScanInclusive<true>(mark) - 1u;
-                        const bool               pairLive = lane < pairs;
-                        const uint32_t           src = pairLive ? owner : lane;
-                        const uint32_t           triOfPair = laneGather(firstD - off, src) + base + lane;
-                        const Vec3               po = vec3(laneGather(oX, src), laneGather(oY, src), laneGather(oZ, src));
-                        const Vec3               pd = vec3(laneGather(rayDir.x, src), laneGather(rayDir.y, src), laneGather(rayDir.z, src));
-                        const float              pTMax = ANY_HIT ? tMax : laneGather(rayTMax, src);
-                        TriangleHit              th{};
-                        bool                     pairHit = false;
-                        if (pairLive)
-                        {
-                            const v3f a = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * static_cast<size_t>(triOfPair));
-                            const v3f b = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * static_cast<size_t>(triOfPair) + 1);
-                            const v3f c = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * static_cast<size_t>(triOfPair) + 2);
-                            pairHit = intersectTriangle(po, pd, vec3(a.x, a.y, a.z), vec3(b.x, b.y, b.z), vec3(c.x, c.y, c.z), pTMax, th);
-                        }
-                        const unsigned long long hitMask = __ballot(pairHit);
-                        uint32_t                 mine = inTrip ? static_cast<uint32_t>(hitMask >> segLo) & ((1u << cnt) - 1u) : 0u; // hits among this lane's own pairs, bit j = triangle first + j
-                        if constexpr (ANY_HIT)
-                        {
-                            if (mine != 0u) stopped = true;
-                        }
-                        else
-                        {
-                            while (__ballot(mine != 0u) != 0ull) // (wave-uniform: the gathers below read other lanes' registers)
-                            {
-                                const uint32_t j = mine != 0u ? static_cast<uint32_t>(__builtin_ctz(mine)) : 0u;
-                                const uint32_t from = mine != 0u ? segLo + j : lane;
-                                const float    tj = laneGather(th.t, from), uj = laneGather(th.u, from), vj = laneGather(th.v, from);
-                                if (mine != 0u && tj < rayTMax)
-                                {
-                                    rayTMax = tj;
-                                    best.u = uj;
-                                    best.v = vj;
-                                    best.triangle = firstD + j;
-                                }
-                                mine &= mine - 1u;
-                            }
-                        }
-                        if (inTrip) dealt = true;
-                        base = next;
-                    }
-                }
-                else dealt = false; // (not worth it: the loop below takes every leaf, the rejected ones included -- it repeats their box test)
-                // what the loop below does with a leaf it has finished with
-                if (dealt)
-                {
-                    if (ANY_HIT && stopped)
-                    {
-                        occluded = true;
-                        if (kOccluderCache) occluderWord = hintD != 0u ? hintD : node;
-                        node = kNodeDone;
-                    }
-                    else popNext();
-                }
-                denseDone = dealt;
-            }
-        }
-        if (node - kWideLeafBit < kNodeDone - kWideLeafBit && !denseDone) // (a lane the dense phase has moved on may hold its NEXT leaf by now: that one waits for the next phase)
-        {
-            uint32_t first = node & ((1u << kWideIndexBits) - 1u), n = ((node >> kWideIndexBits) & 7u) + 1u;
-            if (n == 8u)
-            {
-                const uint2 big = wide.bigLeaves[first];
-                first = big.x;
-                n = big.y;
-            }
-            bool finished = false;
-            if (kPhase) ++wLeafPhase;
-            float4 firstA{}, firstB{}, firstC{};
-            uint32_t leafHint = 0u;
-            if (leafBoxAtLeaf)
-            {
-                // The half-precision / local-grid quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
-                // test its box, exactly, with its own formula, against the rayTMax of this moment -- happens here.  The leaf's box
-                // rides in the spare floats of its first triangle record (leafBoxesIntoTriangles): the same 64-byte line.
-                const float4* t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
-                firstA = t0[0], firstB = t0[1], firstC = t0[2];
-                float4 hi;
-                if constexpr (kOccluderCache) hi = t0[3]; // .w: what the occluder cache remembers for this leaf (leafBoxesIntoTriangles)
-                else
-                {
-                    const v3f h3 = *reinterpret_cast<const v3f*>(t0 + 3);
-                    hi = make_float4(h3.x, h3.y, h3.z, 0.0f);
-                }
-                if constexpr (kOccluderCache) leafHint = __float_as_uint(hi.w);
-                float     bn, bf;
-                bool      boxNaN;
-                PackedRay exact = pr;
-                if (kConservative && __builtin_expect((negMask & 8u) != 0u, 0))
-                {
-                    // class B: the infinite components of 1/d that the conservative tests replaced by +-1e30 (refill) are infinite again
-                    const float inf = __uint_as_float(0x7F800000u);
-                    if (fabsf(exact.iXY.x) == 1e30f) exact.iXY.x = __builtin_copysignf(inf, exact.iXY.x);
-                    if (fabsf(exact.iXY.y) == 1e30f) exact.iXY.y = __builtin_copysignf(inf, exact.iXY.y);
-                    if (fabsf(exact.iZ) == 1e30f) exact.iZ = __builtin_copysignf(inf, exact.iZ);
-                }
-                slabSingleBounds(exact, firstA.w, firstB.w, firstC.w, hi.x, hi.y, hi.z, bn, bf, boxNaN);
-                if (__builtin_expect((negMask & 8u) != 0u && boxNaN, 0))
-                {
-                    // class B ray with a 0 * inf product at this box: the reference's NaN rules apply -- the whole ray is redone by
-                    // the scalar traversal (as the exact-record kernels do for any step with such a product)
-                    needScalar = true;
-                    stackSize = spBase, negMask &= 0xFFu;
-                    n = 0;
-                }
-                else if (!(bn <= bf && bf > 0.0f && bn < rayTMax)) n = 0; // the reference rejects this leaf: no triangle is tested
-            }
-            for (uint32_t i = 0; i < n; ++i)
-            {
-                if (kPhase) ++wLeaf;
-                const uint32_t tri = first + i;
-                Vec3           p0, p1, p2;
-                // the same triangle in every lane of this leaf phase (one pixel's samples reaching the same leaf): scalar cache
-                const uint32_t uTri = __builtin_amdgcn_readfirstlane(tri);
-                if (leafBoxAtLeaf && i == 0u)
-                {
-                    p0 = vec3(firstA.x, firstA.y, firstA.z), p1 = vec3(firstB.x, firstB.y, firstB.z), p2 = vec3(firstC.x, firstC.y, firstC.z);
-                }
-                else if (uniformTri && __ballot(tri != uTri) == 0ull)
-                {
-                    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                    const float4* ut = scene.triangles + kTriStride * static_cast<size_t>(uTri);
-                    u8v           ab;
-                    u4v           cc;
-                    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ab), "=&s"(cc) : "s"(ut) : "memory");
-                    p0 = vec3(__uint_as_float(ab.s0), __uint_as_float(ab.s1), __uint_as_float(ab.s2));
-                    p1 = vec3(__uint_as_float(ab.s4), __uint_as_float(ab.s5), __uint_as_float(ab.s6));
-                    p2 = vec3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
-                }
-                else
-                {
-                    const v3f a = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri);
-                    const v3f b = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 1);
-                    const v3f c = *reinterpret_cast<const v3f*>(scene.triangles + kTriStride * tri + 2);
-                    p0 = vec3(a.x, a.y, a.z), p1 = vec3(b.x, b.y, b.z), p2 = vec3(c.x, c.y, c.z);
-                }
-                if (COUNT) ++rayTris;
-#if defined(RF_EXP_PHASE)
-                ++phaseTris;
-#endif
-                TriangleHit th;
-                if (intersectTriangle(vec3(pr.oXY.x, pr.oXY.y, pr.oZ), rayDir, p0, p1, p2, rayTMax, th))
-                {
-                    if (ANY_HIT)
-                    {
-                        occluded = true;
-                        finished = true;
-                        break;
-                    }
-                    // the offset hit point (wgsl:511-519) is rebuilt from (triangle, u, v) by kShade
-                    rayTMax = th.t;
-                    best.u = th.u;
-                    best.v = th.v;
-                    best.triangle = tri;
-                }
-            }
-            if (finished)
-            {
-                if (kOccluderCache) occluderWord = leafHint != 0u ? leafHint : node;
-#if defined(RF_EXP_PHASE)
-                if (ANY_HIT) { ++phaseOccluded; if (phaseFromCache && stackSize == spBase + kSpStep) ++phaseOccHit; }
-#endif
-                node = kNodeDone;
-            }
-            else popNext();
-        }
-
-        // ---- write back finished rays
-        if (kSpill && node == kNodeDone && !needScalar && !occluded)
-        {
-            while (node == kNodeDone && (negMask >> 8) != 0u) // evicted entries pending: not finished after all (rare: see evict())
-            {
-                unspill();
-                popNext();
-            }
-        }
-        if (node == kNodeDone)
-        {
-            if (needScalar)
-            {
-                // axis-parallel / denormal / non-finite rays (0 * inf slabs) and rays whose stack outgrew
-                // LDS: the reference's own scalar traversal, whole ray at once
-                TraversalCounters c2;
-                atomicAdd(&counters->scalarRedo[ANY_HIT ? 1 : 0], 1ull);
-                best.triangle = kMiss;
-                occluded = traverse<ANY_HIT, COUNT, 0>(scene, vec3(pr.oXY.x, pr.oXY.y, pr.oZ), rayDir, tMax, nullptr, best, c2);
-                if (c2.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-                rayTMax = best.triangle != kMiss ? best.t : tMax;
-                rayNodes = c2.nodesVisited;
-                rayTris = c2.triangleTests;
-                rayStackHigh = c2.stackHigh;
-            }
-            if (COUNT)
-            {
-                tc.nodesVisited += rayNodes;
-                tc.triangleTests += rayTris;
-                tc.stackHigh = max(tc.stackHigh, rayStackHigh);
-            }
-            if constexpr (kOccluderCache)
-            {
-                // kOccSlots entries per cell, most recent first: a new occluder goes to the front (the others move back, the last one drops out); a ray
-                // that tried the cell's entries and reached the sun drops the first one
-                if (occluderCache && (occluderWord != 0u || (!occluded && (negMask & kNegTriedHint) != 0u)))
-                {
-                    uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(occluderCell(pr.oXY.x, pr.oXY.y, pr.oZ));
-                    uint32_t        old[kOccSlots], now[kOccSlots];
-                    loadOccluderCell(cell, old);
-                    if (occluderWord == 0u)
-                    {
-#pragma unroll
-                        for (int k = 0; k < kOccSlots; ++k) now[k] = k + 1 < kOccSlots ? old[k + 1 < kOccSlots ? k + 1 : k] : 0u;
-                        storeOccluderCell(cell, now);
-                    }
-                    else if (occluderWord != old[0])
-                    {
-                        int at = kOccSlots - 1; // where the word sits already (else: the last place is given up)
-#pragma unroll
-                        for (int k = kOccSlots - 2; k >= 1; --k)
-                            if (old[k] == occluderWord) at = k;
-                        now[0] = occluderWord;
-#pragma unroll
-                        for (int k = 1; k < kOccSlots; ++k) now[k] = k <= at ? old[k - 1] : old[k];
-                        storeOccluderCell(cell, now);
-                    }
-                }
-            }
-            if (ANY_HIT)
-            {
-                const float visibility = occluded ? 0.0f : 1.0f;
-                const Vec3  add = (pendingTerm * visibility) * __uint_as_float(kSolarInvPdfBits);
-                // An occluded ray adds pending * 0 = +-0 to a sum that is never -0 (it starts at +0, and x + y = -0 only for two
-                // negative zeros): the sum keeps its bits, so its slot -- a random 16-byte read-modify-write by now -- is left
-                // alone.  Not at bounce 1 (the sum is not in memory yet), and not when the product is NaN (an infinite or NaN
-                // NEE term times 0: the reference's sum turns NaN, and so does this one).
-                const bool unchanged = !firstBounce && add.x == 0.0f && add.y == 0.0f && add.z == 0.0f;
-                if (!unchanged)
-                {
-                    const Vec3 radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add; // bounce 1: still 0 (wgsl:183)
-                    store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
-                }
-            }
-            else
-            {
-                // .w = t of the hit (rayTMax == best.t then); read by the query path only
-                store4s(ps.hit + resultIndex, __uint_as_float(best.triangle), best.u, best.v, rayTMax);
-            }
-            node = kNodeIdle;
-        }
-    }
-
-    if (COUNT)
-    {
-        const unsigned long long nv = waveSum(tc.nodesVisited), tt = waveSum(tc.triangleTests);
-        const uint32_t           sh = waveMax(tc.stackHigh);
-        if (lane == 0)
-        {
-            atomicAdd(ANY_HIT ? &counters->shadowNodeVisits : &counters->closestNodeVisits, nv);
-            atomicAdd(ANY_HIT ? &counters->shadowTriangleTests : &counters->closestTriangleTests, tt);
-            if (!ANY_HIT) atomicMax(&counters->stackHigh, sh);
-        }
-        const unsigned long long rf = waveSum(recordFetches);
-        if (lane == 0) atomicAdd(ANY_HIT ? &counters->shadowRecordFetches : &counters->closestRecordFetches, rf);
-        // wave-level trips: a loop body executed by the wave counts once whatever the number of active lanes
-        // (lanes that were active carry the count; take the max over the wave), except pops (lane work)
-        const int                k = ANY_HIT ? 1 : 0;
-        const unsigned long long pops = waveSum(wPop);
-        const uint32_t           d = waveMax(wDescend), l = waveMax(wLeaf), lp = waveMax(wLeafPhase), r = waveMax(wRefill), o = waveMax(wOuter);
-        if (lane == 0)
-        {
-            atomicAdd(&counters->descendTrips[k], static_cast<unsigned long long>(d));
-            atomicAdd(&counters->leafTrips[k], static_cast<unsigned long long>(l));
-            atomicAdd(&counters->leafPhases[k], static_cast<unsigned long long>(lp));
-            atomicAdd(&counters->refillTrips[k], static_cast<unsigned long long>(r));
-            atomicAdd(&counters->popLaneTrips[k], pops);
-            atomicAdd(&counters->outerTrips[k], static_cast<unsigned long long>(o));
-        }
-    }
-#if defined(RF_EXP_PHASE)
-    if (!COUNT)
-    {
-        const int                k = ANY_HIT ? 1 : 0;
-        const unsigned long long laneSteps = waveSum(recordFetches), laneLeaves = waveSum(wLeafPhase), laneTris = waveSum(phaseTris);
-        const uint32_t           d = waveMax(wDescend), lp = waveMax(phaseLeafWave), r = waveMax(wRefill), o = waveMax(wOuter);
-        if (lane == 0)
-        {
-            atomicAdd(ANY_HIT ? &counters->shadowRecordFetches : &counters->closestRecordFetches, laneSteps);
-            atomicAdd(&counters->descendTrips[k], static_cast<unsigned long long>(d));
-            atomicAdd(&counters->leafPhases[k], static_cast<unsigned long long>(lp));
-            atomicAdd(&counters->leafTrips[k], laneLeaves);
-            atomicAdd(&counters->popLaneTrips[k], laneTris);
-            atomicAdd(&counters->refillTrips[k], static_cast<unsigned long long>(r));
-            atomicAdd(&counters->outerTrips[k], static_cast<unsigned long long>(o));
-        }
-        const unsigned long long ot = waveSum(phaseOccTried), oh = waveSum(phaseOccHit), oc = waveSum(phaseOccluded);
-        if (lane == 0 && ANY_HIT) atomicAdd(&counters->occluderTried, ot), atomicAdd(&counters->occluderHit, oh), atomicAdd(&counters->occludedRays, oc);
-    }
-#endif
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !(flags & kFlagNoRayCount)) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// kShadowFirstLook: the occluder cache (kTraceWide, kFlagOccluderCache) without the traversal kernel around it.  Once the grid is warm nine
-// shadow rays in ten are stopped by one of the (up to) kOccSlots leaves their cell names -- 1.4 leaf visits and no interior step at all --
-// and a persistent, stack-carrying, lane-refilling kernel is a poor place for work that short.  This kernel walks the bounce's shadow queue
-// densely, one ray per lane and nothing to carry: cell of the origin -> its leaves in turn -> each leaf's exact box with the reference's
-// formula (leafBoxesIntoTriangles) -> the leaf's triangles.  A ray stopped there is finished (its NEE term times 0, exactly as the
-// traversal's write-back adds it; a leaf other than the cell's first moves to the front); every other ray's queue position goes onto a list
-// that the traversal launch works through -- without a first look of its own (kFlagOccluderNoTry), recording what it finds in the grid.
-//
-// Same visibility as the reference's shadowRay (wgsl:321-368), by the argument at kOccluderCache: a triangle is tested there iff the walk
-// reaches its leaf, i.e. iff the boxes of the leaf and of all its ancestors pass; an ancestor's box contains the leaf's and the slab
-// arithmetic is monotone in the planes, so a ray that passes the leaf's own test passes every ancestor's: the reference either reaches this
-// leaf and finds the same triangle, or has found another one before -- occluded either way.  Rays that are not class A (rf_wide.hpp: an
-// infinite 1/direction component, a non-finite origin), big leaves and cells without an entry are simply passed on.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
-                                                            const uint32_t* queueCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax, uint32_t firstBounce)
-{
-    __shared__ uint32_t sScratch[8];
-    const uint32_t      count = *queueCount;
-    const uint32_t      tiles = (count + kItems * kBlock - 1) / (kItems * kBlock);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
-    // (one entry after the other: staging the kItems entries of a thread -- four cells, then four triangle records in flight per lane -- takes 163
-    // registers, three waves per SIMD instead of eight, and measured 17 % slower: profiles/r04_occluder/firstlook2.log)
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
-    {
-        bool     keep[kItems];
-        uint32_t entry[kItems];
-#pragma unroll
-        for (int k = 0; k < kItems; ++k)
-        {
-            const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
-            keep[k] = i < count;
-            entry[k] = i;
-            if (i >= count) continue;
-            const Vec3     o = load3(ps.rayO + i);
-            uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(occluderCellIndex(wide, o.x, o.y, o.z));
-            uint32_t        e[kOccSlots];
-            loadOccluderCell(cell, e);
-            if (e[0] == 0u) continue;
-            const Vec3    nz = load3(ps.noiseOut + i);
-            const Vec3    dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
-            const RayPrep ray = prepareRay(o, dir);
-            if (classifyRay(ray) != kRayPlain) continue;
-            entry[k] = i | 0x80000000u; // has tried its cell's leaves
-            const PackedRay pr = packRay(ray);
-            int             at = -1; // which of the cell's leaves stopped the ray
-#pragma unroll
-            for (int j = 0; j < kOccSlots; ++j)
-            {
-                const uint32_t w = e[j];
-                // (a leaf word with its triangle count in the word, not in the big-leaf table)
-                if (at >= 0 || (w & kWideLeafBit) == 0u || ((w >> kWideIndexBits) & 7u) == 7u) continue;
-                const uint32_t first = w & ((1u << kWideIndexBits) - 1u), n = ((w >> kWideIndexBits) & 7u) + 1u;
-                const float4*  t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
-                const float4   a = t0[0], b = t0[1], c = t0[2];
-                const v3f      hi = *reinterpret_cast<const v3f*>(t0 + 3);
-                float          bn, bf;
-                bool           boxNaN;
-                slabSingleBounds(pr, a.w, b.w, c.w, hi.x, hi.y, hi.z, bn, bf, boxNaN);
-                if (!(bn <= bf && bf > 0.0f && bn < tMax)) continue; // the reference rejects this leaf
-                TriangleHit th;
-                bool        stopped = intersectTriangle(o, dir, vec3(a.x, a.y, a.z), vec3(b.x, b.y, b.z), vec3(c.x, c.y, c.z), tMax, th);
-                for (uint32_t t = 1; t < n && !stopped; ++t)
-                {
-                    const v3f q0 = *reinterpret_cast<const v3f*>(t0 + kTriStride * t), q1 = *reinterpret_cast<const v3f*>(t0 + kTriStride * t + 1),
-                              q2 = *reinterpret_cast<const v3f*>(t0 + kTriStride * t + 2);
-                    stopped = intersectTriangle(o, dir, vec3(q0.x, q0.y, q0.z), vec3(q1.x, q1.y, q1.z), vec3(q2.x, q2.y, q2.z), tMax, th);
-                }
-                if (stopped) at = j;
-            }
-            if (at < 0) continue;
-            keep[k] = false;
-            if (at > 0)
-            {
-                uint32_t now[kOccSlots];
-                now[0] = e[at];
-#pragma unroll
-                for (int j = 1; j < kOccSlots; ++j) now[j] = j <= at ? e[j - 1] : e[j];
-                storeOccluderCell(cell, now);
-            }
-            // the traversal's write-back for an occluded ray (kTraceWide): radiance += (pending * 0) * invPdf -- a sum that keeps its bits unless the
-            // product is NaN, or the sum is not in memory yet (bounce 1)
-            const Vec3 add = (load3(ps.pending + i) * 0.0f) * __uint_as_float(kSolarInvPdfBits);
-            const bool unchanged = firstBounce == 0u && add.x == 0.0f && add.y == 0.0f && add.z == 0.0f;
-            if (!unchanged)
-            {
-                const uint32_t slot = queue[i];
-                const Vec3     radiance = (firstBounce != 0u ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot)) + add;
-                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            }
-        }
-        blockAppend<kItems>(keep, entry, list, listCount, sScratch);
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// kTracePacket: 64 consecutive queue entries = ONE packet that walks the tree in lockstep.
-//
-// With the pixel-major, direction-sorted slot order the 64 rays of a wave at bounce 1 are 64 samples of one pixel:
-// (almost) one origin, one direction.  Such a wave does not need 64 private traversals.  The packet runs the
-// reference's depth-first order ONCE -- wave-uniform node, wave-uniform stack, records and triangles through the
-// scalar cache (s_load: no vector-L1 traffic for the tree at all), scalar branches -- and every lane carries only its
-// own ray, its own rayTMax and an `active` bit:
-//
-//   at a record:   hitN/hitF per lane as in kTraceWide (P(child) && tmin < rayTMax, for lanes active at this node);
-//                  any lane enters near -> the packet enters near with active = hitN, and far is pushed (if any lane
-//                  hits it) with EVERY lane's own tmin (+inf for lanes that do not hit it); no lane near but some far
-//                  -> the packet enters far directly; none -> pop
-//   at a pop:      active = (the lane's stored tmin < the lane's rayTMax NOW) -- the reference's test at pop time;
-//                  an entry no lane wants is skipped
-//   at a leaf:     the active lanes test the leaf's triangles in order.
-//
-// A lane is active at a node iff its own traversal would visit that node, and the nodes at which it is active come in
-// its own depth-first order PROVIDED the near/far order is the lane's: the order is dirNeg[splitAxis] (wgsl:409-417),
-// so a closest-hit packet is formed of lanes with equal direction signs (a wave with mixed signs -- pixels on the
-// screen's axes -- runs one pass per sign pattern).  Its rayTMax therefore evolves exactly as in the reference and
-// hit{triangle,u,v,t} are bit-identical.  Any-hit packets take all lanes at once and choose the order by vote (the
-// visibility bit does not depend on the order: see NEAREST_FIRST above); an occluded lane drops out with rayTMax = -inf.
-// Rays that are not class A (rf_wide.hpp), and the members of a packet whose shared stack outgrows kPacketDepth, are
-// redone by the scalar reference-ordered traversal, as in kTraceWide.
-// ------------------------------------------------------------------------------------------------
-#if defined(RF_EXP_LEGACY_LAYOUTS) // (round 5: the packet kernel lost to kTraceWide in round 2 and has been off since; `make EXP=RF_EXP_LEGACY_LAYOUTS` builds it, the compact-capable and the 32-byte records)
-constexpr int kPacketDepth = 24; // shared stack entries per wave (<= 64): per-lane tmin [depth][lane] in LDS + one child word per entry
-
-template<bool ANY_HIT>
-__global__ __launch_bounds__(kBlock, 6) void kTracePacket(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
-                                                          const uint32_t* queue, const uint32_t* queueCount, DeviceCounters* counters, float tMax, uint32_t flags)
-{
-    __shared__ float    sTMin[kPacketDepth * kBlock];
-    const uint32_t      count = *queueCount;
-    const uint32_t      lane = __lane_id(), wave = threadIdx.x >> 6;
-    const bool          shadowDirFromStream = flags & kFlagShadowDirFromStream;
-    const bool          firstBounce = flags & kFlagFirstBounce;
-    const float         kInf = __uint_as_float(0x7F800000u);
-    float* const        myTMin = sTMin + threadIdx.x;
-    const uint32_t      numChunks = (count + 63u) / 64u;
-    const uint32_t      totalWaves = gridDim.x * (kBlock / 64);
-
-    for (uint32_t chunkIdx = blockIdx.x * (kBlock / 64) + wave; chunkIdx < numChunks; chunkIdx += totalWaves)
-    {
-        const uint32_t idx = chunkIdx * 64u + lane;
-        const bool     valid = idx < count;
-        uint32_t       slot = 0;
-        Vec3           o = vec3(0.0f, 0.0f, 0.0f), dir = vec3(0.0f, 0.0f, 1.0f);
-        if (valid)
-        {
-            if (ANY_HIT) slot = loadQ(queue + idx);
-            o = load3s(ps.rayO + idx);
-            if (ANY_HIT && !shadowDirFromStream)
-            {
-                const Vec3 nz = load3s(ps.noiseOut + idx);
-                dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
-            }
-            else dir = load3s(ps.rayD + idx);
-        }
-        const RayPrep   ray = prepareRay(o, dir);
-        const PackedRay pr = packRay(ray);
-        const uint32_t  rayClass = classifyRay(ray);
-        const uint32_t  negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2);
-        bool            needScalar = valid && rayClass != kRayPlain;
-        const bool      regular = valid && rayClass == kRayPlain;
-        float           rootTMin;
-        const bool      rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin);
-        ClosestHit      best{};
-        best.triangle = kMiss;
-        float resultT = tMax;  // closest: t of the hit (tMax: none); any-hit: -inf once occluded
-        bool  occluded = false;
-
-        unsigned long long todo = __ballot(regular);
-        while (todo != 0ull)
-        {
-            // members of this pass: closest-hit -- the lanes that share the first waiting lane's direction signs
-            bool member = regular;
-            if (!ANY_HIT)
-            {
-                const uint32_t leader = static_cast<uint32_t>(__ffsll(static_cast<long long>(todo))) - 1u;
-                const uint32_t uNeg = __builtin_amdgcn_readlane(negMask, leader);
-                member = regular && ((todo >> lane) & 1ull) != 0ull && negMask == uNeg;
-            }
-            const unsigned long long memberMask = __ballot(member);
-            todo &= ~memberMask;
-            const uint32_t passNeg = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(negMask, static_cast<uint32_t>(__ffsll(static_cast<long long>(memberMask))) - 1u));
-
-            float limit = member ? tMax : -kInf; // the lane's rayTMax; -inf: every comparison `t < limit` fails
-            bool  active = rootOk && rootTMin < limit;
-            if (__ballot(active) == 0ull) continue;
-            uint32_t node = wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u;
-            int      depth = 0;
-            bool     overflow = false;
-            uint32_t wordStack = 0; // the shared stack's child words: entry d lives in lane d of this register (v_writelane / v_readlane)
-            for (;;)
-            {
-                node = __builtin_amdgcn_readfirstlane(node);
-                bool popNow = false;
-                if (static_cast<int32_t>(node) >= 0)
-                {
-                    typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-                    const float4* un = wide.nodes + 4 * static_cast<size_t>(node);
-                    u8v           a;
-                    u4v           b;
-                    u2v           c;
-                    asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&s"(a), "=&s"(b), "=&s"(c)
-                                 : "s"(un)
-                                 : "memory");
-                    const float4   q0 = make_float4(__uint_as_float(a.s0), __uint_as_float(a.s1), __uint_as_float(a.s2), __uint_as_float(a.s3));
-                    const float4   q1 = make_float4(__uint_as_float(a.s4), __uint_as_float(a.s5), __uint_as_float(a.s6), __uint_as_float(a.s7));
-                    const float4   q2 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
-                    const uint32_t axis = (c.x >> kWideAxisShift) & 3u;
-                    const uint32_t word0 = c.x & ~(3u << kWideAxisShift), word1 = c.y;
-                    float          t0, t1;
-                    bool           ok0, ok1;
-                    slabPair(pr, q0, q1, q2, ok0, t0, ok1, t1);
-                    const bool hit0 = active && ok0 && t0 < limit, hit1 = active && ok1 && t1 < limit;
-                    const unsigned long long m0 = __ballot(hit0), m1 = __ballot(hit1);
-                    // which child is "near": the reference's split-axis order (closest-hit), a vote (any-hit)
-                    bool secondFirst;
-                    if (ANY_HIT) secondFirst = 2 * __popcll(__ballot(hit0 && hit1 && t1 < t0)) > __popcll(m0 & m1);
-                    else secondFirst = ((passNeg >> axis) & 1u) != 0u;
-                    const unsigned long long mN = secondFirst ? m1 : m0, mF = secondFirst ? m0 : m1;
-                    const uint32_t           nearWord = secondFirst ? word1 : word0, farWord = secondFirst ? word0 : word1;
-                    const bool               hitN = secondFirst ? hit1 : hit0, hitF = secondFirst ? hit0 : hit1;
-                    const float              tF = secondFirst ? t0 : t1;
-                    if (mN != 0ull)
-                    {
-                        if (mF != 0ull)
-                        {
-                            if (depth >= kPacketDepth)
-                            {
-                                overflow = true;
-                                break;
-                            }
-                            myTMin[depth * kBlock] = hitF ? tF : kInf;
-                            {
-                                // v_writelane takes its lane select from m0 when the value is an SGPR too (constant-bus limit); m0 is put back
-                                uint32_t keepM0;
-                                asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                                             : "+v"(wordStack), "=&s"(keepM0)
-                                             : "s"(farWord), "s"(depth));
-                            }
-                            ++depth;
-                        }
-                        node = nearWord;
-                        active = hitN;
-                    }
-                    else if (mF != 0ull)
-                    {
-                        node = farWord;
-                        active = hitF;
-                    }
-                    else popNow = true;
-                }
-                else
-                {
-                    // ---- leaf: the active lanes test its triangles in order
-                    uint32_t first = node & ((1u << kWideIndexBits) - 1u), n = ((node >> kWideIndexBits) & 7u) + 1u;
-                    if (n == 8u)
-                    {
-                        const uint2 big = wide.bigLeaves[first];
-                        first = __builtin_amdgcn_readfirstlane(big.x);
-                        n = __builtin_amdgcn_readfirstlane(big.y);
-                    }
-                    for (uint32_t i = 0; i < n; ++i)
-                    {
-                        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
-                        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-                        const uint32_t tri = first + i;
-                        const float4*  ut = scene.triangles + kTriStride * static_cast<size_t>(tri);
-                        u8v            ab;
-                        u4v            cc;
-                        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ab), "=&s"(cc) : "s"(ut) : "memory");
-                        const Vec3 p0 = vec3(__uint_as_float(ab.s0), __uint_as_float(ab.s1), __uint_as_float(ab.s2));
-                        const Vec3 p1 = vec3(__uint_as_float(ab.s4), __uint_as_float(ab.s5), __uint_as_float(ab.s6));
-                        const Vec3 p2 = vec3(__uint_as_float(cc.x), __uint_as_float(cc.y), __uint_as_float(cc.z));
-                        TriangleHit th;
-                        if (active && intersectTriangle(o, dir, p0, p1, p2, limit, th))
-                        {
-                            if (ANY_HIT)
-                            {
-                                occluded = true;
-                                limit = -kInf;
-                                active = false;
-                            }
-                            else
-                            {
-                                limit = th.t;
-                                best.u = th.u;
-                                best.v = th.v;
-                                best.triangle = tri;
-                            }
-                        }
-                    }
-                    if (ANY_HIT && __ballot(member && !occluded) == 0ull) break; // every member has its answer
-                    popNow = true;
-                }
-                if (popNow)
-                {
-                    bool found = false;
-                    while (depth > 0)
-                    {
-                        --depth;
-                        const float tm = myTMin[depth * kBlock];
-                        active = tm < limit;
-                        if (__ballot(active) != 0ull)
-                        {
-                            node = __builtin_amdgcn_readlane(wordStack, static_cast<uint32_t>(depth));
-                            found = true;
-                            break;
-                        }
-                    }
-                    if (!found) break;
-                }
-            }
-            if (overflow)
-            {
-                // deeper than the shared stack: the members of this pass are redone one by one
-                if (member)
-                {
-                    needScalar = true;
-                    best.triangle = kMiss;
-                    occluded = false;
-                }
-            }
-            else if (member) resultT = limit;
-        }
-
-        if (needScalar)
-        {
-            TraversalCounters c2;
-            atomicAdd(&counters->scalarRedo[ANY_HIT ? 1 : 0], 1ull);
-            best.triangle = kMiss;
-            occluded = traverse<ANY_HIT, false, 0>(scene, o, dir, tMax, nullptr, best, c2);
-            if (c2.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-            resultT = best.triangle != kMiss ? best.t : tMax;
-        }
-        if (valid)
-        {
-            if (ANY_HIT)
-            {
-                const float visibility = occluded ? 0.0f : 1.0f;
-                const Vec3  add = (load3s(ps.pending + idx) * visibility) * __uint_as_float(kSolarInvPdfBits);
-                const Vec3  radiance = (firstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3s(ps.rad + slot)) + add;
-                store4s(ps.rad + slot, radiance.x, radiance.y, radiance.z, 0.0f);
-            }
-            else store4s(ps.hit + idx, __uint_as_float(best.triangle), best.u, best.v, resultT);
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ANY_HIT ? &counters->shadowRays : &counters->closestRays, static_cast<unsigned long long>(count));
-}
-#endif // RF_EXP_LEGACY_LAYOUTS
-
-// Query path: offset hit points of a hit stream (the render path does this in kShade).
-__global__ void kHitPoints(DeviceScene scene, const float4* hit, P3* rayO, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4   h = hit[i];
-    const uint32_t tri = __float_as_uint(h.x);
-    if (tri == kMiss) return;
-    const Vec3 hp = hitPoint(scene, tri, h.y, h.z);
-    store3(rayO + i, hp);
-}
-
-// Queue occupancy per bounce: Q[b-1] paths enter bounce b (closest-hit rays), Q[b] of them hit
-// something (shadow rays).  Folded into running totals at the end of every batch.
-// `listCounts` / `lookMask`: bounces whose any-hit launch ran behind kShadowFirstLook (bit b) -- Q[b] minus the length of its list is what that kernel answered.
-__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals, const uint32_t* listCounts, unsigned long long lookMask, unsigned long long* lookBatch)
-{
-    const uint32_t b = threadIdx.x;
-    if (b >= numBounces) return;
-    const uint32_t k = min(b, RenderStats::kMaxBounceStats - 1);
-    atomicAdd(&totals[k], static_cast<unsigned long long>(queueCounts[kLineWords * b]));
-    atomicAdd(&totals[RenderStats::kMaxBounceStats + k], static_cast<unsigned long long>(queueCounts[kLineWords * (b + 1)]));
-    if ((lookMask >> b) & 1ull)
-    {
-        const unsigned long long rays = queueCounts[kLineWords * (b + 1)], answered = rays - listCounts[kLineWords * b];
-        atomicAdd(&totals[2 * RenderStats::kMaxBounceStats + k], answered);
-        atomicAdd(&lookBatch[0], answered); // this batch alone: the host decides from it whether the first look pays (Impl::firstLookHoldOff)
-        atomicAdd(&lookBatch[1], rays);
-    }
-}
-
-// image[lp] += radiance of samples 0..numSamples-1 in order (f32, wgsl:55); image is the compact
-// tile-major float4 buffer.
-__global__ __launch_bounds__(kBlock) void kAccumulate(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image)
-{
-    const uint32_t lp = blockIdx.x * kBlock + threadIdx.x;
-    if (lp >= fp.pixelsPadded) return;
-    uint32_t x, y;
-    if (!localPixelToXY(fp, tileIds, lp, x, y)) return;
-    float4 acc = image[lp];
-    for (uint32_t k = 0; k < fp.numSamples; ++k)
-    {
-        const float4 r = ps.rad[samplePixelToSlot(fp, fp.sampleInvPerm ? fp.sampleInvPerm[k] : k, lp)];
-        acc.x += r.x;
-        acc.y += r.y;
-        acc.z += r.z;
-    }
-    image[lp] = acc;
-}
-
-// The same sum for the pixel-major slot order (slotGroupShift = 0), where a pixel's samples sit in one contiguous run of
-// numSamples float4: there kAccumulate's per-thread reads are a 16-byte gather at a stride of numSamples * 16 bytes (8.2 ms per
-// 320 spp of a 1080p frame).  Here one wave takes kAccPixels pixels: their runs are read coalesced (1 KiB per load) into LDS, then
-// one lane per (pixel, channel) adds its samples in sample-index order -- the order is the result (f32, H15), so the
-// additions stay sequential; only the memory traffic changes.  Dynamic LDS: kAccPixels * (numSamples + 1) * 12 bytes (rows padded by one float: bank-conflict-free sums).
-#if defined(RF_EXP_ACC_PIXELS)
-constexpr uint32_t kAccPixels = RF_EXP_ACC_PIXELS;
-#else
-constexpr uint32_t kAccPixels = 4;
-#endif
-constexpr uint32_t kAccMaxSamples = 1024;
-
-__global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image)
-{
-    extern __shared__ float sRun[]; // [pixel][channel][sample], rows of S + 1 floats: the twelve lanes that sum walk twelve different banks
-    const uint32_t S = fp.numSamples, R = S + 1u, lane = threadIdx.x;
-    const uint32_t lp0 = blockIdx.x * kAccPixels;
-    for (uint32_t px = 0; px < kAccPixels; ++px)
-    {
-        const uint32_t lp = lp0 + px;
-        if (lp >= fp.pixelsPadded) break;
-        const float4* run = ps.rad + static_cast<size_t>(lp) * S;
-        float*        dst = sRun + px * 3u * R;
-        for (uint32_t p = lane; p < S; p += 64u)
-        {
-            // position p of the run holds sample samplePerm[p]: stored at ITS index, so that the sums below walk LDS in order
-            const Vec3     v = load3(run + p);
-            const uint32_t k = fp.samplePerm ? fp.samplePerm[p] : p;
-            dst[k] = v.x;
-            dst[R + k] = v.y;
-            dst[2u * R + k] = v.z;
-        }
-    }
-    __syncthreads();
-    if (lane >= kAccPixels * 3u) return;
-    const uint32_t px = lane / 3u, c = lane % 3u, lp = lp0 + px;
-    if (lp >= fp.pixelsPadded) return;
-    uint32_t x, y;
-    if (!localPixelToXY(fp, tileIds, lp, x, y)) return;
-    float*       out = reinterpret_cast<float*>(image + lp) + c;
-    float        acc = *out;
-    const float* src = sRun + (px * 3u + c) * R;
-#pragma unroll 8
-    for (uint32_t k = 0; k < S; ++k) acc += src[k]; // sample order (wgsl:56-57): one dependent chain of f32 additions per channel
-    *out = acc;
-}
-
-// wgsl:59-63,277-285 -> BGRA8Unorm texel
-__global__ void kTonemap(const float4* image, uint32_t n, uint32_t accumulatedSamples, float exposure, uint32_t* out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 px = image[i];
-    const float  in[3] = {px.x, px.y, px.z};
-    uint32_t     q[3];
-    for (int c = 0; c < 3; ++c)
-    {
-        const float est = in[c] / static_cast<float>(accumulatedSamples);
-        const float x = exposure * est;
-        const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
-        float       y = (x * (a * x + b)) / (x * (cc * x + d) + e);
-        y = minf(maxf(y, 0.0f), 1.0f);
-        const float srgb = wPow(y, 1.0f / 2.2f);
-        q[c] = static_cast<uint32_t>(floorf(srgb * 255.0f + 0.5f));
-    }
-    out[i] = q[2] | (q[1] << 8) | (q[0] << 16) | (255u << 24);
-}
-
-// bvh-visualizer pass (src/bvh-visualizer/main.cpp:60-78): pinhole camera.cpp:44-52 rays.
-__global__ __launch_bounds__(kBlock) void kPrimaryStats(DeviceScene scene, Camera cam, uint32_t width, uint32_t height,
-                                                         uint32_t* nodesVisited, uint8_t* hitOut, float* tOut, uint32_t* triTests, DeviceCounters* counters)
-{
-    __shared__ uint32_t sStack[kLdsStack * kBlock];
-    // 8x8 pixel blocks per wave for coherence; output is row-major
-    const uint32_t blocksX = (width + 7u) / 8u;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t j = (wave % blocksX) * 8u + (lane & 7u);
-    const uint32_t i = (wave / blocksX) * 8u + (lane >> 3);
-    if (j >= width || i >= height) return;
-    const float u = static_cast<float>(j) / static_cast<float>(width);
-    const float v = 1.0f - static_cast<float>(i + 1) / static_cast<float>(height);
-    const Vec3  dir = normalize(cam.lowerLeftCorner + cam.horizontal * u + cam.vertical * v - cam.origin);
-    ClosestHit        h;
-    TraversalCounters tc;
-    const bool        found = traverse<false, true>(scene, cam.origin, dir, FLT_MAX, &sStack[threadIdx.x], h, tc);
-    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-    const size_t      k = static_cast<size_t>(i) * width + j;
-    nodesVisited[k] = tc.nodesVisited;
-    if (hitOut) hitOut[k] = found ? 1 : 0;
-    if (tOut) tOut[k] = found ? h.t : 0.0f;
-    if (triTests) triTests[k] = tc.triangleTests;
-}
-
-__global__ __launch_bounds__(kBlock) void kIntersectRays(DeviceScene scene, const float* rays, uint64_t n, float tMax, uint32_t* triOut,
-                                                          float* tOut, float* uvOut, float* pOut, uint32_t* nvOut, uint32_t* ttOut, DeviceCounters* counters)
-{
-    __shared__ uint32_t sStack[kLdsStack * kBlock];
-    const uint64_t      i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float*      r = rays + 6 * i;
-    ClosestHit        h;
-    TraversalCounters tc;
-    const bool        found = traverse<false, true>(scene, vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), tMax, &sStack[threadIdx.x], h, tc);
-    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-    triOut[i] = h.triangle;
-    if (tOut) tOut[i] = found ? h.t : 0.0f;
-    if (uvOut)
-    {
-        uvOut[2 * i] = found ? h.u : 0.0f;
-        uvOut[2 * i + 1] = found ? h.v : 0.0f;
-    }
-    if (pOut)
-    {
-        pOut[3 * i] = found ? h.p.x : 0.0f;
-        pOut[3 * i + 1] = found ? h.p.y : 0.0f;
-        pOut[3 * i + 2] = found ? h.p.z : 0.0f;
-    }
-    if (nvOut) nvOut[i] = tc.nodesVisited;
-    if (ttOut) ttOut[i] = tc.triangleTests;
-}
-
-__global__ __launch_bounds__(kBlock) void kOccludedRays(DeviceScene scene, const float* rays, uint64_t n, float tMax, float* visOut, DeviceCounters* counters)
-{
-    __shared__ uint32_t sStack[kLdsStack * kBlock];
-    const uint64_t      i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float*      r = rays + 6 * i;
-    ClosestHit        h;
-    TraversalCounters tc;
-    const bool        occluded = traverse<true, false>(scene, vec3(r[0], r[1], r[2]), vec3(r[3], r[4], r[5]), tMax, &sStack[threadIdx.x], h, tc);
-    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-    visOut[i] = occluded ? 0.0f : 1.0f;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Deferred-lighting variant: src/pt/deferred_renderer_lighting_pass.wgsl:96-186 and
-// deferred_renderer_resolve_pass.wgsl:33-54 over a G-buffer that comes from ONE PRIMARY RAY per pixel instead of
-// the reference's raster pass (deferred_renderer_gbuffer_pass.wgsl: needs a hardware rasteriser).  What differs from
-// the reference by construction, and only there: the albedo is the nearest texel (the path tracer's textureLookup,
-// the raster pass samples through a sampler), the shading normal and position are not quantised by a texture format,
-// and visibility comes from the primary ray rather than the depth buffer.  Everything downstream is the WGSL's: the
-// fixed 2-bounce surfaceColor with the solar disk in the sky term (:231-235), the OTHER self-intersection constants
-// (1/16384 and 1024, :498-500), one blue-noise pair per pixel with a 2^20-frame cycle, the 0.1 / 0.9 exponential
-// resolve.  An interactive-preview path: one thread per pixel, the scalar reference-ordered traversal.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ Vec3 offsetPositionDeferred(Vec3 p, Vec3 n)
-{
-    constexpr float kOrigin = 1.0f / 32.0f, kFloatScale = 1.0f / 16384.0f, kIntScale = 1024.0f; // lighting_pass.wgsl:498-500
-    const int       ox = static_cast<int>(kIntScale * n.x), oy = static_cast<int>(kIntScale * n.y), oz = static_cast<int>(kIntScale * n.z);
-    const Vec3      shifted = vec3(__int_as_float(__float_as_int(p.x) + (p.x < 0 ? -ox : ox)), __int_as_float(__float_as_int(p.y) + (p.y < 0 ? -oy : oy)),
-                                   __int_as_float(__float_as_int(p.z) + (p.z < 0 ? -oz : oz)));
-    return vec3(fabsf(p.x) < kOrigin ? p.x + kFloatScale * n.x : shifted.x, fabsf(p.y) < kOrigin ? p.y + kFloatScale * n.y : shifted.y,
-                fabsf(p.z) < kOrigin ? p.z + kFloatScale * n.z : shifted.z);
-}
-
-struct DeferredSurface
-{
-    Vec3 plain, offset, normal, albedo;
-};
-
-// interpolated attributes of a hit (lighting_pass.wgsl:312-321) + hit point pushed along the geometric normal (:447-450)
-__device__ __forceinline__ DeferredSurface deferredSurface(const DeviceScene& scene, const float* lut, const ClosestHit& h)
-{
-    DeferredSurface out;
-    const Vec3 p0 = load3(scene.triangles + kTriStride * h.triangle), p1 = load3(scene.triangles + kTriStride * h.triangle + 1),
-               p2 = load3(scene.triangles + kTriStride * h.triangle + 2);
-    const Vec3 e1 = p1 - p0, e2 = p2 - p0;
-    out.plain = p0 + h.u * e1 + h.v * e2;
-    out.offset = offsetPositionDeferred(out.plain, normalize(cross(e1, e2)));
-    const float4* va = scene.attributes + 4 * static_cast<size_t>(h.triangle);
-    const float4  a0 = va[0], a1 = va[1], a2 = va[2], a3 = va[3];
-    const Vec3    n0 = vec3(a0.x, a0.y, a0.z), n1 = vec3(a0.w, a1.x, a1.y), n2 = vec3(a1.z, a1.w, a2.x);
-    const float   b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
-    out.normal = (b0 * n0 + b1 * n1) + b2 * n2;
-    const float uvx = (b0 * a2.y + b1 * a2.w) + b2 * a3.y, uvy = (b0 * a2.z + b1 * a3.x) + b2 * a3.z;
-    out.albedo = evalTexture(scene, lut, __float_as_uint(a3.w), uvx, uvy);
-    return out;
-}
-
-// lighting_pass.wgsl:200-238: the dome plus the solar disk; TERRESTRIAL_SOLAR_RADIUS = 0.255f * (PI / 180f) in f32
-__device__ __forceinline__ Vec3 skyWithSun(const SkyStateGpu& sky, Vec3 v)
-{
-    const Vec3  s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
-    const float theta = wAcos(v.y), gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
-    const float cosGamma = wCos(gamma), cosTheta = fabsf(wCos(theta));
-    const bool  inDisk = gamma / __uint_as_float(0x3B91D640u) <= 1.0f;
-    return vec3(skyRadiance(sky, cosTheta, gamma, cosGamma, 0) + (inDisk ? sky.solarRadiances[0] : 0.0f),
-                skyRadiance(sky, cosTheta, gamma, cosGamma, 1) + (inDisk ? sky.solarRadiances[1] : 0.0f),
-                skyRadiance(sky, cosTheta, gamma, cosGamma, 2) + (inDisk ? sky.solarRadiances[2] : 0.0f));
-}
-
-__global__ __launch_bounds__(kBlock) void kDeferredLighting(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, Camera cam, uint32_t width, uint32_t height,
-                                                             uint32_t frameCount, float jitterX, float jitterY, float exposure, float* sampleBuffer,
-                                                             float* accumulationBuffer, uint32_t* bgraOut, DeviceCounters* counters)
-{
-    __shared__ uint32_t sStack[kLdsStack * kBlock];
-    __shared__ float    sLut[256];
-    sLut[threadIdx.x] = scene.albedoLut[threadIdx.x];
-    __syncthreads();
-    // 8x8-pixel blocks per wave
-    const uint32_t blocksX = (width + 7u) / 8u;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    const uint32_t x = (wave % blocksX) * 8u + (lane & 7u), y = (wave / blocksX) * 8u + (lane >> 3);
-    // lanes outside the frame (sizes that are not multiples of 8) stay alive for the wave reduction at the end and contribute 0
-    unsigned long long closest = 0, shadow = 0;
-    if (x < width && y < height)
-    {
-    const float W = static_cast<float>(width), H = static_cast<float>(height);
-    // pixel centre displaced by the frame's projection jitter (deferred_renderer.cpp:309-315: (r2 - 0.5) / size in NDC)
-    const float su = (static_cast<float>(x) + 0.5f) / W - (jitterX - 0.5f) / (2.0f * W);
-    const float tv = (1.0f - (static_cast<float>(y) + 0.5f) / H) - (jitterY - 0.5f) / (2.0f * H);
-    const Vec3  rd = normalize(cam.lowerLeftCorner + cam.horizontal * su + cam.vertical * tv - cam.origin);
-    TraversalCounters  tc;
-    ClosestHit         h;
-    closest = 1;
-    Vec3               color;
-    const Vec3         lightIntensity = vec3(sky.solarRadiances[0], sky.solarRadiances[1], sky.solarRadiances[2]);
-    if (!traverse<false, false>(scene, cam.origin, rd, kTMax, &sStack[threadIdx.x], h, tc)) color = skyWithSun(sky, rd); // :106-117
-    else
-    {
-        DeferredSurface sf = deferredSurface(scene, sLut, h);
-        Vec3            normal = sf.normal, albedo = sf.albedo;
-        Vec3            position = offsetPositionDeferred(sf.plain, normal); // :118-125: along the SHADING normal
-        float           ux, uy;
-        animatedBlueNoise(scene.blueNoise, x, y, frameCount, 1u << 20, ux, uy);
-        const float phi = 2.0f * kPi * uy;
-        const float cosPhi = wCos(phi), sinPhi = wSin(phi);
-        const Vec3  light = sunSample(sky, sunBasis, ux, cosPhi, sinPhi);
-        const auto  lightSample = [&](Vec3 pos, Vec3 n, Vec3 alb) { // :188-198
-            const Vec3 reflectance = (alb * kFrac1Pi) * dot(n, light);
-            ClosestHit unused;
-            ++shadow;
-            const float vis = traverse<true, false>(scene, pos, light, kTMax, &sStack[threadIdx.x], unused, tc) ? 0.0f : 1.0f;
-            return ((lightIntensity * reflectance) * vis) * __uint_as_float(kSolarInvPdfBits);
-        };
-        Vec3 radiance = vec3(0.0f, 0.0f, 0.0f), throughput = vec3(1.0f, 1.0f, 1.0f);
-        radiance = radiance + throughput * lightSample(position, normal, albedo);
-        for (int bounce = 1; bounce < 2; ++bounce) // NUM_BOUNCES = 2 (:140)
-        {
-            const float sinTheta = rf_sqrt(1.0f - ux);
-            Vec3        bu, bv;
-            pixarOnb(normal, bu, bv);
-            const Vec3 wi = basisTimes(bu, bv, normal, vec3(cosPhi * sinTheta, sinPhi * sinTheta, rf_sqrt(ux)));
-            throughput = throughput * albedo;
-            ++closest;
-            if (traverse<false, false>(scene, position, wi, kTMax, &sStack[threadIdx.x], h, tc))
-            {
-                sf = deferredSurface(scene, sLut, h);
-                position = sf.offset;
-                normal = sf.normal;
-                albedo = sf.albedo;
-            }
-            else
-            {
-                radiance = radiance + throughput * skyWithSun(sky, wi);
-                break;
-            }
-            radiance = radiance + throughput * lightSample(position, normal, albedo);
-        }
-        color = radiance;
-    }
-    const size_t idx = static_cast<size_t>(y) * width + x;
-    sampleBuffer[3 * idx] = color.x;
-    sampleBuffer[3 * idx + 1] = color.y;
-    sampleBuffer[3 * idx + 2] = color.z;
-    // resolve_pass.wgsl:38-52
-    Vec3 outc = color;
-    if (frameCount != 0u)
-    {
-        const Vec3 prev = vec3(accumulationBuffer[3 * idx], accumulationBuffer[3 * idx + 1], accumulationBuffer[3 * idx + 2]);
-        outc = 0.1f * color + 0.9f * prev;
-    }
-    accumulationBuffer[3 * idx] = outc.x;
-    accumulationBuffer[3 * idx + 1] = outc.y;
-    accumulationBuffer[3 * idx + 2] = outc.z;
-    const float in[3] = {outc.x, outc.y, outc.z};
-    uint32_t    q[3];
-    for (int c = 0; c < 3; ++c)
-    {
-        const float xx = exposure * in[c];
-        const float a = 2.51f, b = 0.03f, cc = 2.43f, d = 0.59f, e = 0.14f;
-        float       yy = (xx * (a * xx + b)) / (xx * (cc * xx + d) + e);
-        yy = minf(maxf(yy, 0.0f), 1.0f);
-        q[c] = static_cast<uint32_t>(floorf(wPow(yy, 1.0f / 2.2f) * 255.0f + 0.5f));
-    }
-    bgraOut[idx] = q[2] | (q[1] << 8) | (q[0] << 16) | (255u << 24);
-    if (tc.abandoned) atomicAdd(&counters->abandonedRays, 1ull);
-    }
-    const unsigned long long cr = waveSum(closest), sr = waveSum(shadow);
-    if (__lane_id() == 0)
-    {
-        atomicAdd(&counters->closestRays, cr);
-        atomicAdd(&counters->shadowRays, sr);
-    }
-}
-
 template<typename T>
 struct DeviceBuffer
 {
@@ -3179,11 +414,14 @@ struct Renderer::Impl
         dim3            grid;
         uint32_t        extraLds;
     };
-    template<bool ANY_HIT, bool COUNT, bool NEAREST, int COMPACT, bool DENSE = false>
-    void launchWide(const WideScene& w, const WideArgs& a, uint32_t flags)
+    // One kTraceWide launch: the instantiation named by (any-hit, counting build, nearest-first, record layout, dense leaf phase) from rf_trace.hip's table; a
+    // combination the table does not hold falls back to the same one without the dense leaf phase (options can ask for it on a layout it is not built for)
+    void launchWide(bool anyHit, bool count, bool nearest, int compact, bool dense, const WideScene& w, const WideArgs& a, uint32_t flags)
     {
-        hipLaunchKernelGGL((kTraceWide<ANY_HIT, COUNT, NEAREST, COMPACT, DENSE>), a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr,
-                           a.refillMin, optLeafVote, a.chunk, a.tMax, flags);
+        TraceWideKernel k = traceWideKernel(anyHit, count, nearest, compact, dense);
+        if (k == nullptr && dense) k = traceWideKernel(anyHit, count, nearest, compact, false);
+        if (k == nullptr) throw std::logic_error("kTraceWide: record layout " + std::to_string(compact) + " is not compiled into this build");
+        hipLaunchKernelGGL(k, a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr, a.refillMin, optLeafVote, a.chunk, a.tMax, flags);
     }
     // the layout a test asks for, if this scene has it (else the binary records)
     int layoutIfPresent(int want) const
@@ -3200,7 +438,7 @@ struct Renderer::Impl
         }
     }
     // does a launch with these flags want the dense leaf phase?  (the scene has a leaf as long as the threshold the flags carry: the instantiations that
-    // contain the block -- the layouts the renderer picks by itself -- are used only then)
+    // contain the block -- the layouts the renderer picks by itself -- are used only then: its mere presence costs a launch 2.5 %, profiles/r05_leaf)
     bool denseWanted(uint32_t flags) const
     {
         const uint32_t threshold = (flags >> kFlagDenseLeafShift) & 15u;
@@ -3208,49 +446,15 @@ struct Renderer::Impl
     }
     void launchClosestWide(int layout, bool count, const WideScene& w, const WideArgs& a, uint32_t flags)
     {
-        if (count) return launchWide<false, true, false, 0>(w, a, flags);
-        if (denseWanted(flags))
-            switch (layout)
-            {
-            case kLayoutQuadLocal: return launchWide<false, false, false, 5, true>(w, a, flags);
-            case kLayoutQuadHalf: return launchWide<false, false, false, 4, true>(w, a, flags);
-            case kLayoutQuad: return launchWide<false, false, false, 3, true>(w, a, flags);
-            default: break;
-            }
-        switch (layout)
-        {
-        case kLayoutOct: return launchWide<false, false, false, 6>(w, a, flags);
-        case kLayoutQuadLocal: return launchWide<false, false, false, 5>(w, a, flags);
-        case kLayoutQuadHalf: return launchWide<false, false, false, 4>(w, a, flags);
-        case kLayoutQuad: return launchWide<false, false, false, 3>(w, a, flags);
-#if defined(RF_EXP_LEGACY_LAYOUTS)
-        case kLayoutHot: return launchWide<false, false, false, 2>(w, a, flags);
-        case kLayoutCompact: return launchWide<false, false, false, 1>(w, a, flags);
-#endif
-        default: return launchWide<false, false, false, 0>(w, a, flags);
-        }
+        if (count) return launchWide(false, true, false, 0, false, w, a, flags);
+        launchWide(false, false, false, layout <= kLayoutOct ? layout : kLayoutBinary, denseWanted(flags), w, a, flags);
     }
     // nearest: entries ordered by slab distance (NEAREST_FIRST); else record order (the conservative layouts' default: optShadowSignOrder)
     void launchShadowWide(int layout, bool nearest, bool count, const WideScene& w, const WideArgs& a, uint32_t flags)
     {
-        if (count) return nearest ? launchWide<true, true, true, 0>(w, a, flags) : launchWide<true, true, false, 0>(w, a, flags);
-        if (denseWanted(flags))
-        {
-            if (layout == kLayoutQuadLocal && !nearest) return launchWide<true, false, false, 5, true>(w, a, flags);
-            if (layout == kLayoutQuadHalf && !nearest) return launchWide<true, false, false, 4, true>(w, a, flags);
-            if (layout == kLayoutQuad && nearest) return launchWide<true, false, true, 3, true>(w, a, flags);
-        }
-        switch (layout)
-        {
-        case kLayoutQuadLocal: return nearest ? launchWide<true, false, true, 5>(w, a, flags) : launchWide<true, false, false, 5>(w, a, flags);
-        case kLayoutQuadHalf: return nearest ? launchWide<true, false, true, 4>(w, a, flags) : launchWide<true, false, false, 4>(w, a, flags);
-        case kLayoutQuad: return nearest ? launchWide<true, false, true, 3>(w, a, flags) : launchWide<true, false, false, 3>(w, a, flags);
-#if defined(RF_EXP_LEGACY_LAYOUTS)
-        case kLayoutHot: return launchWide<true, false, true, 2>(w, a, flags);
-        case kLayoutCompact: return launchWide<true, false, true, 1>(w, a, flags);
-#endif
-        default: return nearest ? launchWide<true, false, true, 0>(w, a, flags) : launchWide<true, false, false, 0>(w, a, flags);
-        }
+        if (count) return launchWide(true, true, nearest, 0, false, w, a, flags);
+        const int compact = (layout <= kLayoutQuadLocal) ? layout : kLayoutBinary;
+        launchWide(true, false, (compact == kLayoutCompact || compact == kLayoutHot) ? true : nearest, compact, denseWanted(flags), w, a, flags);
     }
     // The layout the renderer picks BY ITSELF for the closest-hit / any-hit launch of a bounce (the per-scene defaults set at upload + the options; reported by
     // rf_renderer_layout_info and used by traceBatch): kLayoutScalar = the one-ray-per-thread kernels (trees the packed tests cannot serve), kLayoutPacket = kTracePacket
@@ -3348,7 +552,7 @@ struct Renderer::Impl
         else
         {
             launchClosestWide(layoutIfPresent(optQueryCompact), false, wide, wa, denseFlag);
-            hipLaunchKernelGGL(kHitPoints, dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
+            hipLaunchKernelGGL(hitPointsKernel(), dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
         }
         RF_HIP(hipGetLastError());
         RF_HIP(hipStreamSynchronize(stream));
@@ -3443,10 +647,10 @@ struct Renderer::Impl
         uint32_t* qIn = queueA.ptr;
         uint32_t* qOut = queueB.ptr;
         if (fp.samplePerm)
-            hipLaunchKernelGGL(kSamplePermutation, dim3((numSamples + 255) / 256), dim3(256), 0, stream, firstFrame, fp.samplesPerPixel, numSamples,
+            hipLaunchKernelGGL(samplePermutationKernel(), dim3((numSamples + 255) / 256), dim3(256), 0, stream, firstFrame, fp.samplesPerPixel, numSamples,
                                const_cast<uint32_t*>(fp.samplePerm), const_cast<uint32_t*>(fp.sampleInvPerm));
         launchTimed(0, [&] {
-            hipLaunchKernelGGL(kRaygen, dim3(itemBlocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
+            hipLaunchKernelGGL(raygenKernel(), dim3(itemBlocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
         });
         const dim3 persistentGrid(std::min(blocks, wideBlocks));
         for (uint32_t bounce = 1; bounce <= numBounces; ++bounce)
@@ -3470,13 +674,13 @@ struct Renderer::Impl
                 if (layoutClosest == kLayoutScalar)
                 {
                     if (counting)
-                        hipLaunchKernelGGL(kTraceClosest<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+                        hipLaunchKernelGGL(traceClosestKernel(true), dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
                     else
-                        hipLaunchKernelGGL(kTraceClosest<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
+                        hipLaunchKernelGGL(traceClosestKernel(false), dim3(blocks), dim3(kBlock), 0, stream, scene, ps, qIn, countIn, counters.ptr);
                 }
 #if defined(RF_EXP_LEGACY_LAYOUTS)
                 else if (layoutClosest == kLayoutPacket)
-                    hipLaunchKernelGGL((kTracePacket<false>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
+                    hipLaunchKernelGGL(tracePacketKernel(false), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
 #endif
                 else
                     launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds},
@@ -3487,11 +691,11 @@ struct Renderer::Impl
                 const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u);
                 const dim3     shadeGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
                 if (optShadeSortFromBounce != 0u && bounce >= optShadeSortFromBounce)
-                    hipLaunchKernelGGL(kShade<true>, shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, sortScale);
+                    hipLaunchKernelGGL(shadeKernel(true), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, sortScale);
                 else
-                    hipLaunchKernelGGL(kShade<false>, shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, 0u);
+                    hipLaunchKernelGGL(shadeKernel(false), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, 0u);
                 // the paths that left the scene at this bounce, while its direction / throughput arrays and queue are intact
-                hipLaunchKernelGGL(kSky, dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, qIn, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
+                hipLaunchKernelGGL(skyKernel(), dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, qIn, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
             });
             // occluder cache (kTraceWide, kFlagOccluderCache): the conservative-record any-hit launches of bounces 1..optOccluderCacheBounces; their rays are
             // short (a third of the steps), so the deep launches refill earlier
@@ -3509,19 +713,19 @@ struct Renderer::Impl
                 {
                     // (the bounce's input queue is free by now -- kShade and kSky have consumed it -- and holds the list)
                     const dim3 lookGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
-                    hipLaunchKernelGGL(kShadowFirstLook, lookGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, qIn, listCount, counters.ptr, kTMax, bounce == 1 ? 1u : 0u);
+                    hipLaunchKernelGGL(shadowFirstLookKernel(), lookGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, qIn, listCount, counters.ptr, kTMax, bounce == 1 ? 1u : 0u);
                     wide.rayList = qIn;
                 }
                 if (layoutShadow == kLayoutScalar)
                 {
                     if (counting)
-                        hipLaunchKernelGGL(kTraceShadow<true>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
+                        hipLaunchKernelGGL(traceShadowKernel(true), dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
                     else
-                        hipLaunchKernelGGL(kTraceShadow<false>, dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
+                        hipLaunchKernelGGL(traceShadowKernel(false), dim3(blocks), dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qOut, countOut, counters.ptr, bounce == 1 ? 1u : 0u);
                 }
 #if defined(RF_EXP_LEGACY_LAYOUTS)
                 else if (layoutShadow == kLayoutPacket)
-                    hipLaunchKernelGGL((kTracePacket<true>), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, counters.ptr, kTMax,
+                    hipLaunchKernelGGL(tracePacketKernel(true), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, counters.ptr, kTMax,
                                        shadowFlags & kFlagFirstBounce);
 #endif
                 else
@@ -3537,7 +741,7 @@ struct Renderer::Impl
             std::swap(ps.thr, ps.thrOut);
             std::swap(ps.noise, ps.noiseOut);
         }
-        hipLaunchKernelGGL(kBounceTotals, dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr, listCounts, lookMask, lookBatch.ptr);
+        hipLaunchKernelGGL(bounceTotalsKernel(), dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr, listCounts, lookMask, lookBatch.ptr);
         if (lookMask != 0ull && lookBatchHost != nullptr)
         {
             RF_HIP(hipMemcpyAsync(lookBatchHost, lookBatch.ptr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -3547,10 +751,10 @@ struct Renderer::Impl
         if (wide.occGrid != nullptr) occluderGridWarm = true;
         launchTimed(4, [&] {
             if (fp.slotGroupShift == 0u && numSamples > 4u && numSamples <= kAccMaxSamples && optAccumulateRuns)
-                hipLaunchKernelGGL(kAccumulateRuns, dim3((fp.pixelsPadded + kAccPixels - 1) / kAccPixels), dim3(64), kAccPixels * 3u * (numSamples + 1u) * sizeof(float), stream, fp,
+                hipLaunchKernelGGL(accumulateRunsKernel(), dim3((fp.pixelsPadded + kAccPixels - 1) / kAccPixels), dim3(64), kAccPixels * 3u * (numSamples + 1u) * sizeof(float), stream, fp,
                                    tileIds.ptr, ps, image);
             else
-                hipLaunchKernelGGL(kAccumulate, dim3((fp.pixelsPadded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, fp, tileIds.ptr, ps, image);
+                hipLaunchKernelGGL(accumulateKernel(), dim3((fp.pixelsPadded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, fp, tileIds.ptr, ps, image);
         });
         RF_HIP(hipGetLastError());
         RF_HIP(hipEventRecord(bt.stop, stream));
@@ -3784,7 +988,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         hipDeviceProp_t prop{};
         RF_HIP(hipGetDeviceProperties(&prop, m.device));
         int perCu = 0;
-        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, 0));
+        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(traceWideKernel(false, false, false, 0, false)), kBlock, 0));
         m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
         m.skyBlocks = 8u * static_cast<uint32_t>(prop.multiProcessorCount);
         if (const char* v = std::getenv("RF_TRAVERSAL_VARIANT")) m.traversalVariant = std::atoi(v);
@@ -4052,7 +1256,7 @@ void Renderer::readTonemapped(uint32_t* dst)
         RF_HIP(hipMemsetAsync(m.image, 0, static_cast<size_t>(n) * sizeof(float4), m.stream));
         m.imageDirty = false;
     }
-    if (n) hipLaunchKernelGGL(kTonemap, dim3((n + 255) / 256), dim3(256), 0, m.stream, m.image, n, m.accumulated, m.params.exposure, out.ptr);
+    if (n) hipLaunchKernelGGL(tonemapKernel(), dim3((n + 255) / 256), dim3(256), 0, m.stream, m.image, n, m.accumulated, m.params.exposure, out.ptr);
     RF_HIP(hipStreamSynchronize(m.stream));
     std::vector<uint32_t> compact(n);
     if (n) RF_HIP(hipMemcpy(compact.data(), out.ptr, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
@@ -4077,7 +1281,7 @@ void Renderer::tonemapDeviceImage(const void* imageDevice, uint64_t numPixels, u
     const uint32_t         n = static_cast<uint32_t>(numPixels);
     DeviceBuffer<uint32_t> out;
     out.alloc(n);
-    hipLaunchKernelGGL(kTonemap, dim3((n + 255) / 256), dim3(256), 0, m.stream, static_cast<const float4*>(imageDevice), n, samples, m.params.exposure, out.ptr);
+    hipLaunchKernelGGL(tonemapKernel(), dim3((n + 255) / 256), dim3(256), 0, m.stream, static_cast<const float4*>(imageDevice), n, samples, m.params.exposure, out.ptr);
     RF_HIP(hipGetLastError());
     RF_HIP(hipMemcpyAsync(dst, out.ptr, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost, m.stream));
     RF_HIP(hipStreamSynchronize(m.stream));
@@ -4106,7 +1310,7 @@ void Renderer::renderDeferred(uint32_t numFrames)
         const float     i = static_cast<float>(m.deferredFrameCount % (1u << 20));
         const float     a = 0.5f + A1 * i, b = 0.5f + A2 * i;
         const float     jx = a - std::floor(a), jy = b - std::floor(b);
-        hipLaunchKernelGGL(kDeferredLighting, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, m.stream, m.scene, m.sky, m.sunBasis, m.params.camera, W, H,
+        hipLaunchKernelGGL(deferredLightingKernel(), dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, m.stream, m.scene, m.sky, m.sunBasis, m.params.camera, W, H,
                            m.deferredFrameCount, jx, jy, m.params.exposure, m.deferredSample.ptr, m.deferredAccum.ptr, m.deferredBgra.ptr, m.counters.ptr);
         ++m.deferredFrameCount;
     }
@@ -4190,7 +1394,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
         hipDeviceProp_t prop{};
         RF_HIP(hipGetDeviceProperties(&prop, m.device));
         int perCu = 0;
-        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kTraceWide<false, false>, kBlock, m.optExtraLds));
+        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(traceWideKernel(false, false, false, 0, false)), kBlock, m.optExtraLds));
         m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
     }
     else throw std::invalid_argument("unknown option " + name);
@@ -4287,7 +1491,7 @@ void Renderer::tracePrimaryStats(const Camera& camera, uint32_t width, uint32_t 
     hit.alloc(n);
     t.alloc(n);
     const uint32_t waves = ((width + 7) / 8) * ((height + 7) / 8);
-    hipLaunchKernelGGL(kPrimaryStats, dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, m.stream, m.scene, camera, width, height,
+    hipLaunchKernelGGL(primaryStatsKernel(), dim3((waves * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, m.stream, m.scene, camera, width, height,
                        nv.ptr, hit.ptr, t.ptr, tt.ptr, m.counters.ptr);
     RF_HIP(hipGetLastError());
     RF_HIP(hipStreamSynchronize(m.stream));
@@ -4329,7 +1533,7 @@ void Renderer::intersectRays(const float* rays6, uint64_t numRays, float tMax, u
     p.alloc(3 * numRays);
     nv.alloc(numRays);
     tt.alloc(numRays);
-    hipLaunchKernelGGL(kIntersectRays, dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
+    hipLaunchKernelGGL(intersectRaysKernel(), dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
                        numRays, tMax, tri.ptr, t.ptr, uv.ptr, p.ptr, nv.ptr, tt.ptr, m.counters.ptr);
     RF_HIP(hipGetLastError());
     RF_HIP(hipStreamSynchronize(m.stream));
@@ -4356,7 +1560,7 @@ void Renderer::occludedRays(const float* rays6, uint64_t numRays, float tMax, fl
     DeviceBuffer<float> rays, vis;
     rays.upload(rays6, 6 * numRays);
     vis.alloc(numRays);
-    hipLaunchKernelGGL(kOccludedRays, dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
+    hipLaunchKernelGGL(occludedRaysKernel(), dim3(static_cast<uint32_t>((numRays + kBlock - 1) / kBlock)), dim3(kBlock), 0, m.stream, m.scene, rays.ptr,
                        numRays, tMax, vis.ptr, m.counters.ptr);
     RF_HIP(hipGetLastError());
     RF_HIP(hipStreamSynchronize(m.stream));
@@ -4700,3 +1904,4 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
     return flags;
 }
 } // namespace rf
+
