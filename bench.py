@@ -851,7 +851,8 @@ def main():
             out["bvh_build"] = {"triangles": int(len(tris)), "nodes": int(len(host_nodes)), "host_ms_1_thread": round(host_ms, 2),
                                 "gpu_ms": round(float(gpu_ms), 3), "node_bytes_identical": bool(host_nodes.tobytes() == gpu_nodes.tobytes()),
                                 "triangle_order_identical": bool(np.array_equal(host_idx, gpu_idx))}
-        if world == 1 and not multi and not args.no_regimes and not scene_path and max(args.scene_scale, 1) == 1 and args.scene_detail == "plain":
+        if (world == 1 and not multi and not args.no_regimes and not scene_path and max(args.scene_scale, 1) == 1 and args.scene_detail == "plain"
+                and (W, H, B) == (1920, 1080, 8)):      # (the headline workload only: config 3's frame on the plain atrium)
             # (the headline's renderer is done: its 90 GB of path state go back before the others allocate theirs)
             r.close()
             try:

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-4}; WARMUP=${WARMUP:-2}
 # BENCH_ARGS: extra bench.py arguments (e.g. "--scene-scale 8 --spp-per-step 8"); CALIB_FROM: a committed profile directory whose
 # calibration files are reused instead of re-running the microbenchmark (same chip, same rocprofv3)
-BENCH="python $REPO/bench.py --steps $STEPS --warmup $WARMUP --repeat 1 --no-cpu-baseline --no-counting --no-live-counters ${BENCH_ARGS:-}"   # (--repeat 1: the counters are divided by the rays of ONE timed region + warm-up)
+BENCH="python $REPO/bench.py --steps $STEPS --warmup $WARMUP --repeat 1 --no-cpu-baseline --no-counting --no-live-counters --no-regimes ${BENCH_ARGS:-}"   # (--repeat 1: the counters are divided by the rays of ONE timed region + warm-up)
 CALIB=$REPO/tools/microbench/fetch_calib
 [ -x $CALIB ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $CALIB $REPO/tools/microbench/fetch_calib.hip
 VCALIB=$REPO/tools/microbench/valu_calib
