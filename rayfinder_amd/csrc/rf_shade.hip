@@ -102,15 +102,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     __shared__ uint32_t sHist[SORTED ? kSortBins : 1], sStart[SORTED ? kSortBins : 1], sPerm[SORTED ? kItems * kBlock : 1];
     __shared__ float    sLut[256];
     constexpr uint32_t  kTile = kItems * kBlock;
-#if defined(RF_EXP_SHADE_LDS10)
-    constexpr uint32_t  kStaged = 10; // experiment build: rounds 3-4's staging ({triangle, u, v} and the slot as well: 47 KB of LDS, three workgroups per CU)
-#else
-    constexpr uint32_t  kStaged = 6;
-#endif
-    // SORTED: throughput and blue-noise triple of the tile's hits, [component][entry of the tile], staged in input order by pass 1 for pass 2 (which works in sorted
-    // order).  {triangle, u, v} and the slot are NOT staged any more (round 5): pass 2 reads them again from the tile's own 16 KB + 4 KB of the hit stream and the queue
-    // (L1 / L2 hits), which brings the workgroup from 47 to 31 KB of LDS -- four workgroups per CU instead of three on a kernel that spends 3/4 of its wave-cycles waiting
-    __shared__ float    sIn[SORTED ? kStaged * kTile : 1];
+    __shared__ float    sIn[SORTED ? 10 * kTile : 1]; // SORTED: throughput, blue-noise triple, {triangle, u, v} and slot of the tile's hits, [component][entry of the tile]
     const uint32_t      count = *queueCount;
     // grid-stride over tiles of kItems * kBlock queue entries: the grid is capped (kShadeMaxBlocks), so late bounces, whose
     // queues hold a sixth of the paths, do not pay for hundreds of thousands of empty workgroups
@@ -152,11 +144,8 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
                 const Vec3     t = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3nt(ps.thr + i), z = load3nt(ps.noise + i);
                 sIn[l] = t.x, sIn[kTile + l] = t.y, sIn[2 * kTile + l] = t.z;
                 sIn[3 * kTile + l] = z.x, sIn[4 * kTile + l] = z.y, sIn[5 * kTile + l] = z.z;
-                if constexpr (kStaged == 10)
-                {
-                    sIn[(kStaged - 4) * kTile + l] = hitRec.x, sIn[(kStaged - 3) * kTile + l] = hitRec.y, sIn[(kStaged - 2) * kTile + l] = hitRec.z;
-                    sIn[(kStaged - 1) * kTile + l] = __uint_as_float(slots[k]);
-                }
+                sIn[6 * kTile + l] = hitRec.x, sIn[7 * kTile + l] = hitRec.y, sIn[8 * kTile + l] = hitRec.z;
+                sIn[9 * kTile + l] = __uint_as_float(slots[k]);
             }
         }
     }
@@ -213,8 +202,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             if (!isHit[k]) continue;
             const uint32_t local = sPerm[p];
             hitTri[k] = local; // (reused: which entry of the tile)
-            if constexpr (kStaged == 10) slots[k] = __float_as_uint(sIn[9 * kTile + local]);
-            else slots[k] = queue[(tile * kItems + local / kBlock) * kBlock + (local % kBlock)];
+            slots[k] = __float_as_uint(sIn[9 * kTile + local]);
             hitQueue[outPos[k]] = slots[k];
         }
         __syncthreads(); // LDS is reused by the miss append and the next tile
@@ -235,11 +223,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     if constexpr (kPipelined)
     {
 #pragma unroll
-        for (int k = 0; k < kItems; ++k)
-        {
-            if constexpr (kStaged == 10) hits[k] = isHit[k] ? vec3(sIn[6 * kTile + hitTri[k]], sIn[7 * kTile + hitTri[k]], sIn[8 * kTile + hitTri[k]]) : Vec3{};
-            else hits[k] = isHit[k] ? load3(ps.hit + entryIndex(k)) : Vec3{};
-        }
+        for (int k = 0; k < kItems; ++k) hits[k] = isHit[k] ? vec3(sIn[6 * kTile + hitTri[k]], sIn[7 * kTile + hitTri[k]], sIn[8 * kTile + hitTri[k]]) : Vec3{};
     }
     // everything this stage needs of the triangle sits in ONE 128-byte record (positions + packed attributes): one L2 line
     // per shaded hit instead of a triangle line and an attribute line (kShade 56.1 -> 53.0 ms per 128 spp)
