@@ -145,6 +145,7 @@ struct FrameParams
     const uint32_t* samplePerm;
     const uint32_t* sampleInvPerm;
     uint32_t tilesX;
+    uint32_t skipOrigins; // a pinhole camera whose primary launch takes the origin as a constant (kFlagConstOrigin): kRaygen leaves ps.rayO alone
 };
 
 constexpr uint32_t kSlotSampleMajor = 31u;
@@ -327,6 +328,7 @@ constexpr uint32_t kFlagFirstBounce = 2u;         // any-hit: radiance so far is
 constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first visits the leaves that stopped the last rays from its cell of the scene (see kTraceWide)
 constexpr uint32_t kFlagOccluderNoTry = 32u;      // ... the launch runs behind kShadowFirstLook: its rays have had their first look, it only records what stopped them
 constexpr uint32_t kFlagNoRayCount = 64u;
+constexpr uint32_t kFlagConstOrigin = 128u;      // closest-hit, bounce 1: every ray starts at WideScene::constOrigin (a pinhole camera: kRaygen does not write the origins, the refill does not read them)
 constexpr uint32_t kFlagDenseLeafShift = 8u;       // bits 11..8: leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (0: never; see kTraceWide)         // the launch's rays are counted elsewhere (kShadowFirstLook counted the whole queue)
 #if defined(RF_EXP_OCC_SLOTS)
 constexpr int kOccSlots = RF_EXP_OCC_SLOTS;

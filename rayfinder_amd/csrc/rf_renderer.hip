@@ -210,6 +210,7 @@ struct Renderer::Impl
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
+    bool     optConstPrimaryOrigin = true; // a pinhole camera's primary launch takes its one origin as a kernel argument (kFlagConstOrigin): kRaygen writes no origins
     bool                   optSampleSort = true, optAccumulateRuns = true;
     uint32_t               optCompactFromBounce = 3;       // closest-hit launches of bounce >= this use the compact-capable records (0: never)
     uint32_t               optCompactShadowFromBounce = 2; // ... and the shadow launches of bounce >= this
@@ -592,6 +593,16 @@ struct Renderer::Impl
         }
         fp.tilesX = (params.width + kTileSize - 1) / kTileSize;
         if (fp.numTiles == 0) return;
+        // Pinhole camera (lensRadius == 0): kRaygen's origin = camera.origin + (0 * right + 0 * up) is camera.origin itself for every path, bit for bit, as long as no
+        // component of camera.origin is a zero (whose sign the +-0 addend could flip) and right / up are finite (0 * inf = NaN).  The primary launch then takes it as a kernel
+        // argument and kRaygen writes 28 instead of 40 bytes per path.  Only the wide traversal kernels know the flag (the scalar kernels read ps.rayO).
+        const auto finite3 = [](Vec3 v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); };
+        const Camera& camNow = params.camera;
+        const int     primaryLayout = closestLayoutFor(1);
+        const bool    constOrigin = optConstPrimaryOrigin && camNow.lensRadius == 0.0f && camNow.origin.x != 0.0f && camNow.origin.y != 0.0f && camNow.origin.z != 0.0f &&
+                                 finite3(camNow.origin) && finite3(camNow.right) && finite3(camNow.up) && primaryLayout != kLayoutScalar && primaryLayout != kLayoutPacket;
+        fp.skipOrigins = constOrigin ? 1u : 0u;
+        wide.constOriginX = camNow.origin.x, wide.constOriginY = camNow.origin.y, wide.constOriginZ = camNow.origin.z;
 
         const uint64_t paths = static_cast<uint64_t>(numSamples) * fp.pixelsPadded;
         const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
@@ -684,7 +695,7 @@ struct Renderer::Impl
 #endif
                 else
                     launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds},
-                                      uniformFlag);
+                                      uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u));
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
             launchTimed(2, [&] {
@@ -1365,6 +1376,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "hot_shadow_from_bounce") mImpl->optHotShadowFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "packet_bounces") mImpl->optPacketBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
+    else if (name == "const_primary_origin") mImpl->optConstPrimaryOrigin = value != 0;
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;

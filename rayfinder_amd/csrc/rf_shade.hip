@@ -72,7 +72,8 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
 
         // throughput = 1 and radiance = 0 (wgsl:183-184) are not stored: bounce 1 knows them (kFlagFirstBounce, kSky's
         // first-bounce flag), which saves 32 of the 80 bytes a path costs here and the reads back
-        store3(ps.rayO + pos[k], origin);
+        // (non-temporal stores measured neutral here: the kernel is bound by its f64 sin / cos and the normalisation, not by its 28 - 40 bytes per path: profiles/r05_raygen)
+        if (!fp.skipOrigins) store3(ps.rayO + pos[k], origin);
         store3(ps.rayD + pos[k], dir);
         store3(ps.noise + pos[k], vec3(nx, cosPhi, sinPhi));
     }

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // the NEE term this ray decides about: read with the rest of the ray (consecutive queue positions: coalesced) instead of
                 // at write-back, where every finishing lane gathered its own 12 bytes and the wave waited for them
                 if (ANY_HIT) pendingTerm = load3s(ps.pending + resultIndex);
-                const Vec3 o = load3s(ps.rayO + resultIndex);
+                // (a pinhole camera's primary rays: one origin, a kernel argument -- 12 of the 40 bytes a path costs kRaygen, and the read back here)
+                const Vec3 o = (!ANY_HIT && (flags & kFlagConstOrigin) != 0u) ? vec3(wide.constOriginX, wide.constOriginY, wide.constOriginZ) : load3s(ps.rayO + resultIndex);
                 Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
                 {

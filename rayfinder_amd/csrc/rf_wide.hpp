@@ -92,6 +92,8 @@ struct WideScene
     // any-hit launches behind kShadowFirstLook: the queue POSITIONS of the rays still to trace (bit 31: the ray has tried its cell's leaves), or nullptr = every
     // position of the queue; the launch's count argument is then the length of this list
     const uint32_t* rayList;
+    // closest-hit launch of bounce 1 under a pinhole camera (kFlagConstOrigin): the one origin of all its rays
+    float constOriginX, constOriginY, constOriginZ;
 };
 
 struct WideBuild

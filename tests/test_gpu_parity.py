@@ -466,6 +466,28 @@ def test_occluder_cache_is_invisible(atrium, duck_pt):
             r.close()
 
 
+def test_pinhole_primary_origin_as_a_kernel_argument_is_invisible(duck_pt, duck_oracle):
+    """A pinhole camera's primary rays all start at camera.origin: kRaygen then writes no origins and the bounce-1 closest-hit launch takes the point as a kernel
+    argument (kFlagConstOrigin).  Same image bit for bit with the option off; a camera with a lens, and a pinhole whose origin has a component that is exactly zero
+    (a +-0 the lens term could flip), keep the stream -- and all of them equal the oracle."""
+    W, H, spp, bounces = 160, 120, 4, 3
+    sky = rf.make_sky()
+    cams = {"pinhole": rf.fly_camera(W, H),
+            "pinhole, origin.x == 0": rf.fly_camera(W, H, position=(0.0, 1.25, -1.25)),
+            "lens": rf.fly_camera(W, H, aperture=0.05, focus_distance=2.0)}
+    for name, cam in cams.items():
+        imgs = []
+        for opt in (1, 0):
+            r, params = _renderer(duck_pt, W, H, spp, bounces, cam=cam)
+            r.set_option("const_primary_origin", opt)
+            r.render(spp)
+            imgs.append(r.read_accumulation()[0])
+            r.close()
+        assert np.array_equal(bits(imgs[0]), bits(imgs[1])), name
+        want, _ = orc.render(duck_oracle.scene, orc.make_render_params(W, H, rf.camera_to_array(cam), spp, bounces, 0.25, rf.aligned_sky_state(sky)), 0, spp)
+        assert np.array_equal(bits(imgs[0][..., :3]), bits(want[..., :3])), name
+
+
 def test_occluder_cache_engages_on_the_atrium(atrium):
     """The cache is not silently off: on the second batch of a handle (warm grid) kShadowFirstLook settles most of the shadow rays of bounces >= 2, the shadow
     launches take clearly less time than with the cache off, and the per-bounce ray counts do not change (every shadow ray is still counted)."""
