@@ -125,6 +125,10 @@ typedef struct rf_stats
      * from the same cell of the scene, tested with the reference's box and triangle arithmetic) and that therefore never entered the BVH walk.
      * Same visibility bit; reported so that a rays-per-second figure can be read with and without them. */
     uint64_t shadow_rays_hint_answered;
+    /* Of shadow_rays: rays stopped by the very triangle they start on -- the reference pushes the hit point off the surface along the GEOMETRIC normal whatever side the
+     * path came from (wgsl:511-519), so wherever the sun stands behind that normal shadowRay (wgsl:321-368) finds the surface itself.  The shading stage tests exactly that
+     * (the leaf's exact box, then the triangle, with the reference's arithmetic) and such a ray is never queued for an any-hit launch.  Same visibility bit. */
+    uint64_t shadow_rays_self_answered;
 } rf_stats;
 
 typedef struct rf_renderer rf_renderer;

@@ -78,7 +78,7 @@ class Stats(C.Structure):
                 ("launches_raygen", C.c_uint32), ("launches_closest", C.c_uint32), ("launches_shade", C.c_uint32),
                 ("launches_shadow", C.c_uint32), ("launches_accumulate", C.c_uint32), ("reserved2", C.c_uint32),
                 ("closest_record_fetches", C.c_uint64), ("shadow_record_fetches", C.c_uint64),
-                ("abandoned_rays", C.c_uint64), ("scalar_redo_rays", C.c_uint64), ("shadow_rays_hint_answered", C.c_uint64)]
+                ("abandoned_rays", C.c_uint64), ("scalar_redo_rays", C.c_uint64), ("shadow_rays_hint_answered", C.c_uint64), ("shadow_rays_self_answered", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}

@@ -323,6 +323,7 @@ int rf_renderer_get_stats(rf_renderer* r, rf_stats* out)
         out->abandoned_rays = s.abandonedRays;
         out->scalar_redo_rays = s.scalarRedoRays;
         out->shadow_rays_hint_answered = s.shadowRaysHintAnswered;
+        out->shadow_rays_self_answered = s.shadowRaysSelfAnswered;
         return RF_OK;
     });
 }

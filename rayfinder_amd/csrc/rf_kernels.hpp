@@ -299,6 +299,10 @@ __device__ __forceinline__ Vec3 sunSample(const SkyStateGpu& sky, const SunBasis
 }
 
 constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
+// kShadeSelfShadow: kShade tests every hit's shadow ray against the hit triangle ITSELF (its leaf's exact box, then the triangle: both sit in the shading record it has in
+// registers) and writes the positions of the hits that this does not settle to `shadowList`; the bounce's any-hit launches work through that list only (see kShade)
+constexpr uint32_t kShadeSelfShadow = 4u;
+constexpr uint32_t kLookFirstBounce = 1u, kLookNoRayCount = 2u; // kShadowFirstLook's flags
 
 
 constexpr uint32_t kSortBins = 256; // kShade<SORTED>: triangle ranges of its counting sort (the host derives sortScale from it)
@@ -347,14 +351,14 @@ constexpr uint32_t kNodeDone = 0xFFFFFFFEu; // ray finished, result not yet writ
 using SamplePermutationKernel = void (*)(uint32_t firstFrame, uint32_t spp, uint32_t numSamples, uint32_t* perm, uint32_t* inv);
 using RaygenKernel = void (*)(FrameParams fp, DeviceScene scene, const uint32_t* tileIds, PathStreams ps, uint32_t* queue, uint32_t* queueCount, DeviceCounters* counters);
 using TraceClosestKernel = void (*)(DeviceScene scene, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, DeviceCounters* counters);
-using ShadeKernel = void (*)(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue, uint32_t* missCount, uint32_t bounceFlags, uint32_t sortScale);
+using ShadeKernel = void (*)(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue, uint32_t* missCount, uint32_t* shadowList, uint32_t* shadowListCount, uint32_t bounceFlags, uint32_t sortScale);
 using SkyKernel = void (*)(SkyStateGpu sky, PathStreams ps, const uint32_t* queue, const uint32_t* missQueue, const uint32_t* missCount, uint32_t firstBounce);
 using TraceShadowKernel = void (*)(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, DeviceCounters* counters, uint32_t firstBounce);
 using TraceWideKernel = void (*)(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote, uint32_t chunkMax, float tMax, uint32_t flags);
-using ShadowFirstLookKernel = void (*)(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax, uint32_t firstBounce);
+using ShadowFirstLookKernel = void (*)(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* inList, const uint32_t* inCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax, uint32_t flags);
 using TracePacketKernel = void (*)(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, DeviceCounters* counters, float tMax, uint32_t flags);
 using HitPointsKernel = void (*)(DeviceScene scene, const float4* hit, P3* rayO, uint32_t n);
-using BounceTotalsKernel = void (*)(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals, const uint32_t* listCounts, unsigned long long lookMask, unsigned long long* lookBatch);
+using BounceTotalsKernel = void (*)(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals, const uint32_t* listCounts, unsigned long long lookMask, unsigned long long* lookBatch, const uint32_t* shadowListCounts, unsigned long long selfMask, DeviceCounters* counters);
 using AccumulateKernel = void (*)(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image);
 using AccumulateRunsKernel = void (*)(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image);
 using TonemapKernel = void (*)(const float4* image, uint32_t n, uint32_t accumulatedSamples, float exposure, uint32_t* out);

@@ -164,9 +164,9 @@ struct Renderer::Impl
     uint64_t                maxPaths = 0;
     DeviceBuffer<P3>        sRayO, sRayD, sRayD2, sThr, sThr2, sPending, sNoise, sNoise2; // queue-position arrays, packed xyz; rayD / thr / noise: double-buffered (PathStreams)
     DeviceBuffer<float4>    sRad, sHit;
-    DeviceBuffer<uint32_t>  queueA, queueB, missQueue, queueCounts;
+    DeviceBuffer<uint32_t>  queueA, queueB, missQueue, shadowList, queueCounts; // shadowList: kShade's list of the shadow rays its own-triangle test has not settled (kShadeSelfShadow)
     DeviceBuffer<DeviceCounters> counters;
-    DeviceBuffer<unsigned long long> bounceTotals; // 3 x kMaxBounceStats: closest-hit rays, shadow rays, shadow rays answered by kShadowFirstLook
+    DeviceBuffer<unsigned long long> bounceTotals; // 4 x kMaxBounceStats: closest-hit rays, shadow rays, shadow rays answered by kShadowFirstLook, shadow rays settled by kShade's own-triangle test
 
     // deferred-lighting variant: its own frame counter and buffers (array<array<f32, 3>>)
     uint32_t               deferredFrameCount = 0;
@@ -210,6 +210,8 @@ struct Renderer::Impl
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
+    bool     optShadowSelfTest = true; // kShade tests every shadow ray against the triangle it starts on first (kShadeSelfShadow); needs selfShadowOk
+    bool     selfShadowOk = false;     // the tree's boxes are nested and regular, and the shading records carry their triangles' leaf boxes
     bool     optConstPrimaryOrigin = true; // a pinhole camera's primary launch takes its one origin as a kernel argument (kFlagConstOrigin): kRaygen writes no origins
     bool                   optSampleSort = true, optAccumulateRuns = true;
     uint32_t               optCompactFromBounce = 3;       // closest-hit launches of bounce >= this use the compact-capable records (0: never)
@@ -265,12 +267,12 @@ struct Renderer::Impl
     uint64_t effectivePaths = 0;       // batch depth the last render() call ended up with (<= maxPaths: less when less memory was free THEN)
 
     // bytes of path state + queues per path slot (eight packed xyz streams, two float4 streams, three u32 queues)
-    static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 3 * sizeof(uint32_t);
+    static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 4 * sizeof(uint32_t);
 
     void releasePathState()
     {
         sRayO.release(), sRayD.release(), sRayD2.release(), sThr.release(), sThr2.release(), sRad.release(), sHit.release();
-        sPending.release(), sNoise.release(), sNoise2.release(), queueA.release(), queueB.release(), missQueue.release();
+        sPending.release(), sNoise.release(), sNoise2.release(), queueA.release(), queueB.release(), missQueue.release(), shadowList.release();
         allocatedPaths = 0;
     }
 
@@ -298,7 +300,7 @@ struct Renderer::Impl
         };
         const bool ok = tryAlloc(sRayO, paths) && tryAlloc(sRayD, paths) && tryAlloc(sRayD2, paths) && tryAlloc(sThr, paths) && tryAlloc(sThr2, paths) &&
                         tryAlloc(sRad, paths) && tryAlloc(sHit, paths) && tryAlloc(sPending, paths) && tryAlloc(sNoise, paths) && tryAlloc(sNoise2, paths) &&
-                        tryAlloc(queueA, paths) && tryAlloc(queueB, paths) && tryAlloc(missQueue, paths);
+                        tryAlloc(queueA, paths) && tryAlloc(queueB, paths) && tryAlloc(missQueue, paths) && tryAlloc(shadowList, paths);
         if (!ok)
         {
             releasePathState();
@@ -646,12 +648,13 @@ struct Renderer::Impl
         // device words, one per 64-byte line (they are all hot atomics): [0, B]: queue lengths per
         // bounce; [B+1, 2B]: miss-list length per bounce; then two work cursors per bounce for the traversal launches
         constexpr uint32_t kLine = kLineWords;
-        const uint32_t words = kLine * (2 * numBounces + 1) + kLine * kShards * 2 * numBounces + kLine * numBounces;
+        const uint32_t words = kLine * (2 * numBounces + 1) + kLine * kShards * 2 * numBounces + kLine * numBounces + kLine * numBounces;
         if (queueCounts.count < words) queueCounts.alloc(words);
         uint32_t* const missCounts = queueCounts.ptr + kLine * (numBounces + 1);
         uint32_t* const cursors = queueCounts.ptr + kLine * (2 * numBounces + 1);
         uint32_t* const listCounts = cursors + kLine * kShards * 2 * numBounces; // lengths of the lists kShadowFirstLook leaves to the any-hit launches, per bounce
-        unsigned long long lookMask = 0ull;
+        uint32_t* const shadowListCounts = listCounts + kLine * numBounces; // lengths of kShade's lists of shadow rays still to trace (kShadeSelfShadow), per bounce
+        unsigned long long lookMask = 0ull, selfMask = 0ull;
         const uint32_t  itemBlocks = static_cast<uint32_t>((paths + kBlock * kItems - 1) / (kBlock * kItems));
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
 
@@ -698,35 +701,42 @@ struct Renderer::Impl
                                       uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u));
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
+            // kShade's own-triangle test of the shadow rays (kShadeSelfShadow): wherever this bounce's any-hit launch is one that can work through a list of queue positions
+            // (the kTraceWide instantiations with the occluder-cache code: quad / half / local-grid records) and nothing has to be counted node by node
+            const int      layoutShadow = shadowLayoutFor(bounce);
+            const bool     selfShadow = optShadowSelfTest && selfShadowOk && !counting && (layoutShadow == kLayoutQuad || layoutShadow == kLayoutQuadHalf || layoutShadow == kLayoutQuadLocal);
+            uint32_t* const shadowListCount = shadowListCounts + kLine * (bounce - 1);
+            if (selfShadow) selfMask |= 1ull << (bounce - 1);
             launchTimed(2, [&] {
-                const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u);
+                const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u) | (selfShadow ? kShadeSelfShadow : 0u);
                 const dim3     shadeGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
                 if (optShadeSortFromBounce != 0u && bounce >= optShadeSortFromBounce)
-                    hipLaunchKernelGGL(shadeKernel(true), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, sortScale);
+                    hipLaunchKernelGGL(shadeKernel(true), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, sortScale);
                 else
-                    hipLaunchKernelGGL(shadeKernel(false), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadeFlags, 0u);
+                    hipLaunchKernelGGL(shadeKernel(false), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, 0u);
                 // the paths that left the scene at this bounce, while its direction / throughput arrays and queue are intact
                 hipLaunchKernelGGL(skyKernel(), dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, qIn, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
             });
             // occluder cache (kTraceWide, kFlagOccluderCache): the conservative-record any-hit launches of bounces 1..optOccluderCacheBounces; their rays are
             // short (a third of the steps), so the deep launches refill earlier
-            const int      layoutShadow = shadowLayoutFor(bounce);
             const bool     cachedShadow = layoutShadow != kLayoutScalar && layoutShadow != kLayoutPacket && cachedShadowFor(bounce);
             // ... behind kShadowFirstLook (see there) from the second batch on: the first batch of a renderer fills the grid (the traversal kernel's own first look serves)
             const bool      firstLook = cachedShadow && occluderHintLevels == 0u && optShadowFirstLookFromBounce != 0u && bounce >= optShadowFirstLookFromBounce && bounce <= 64u && occluderGridWarm && firstLookHoldOff == 0u;
             uint32_t* const listCount = listCounts + kLine * (bounce - 1);
-            uint32_t* const countShadow = firstLook ? listCount : countOut;
+            uint32_t* const countShadow = firstLook ? listCount : (selfShadow ? shadowListCount : countOut);
             if (firstLook) lookMask |= 1ull << (bounce - 1);
-            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (cachedShadow ? kFlagOccluderCache : 0u) | (firstLook ? (kFlagOccluderNoTry | kFlagNoRayCount) : 0u);
+            const uint32_t shadowFlags = (bounce == 1 ? kFlagFirstBounce : 0u) | uniformFlag | (cachedShadow ? kFlagOccluderCache : 0u) | (firstLook ? (kFlagOccluderNoTry | kFlagNoRayCount) : 0u) | (selfShadow ? kFlagNoRayCount : 0u);
             launchTimed(3, [&] {
                 WideScene wide = this->wide; // (the launches below name `wide`)
                 if (firstLook)
                 {
                     // (the bounce's input queue is free by now -- kShade and kSky have consumed it -- and holds the list)
                     const dim3 lookGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
-                    hipLaunchKernelGGL(shadowFirstLookKernel(), lookGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, countOut, qIn, listCount, counters.ptr, kTMax, bounce == 1 ? 1u : 0u);
+                    hipLaunchKernelGGL(shadowFirstLookKernel(), lookGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qOut, selfShadow ? shadowList.ptr : nullptr,
+                                       selfShadow ? shadowListCount : countOut, qIn, listCount, counters.ptr, kTMax, (bounce == 1 ? kLookFirstBounce : 0u) | (selfShadow ? kLookNoRayCount : 0u));
                     wide.rayList = qIn;
                 }
+                else if (selfShadow) wide.rayList = shadowList.ptr; // (positions only: bit 31 clear, the traversal kernel takes its own first look)
                 if (layoutShadow == kLayoutScalar)
                 {
                     if (counting)
@@ -752,7 +762,7 @@ struct Renderer::Impl
             std::swap(ps.thr, ps.thrOut);
             std::swap(ps.noise, ps.noiseOut);
         }
-        hipLaunchKernelGGL(bounceTotalsKernel(), dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr, listCounts, lookMask, lookBatch.ptr);
+        hipLaunchKernelGGL(bounceTotalsKernel(), dim3(1), dim3(64), 0, stream, queueCounts.ptr, std::min(numBounces, 64u), bounceTotals.ptr, listCounts, lookMask, lookBatch.ptr, shadowListCounts, selfMask, counters.ptr);
         if (lookMask != 0ull && lookBatchHost != nullptr)
         {
             RF_HIP(hipMemcpyAsync(lookBatchHost, lookBatch.ptr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -793,6 +803,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.sortScale = static_cast<uint32_t>(std::min<uint64_t>((static_cast<uint64_t>(kSortBins) << 32) / std::max<uint64_t>(sceneView.positionAttributes.size(), 1), 0xFFFFFFFFull));
 
     // 48-B reference nodes -> 32-B device nodes
+    bool                  treeNestedRegular = false; // every child's box inside its parent's, all finite and ordered (buildWide)
     std::vector<uint32_t> quadIndexOfNode; // buildWide's numbering of the quad records, for the occluder-cache entries of the leaves (leafBoxesIntoTriangles)
     {
         std::vector<float4> packed(2 * sceneView.bvhNodes.size());
@@ -810,6 +821,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         m.nodes.upload(packed.data(), packed.size());
         const WideBuild wb = buildWide(sceneView.bvhNodes.data(), sceneView.bvhNodes.size());
         quadIndexOfNode = wb.quadIndexOfNode;
+        treeNestedRegular = wb.boxesNested && wb.boxesRegular;
         m.wideNodes.upload(wb.nodes.data(), wb.nodes.size());
         m.bigLeaves.upload(wb.bigLeaves.data(), wb.bigLeaves.size());
         m.wide.nodes = m.wideNodes.ptr;
@@ -950,6 +962,26 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
             rec[8 * i + 2] = make_float4(t.p2.x, t.p2.y, t.p2.z, 0.0f);
             for (int k = 0; k < 4; ++k) rec[8 * i + 3 + k] = packed[4 * i + k];
         }
+        // kShadeSelfShadow: the exact box of the leaf a triangle sits in, in the spare floats of its record ({p0 lo.x} {p1 lo.y} {p2 lo.z} ... {hi.xyz, 1}).  Only where the
+        // argument holds (kShade): boxes nested and regular all the way up (buildWide checked every parent / child pair), and the triangle in exactly ONE leaf.
+        m.selfShadowOk = treeNestedRegular;
+        if (m.selfShadowOk)
+        {
+            std::vector<uint8_t> leaves(n, 0);
+            for (const BvhNode& nd : sceneView.bvhNodes)
+                for (uint32_t t = 0; t < nd.triangleCount; ++t)
+                {
+                    const size_t i = static_cast<size_t>(nd.trianglesOffset) + t;
+                    if (i >= n) continue; // (validateScene has rejected this)
+                    const bool regular = std::fabs(nd.aabb.min.x) < 1e30f && std::fabs(nd.aabb.min.y) < 1e30f && std::fabs(nd.aabb.min.z) < 1e30f && std::fabs(nd.aabb.max.x) < 1e30f &&
+                                         std::fabs(nd.aabb.max.y) < 1e30f && std::fabs(nd.aabb.max.z) < 1e30f && nd.aabb.min.x <= nd.aabb.max.x && nd.aabb.min.y <= nd.aabb.max.y &&
+                                         nd.aabb.min.z <= nd.aabb.max.z;
+                    leaves[i] = static_cast<uint8_t>(std::min(leaves[i] + (regular ? 1 : 2), 2));
+                    rec[8 * i].w = nd.aabb.min.x, rec[8 * i + 1].w = nd.aabb.min.y, rec[8 * i + 2].w = nd.aabb.min.z;
+                    rec[8 * i + 7] = make_float4(nd.aabb.max.x, nd.aabb.max.y, nd.aabb.max.z, 0.0f);
+                }
+            for (size_t i = 0; i < n; ++i) rec[8 * i + 7].w = leaves[i] == 1 ? 1.0f : 0.0f;
+        }
         m.shadeRecords.upload(rec.data(), rec.size());
     }
 
@@ -992,7 +1024,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     DeviceCounters zero{};
     m.counters.upload(&zero, 1);
     {
-        const std::vector<unsigned long long> z(3 * RenderStats::kMaxBounceStats, 0ull);
+        const std::vector<unsigned long long> z(4 * RenderStats::kMaxBounceStats, 0ull);
         m.bounceTotals.upload(z.data(), z.size());
     }
     {
@@ -1377,6 +1409,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "packet_bounces") mImpl->optPacketBounces = static_cast<uint32_t>(std::max<int64_t>(value, 0));
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
     else if (name == "const_primary_origin") mImpl->optConstPrimaryOrigin = value != 0;
+    else if (name == "shadow_self_test") mImpl->optShadowSelfTest = value != 0;
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;
@@ -1420,7 +1453,7 @@ void Renderer::resetStats()
     m.collectTimings();
     DeviceCounters zero{};
     RF_HIP(hipMemcpy(m.counters.ptr, &zero, sizeof zero, hipMemcpyHostToDevice));
-    RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 3 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
+    RF_HIP(hipMemset(m.bounceTotals.ptr, 0, 4 * RenderStats::kMaxBounceStats * sizeof(unsigned long long)));
     m.hostStats = RenderStats{};
     m.primaryRaysHost = 0;
 }
@@ -1478,13 +1511,14 @@ RenderStats Renderer::stats()
                          steps / (64.0 * c.descendTrips[k]), tris / (64.0 * c.leafTrips[k]));
         }
     }
-    unsigned long long totals[3 * RenderStats::kMaxBounceStats];
+    unsigned long long totals[4 * RenderStats::kMaxBounceStats];
     RF_HIP(hipMemcpy(totals, m.bounceTotals.ptr, sizeof totals, hipMemcpyDeviceToHost));
     for (uint32_t b = 0; b < RenderStats::kMaxBounceStats; ++b)
     {
         s.closestRaysByBounce[b] = totals[b];
         s.shadowRaysByBounce[b] = totals[RenderStats::kMaxBounceStats + b];
         s.shadowRaysHintAnswered += totals[2 * RenderStats::kMaxBounceStats + b];
+        s.shadowRaysSelfAnswered += totals[3 * RenderStats::kMaxBounceStats + b];
     }
     return s;
 }

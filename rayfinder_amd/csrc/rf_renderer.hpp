@@ -76,6 +76,7 @@ struct RenderStats
     uint64_t closestRecordFetches = 0, shadowRecordFetches = 0; // 64-B BVH records fetched (counting build)
     uint64_t abandonedRays = 0;  // rays whose traversal stack outgrew 96 entries (reference: undefined past 32); every build
     uint64_t scalarRedoRays = 0; // rays redone by the reference-ordered scalar traversal (irregular rays, LDS stack overflow); every build
+    uint64_t shadowRaysSelfAnswered = 0; // of shadowRays: stopped by the triangle they start on, found by kShade's own test (kShadeSelfShadow); never queued for an any-hit launch
     uint64_t shadowRaysHintAnswered = 0; // of shadowRays: answered by kShadowHint at the leaf the occluder grid named (never entered the traversal); every build
     // hipEvent-timed kernel time (ms) and launch counts, per kernel class, while timing is enabled
     double   msRaygen = 0, msClosest = 0, msShade = 0, msShadow = 0, msAccumulate = 0;

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
 template<bool SORTED>
 __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
                                                   const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
-                                                  uint32_t* missCount, uint32_t bounceFlags, uint32_t sortScale)
+                                                  uint32_t* missCount, uint32_t* shadowList, uint32_t* shadowListCount, uint32_t bounceFlags, uint32_t sortScale)
 {
     static_assert(kSortBins == kBlock, "one bin per thread");
     __shared__ uint32_t sScratch[8];
@@ -113,6 +113,19 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     sLut[threadIdx.x] = scene.albedoLut[threadIdx.x];
     __syncthreads();
     const bool isLastBounce = (bounceFlags & kShadeLastBounce) != 0u, isFirstBounce = (bounceFlags & kShadeFirstBounce) != 0u;
+    // ---- The shadow ray's FIRST candidate occluder is the triangle it starts on (round 5).  The reference pushes the hit point off the surface along the GEOMETRIC normal whatever
+    // side the path arrived from (wgsl:511-519), and then asks shadowRay (wgsl:321-368) whether ANY triangle stops the ray towards the sun: wherever the sun stands behind that
+    // normal the ray crosses the plane of its own triangle a hair's breadth from its origin -- inside the triangle -- and the reference reports it occluded (half of all surfaces).
+    // kShade holds everything that test needs in registers: the origin it has just computed, the sun sample, the triangle's positions -- and, in the spare floats of the shading
+    // record, the EXACT box of the triangle's leaf.  kShadeSelfShadow: it applies the leaf's box with the reference's formula, then the reference's triangle test; a ray that this
+    // stops is FINISHED here (its NEE term times 0, exactly as the traversal's write-back adds it), and only the positions of the other hits go onto `shadowList`, which the
+    // bounce's any-hit launches (kShadowFirstLook, kTraceWide) work through instead of the whole queue.
+    // Same visibility bit as the reference's walk, by the argument of the occluder cache (rf_trace.hip): the reference tests this triangle iff its walk reaches the leaf, i.e. iff
+    // the boxes of the leaf and of all its ancestors pass; an ancestor's box contains the leaf's and the slab arithmetic is monotone in the planes, so a ray that passes the leaf's
+    // own test passes every ancestor's: the reference either reaches this leaf -- and finds this triangle, or an earlier one of the leaf -- or has found another occluder before.
+    // Occluded either way.  A ray the test does NOT stop proves nothing and is traced as before.  (Trees whose boxes are not nested, triangles that sit in two leaves or in
+    // none, rays that are not class A: no shortcut -- the record's flag is 0 / the ray goes onto the list.)
+    const bool selfShadow = (bounceFlags & kShadeSelfShadow) != 0u;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
   {
     // Pass 1: which entries hit, which left the scene -> both output queues are appended FIRST, so that every surviving path
@@ -232,6 +245,8 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     {
         Vec3   p0, p1, p2;
         float4 a0, a1, a2, a3; // packed vertex attributes (one 64-byte sector): {n0.xyz n1.x} {n1.yz n2.xy} {n2.z uv0.xy uv1.x} {uv1.y uv2.xy textureIdx}
+        Vec3   boxLo;          // kShadeSelfShadow: the exact box of the triangle's leaf (the .w of the three position float4s) ...
+        float4 boxHi;          // ... {hi.xyz, 1.0f if the box may be used (the triangle sits in exactly one leaf of a tree with nested boxes), else 0}
     };
     const auto fetchRecord = [&](uint32_t tri) {
         ShadeRecord   r;
@@ -239,13 +254,25 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
 #if defined(RF_EXP_SHADE_ABLATE) && RF_EXP_SHADE_ABLATE >= 3
         if constexpr (SORTED) rec = scene.shadeRecords + 8 * static_cast<size_t>(tri & 63u); // ablation (timing only): 64 records, all L1 hits
 #endif
-        r.p0 = load3(rec), r.p1 = load3(rec + 1), r.p2 = load3(rec + 2);
+        if (selfShadow)
+        {
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            r.p0 = vec3(q0.x, q0.y, q0.z), r.p1 = vec3(q1.x, q1.y, q1.z), r.p2 = vec3(q2.x, q2.y, q2.z);
+            r.boxLo = vec3(q0.w, q1.w, q2.w);
+            r.boxHi = rec[7];
+        }
+        else
+        {
+            r.p0 = load3(rec), r.p1 = load3(rec + 1), r.p2 = load3(rec + 2);
+            r.boxLo = Vec3{}, r.boxHi = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
         r.a0 = rec[3], r.a1 = rec[4], r.a2 = rec[5], r.a3 = rec[6];
         return r;
     };
-    const auto shade = [&](int k, float hu, float hv, const ShadeRecord& cur, uint32_t out) {
+    const auto shade = [&](int k, float hu, float hv, const ShadeRecord& cur, uint32_t out) -> bool {
         const uint32_t i = entryIndex(k);
         (void)i;
+        Vec3 shadowOrigin;
         {
             // hit point pushed off the surface along the geometric normal (wgsl:511-519,523-544): origin of
             // the shadow ray and of the next bounce; same arithmetic as the scalar traversal (rf_device.hpp)
@@ -253,6 +280,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             const Vec3 e1 = p1 - p0, e2 = p2 - p0;
             const Vec3 hp = offsetRay(p0 + hu * e1 + hv * e2, normalize(cross(e1, e2)));
             store3nt(ps.rayO + out, hp); // (this bounce's origins have been consumed by the closest-hit launch)
+            shadowOrigin = hp;
         }
         // SORTED: this thread's entry is the tile's `local`-th in input order; its throughput and blue-noise triple were read in input
         // order (coalesced) by pass 1 and wait in LDS -- gathered from memory, the 64 lanes of a wave would touch ~57 different lines of
@@ -289,7 +317,37 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
         const Vec3 brdf = albedo * kFrac1Pi;
         const Vec3 reflectance = brdf * dot(n, lightDirection);
         const Vec3 pend = (throughput * lightIntensity) * reflectance;
-        store3nt(ps.pending + out, pend); // read by the shadow launch at the same queue position
+        bool       settled = false; // kShadeSelfShadow: the shadow ray is stopped by the triangle it starts on
+        if (selfShadow && cur.boxHi.w != 0.0f)
+        {
+            const RayPrep ray = prepareRay(shadowOrigin, lightDirection);
+            if (classifyRay(ray) == kRayPlain)
+            {
+                const PackedRay pr = packRay(ray);
+                float           bn, bf;
+                bool            boxNaN;
+                slabSingleBounds(pr, cur.boxLo.x, cur.boxLo.y, cur.boxLo.z, cur.boxHi.x, cur.boxHi.y, cur.boxHi.z, bn, bf, boxNaN);
+                if (bn <= bf && bf > 0.0f && bn < kTMax) // the reference reaches this leaf (kShadowFirstLook applies the same test to the leaves its cell names)
+                {
+                    TriangleHit th;
+                    settled = intersectTriangle(shadowOrigin, lightDirection, cur.p0, cur.p1, cur.p2, kTMax, th);
+                }
+            }
+        }
+        if (settled)
+        {
+            // the traversal's write-back for an occluded ray (kTraceWide): radiance += (pending * 0) * invPdf -- a sum that keeps its bits unless the product is NaN, or the
+            // sum is not in memory yet (bounce 1)
+            const Vec3 add = (pend * 0.0f) * __uint_as_float(kSolarInvPdfBits);
+            const bool unchanged = !isFirstBounce && add.x == 0.0f && add.y == 0.0f && add.z == 0.0f;
+            if (!unchanged)
+            {
+                const uint32_t slot = slots[k];
+                const Vec3     radiance = (isFirstBounce ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot)) + add;
+                ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            }
+        }
+        else store3nt(ps.pending + out, pend); // read by the shadow launch at the same queue position
 
         if (!isLastBounce)
         {
@@ -303,7 +361,9 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             store3nt(ps.rayDOut + out, wi);
             store3nt(ps.thrOut + out, t2);
         }
+        return !settled;
     };
+    bool needShadow[kItems]; // hits whose shadow ray is still to be traced
     if constexpr (kPipelined)
     {
         const uint32_t tileHits = sortedHits, base = sortedBase;
@@ -315,20 +375,27 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             const uint32_t p = static_cast<uint32_t>(k) * kBlock + threadIdx.x, pNext = p + kBlock; // positions in the tile's sorted order
             ShadeRecord    next{};
             if (k + 1 < kItems && pNext < tileHits) next = fetchRecord(__float_as_uint(hits[k + 1 < kItems ? k + 1 : k].x));
-            if (p < tileHits) shade(k, hits[k].y, hits[k].z, cur, base + p);
+            needShadow[k] = p < tileHits && shade(k, hits[k].y, hits[k].z, cur, base + p);
             cur = next;
         }
     }
     else
     {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) needShadow[k] = false;
 #pragma unroll 1
         for (int k = 0; k < kItems; ++k)
         {
             if (!isHit[k]) continue;
             const Vec3 h = load3(ps.hit + entryIndex(k));
-            shade(k, h.y, h.z, fetchRecord(__float_as_uint(h.x)), outPos[k]);
+            const bool need = shade(k, h.y, h.z, fetchRecord(__float_as_uint(h.x)), outPos[k]);
+            // (k is a run-time index in this loop: the flag goes in through selects, not through an indexed register array)
+#pragma unroll
+            for (int j = 0; j < kItems; ++j) needShadow[j] = j == k ? need : needShadow[j];
         }
     }
+    // the shadow rays that are still to be traced, by position in the next queue (= where kShade has put their origin, NEE term and blue-noise triple)
+    if (selfShadow) blockAppend<kItems>(needShadow, outPos, shadowList, shadowListCount, sScratch);
     if constexpr (SORTED) __syncthreads(); // (a block that takes another tile refills sIn)
   }
 }
@@ -364,16 +431,26 @@ __global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, 
 // Queue occupancy per bounce: Q[b-1] paths enter bounce b (closest-hit rays), Q[b] of them hit
 // something (shadow rays).  Folded into running totals at the end of every batch.
 // `listCounts` / `lookMask`: bounces whose any-hit launch ran behind kShadowFirstLook (bit b) -- Q[b] minus the length of its list is what that kernel answered.
-__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals, const uint32_t* listCounts, unsigned long long lookMask, unsigned long long* lookBatch)
+// `selfMask` (bit b): kShade settled part of that bounce's shadow rays itself (kShadeSelfShadow) and left shadowListCounts[b] to the any-hit launches, which then do not count
+// rays themselves: all Q[b] of them are counted here; totals[3 K + b] = how many kShade settled.
+__global__ void kBounceTotals(const uint32_t* queueCounts, uint32_t numBounces, unsigned long long* totals, const uint32_t* listCounts, unsigned long long lookMask, unsigned long long* lookBatch,
+                              const uint32_t* shadowListCounts, unsigned long long selfMask, DeviceCounters* counters)
 {
     const uint32_t b = threadIdx.x;
     if (b >= numBounces) return;
     const uint32_t k = min(b, RenderStats::kMaxBounceStats - 1);
     atomicAdd(&totals[k], static_cast<unsigned long long>(queueCounts[kLineWords * b]));
     atomicAdd(&totals[RenderStats::kMaxBounceStats + k], static_cast<unsigned long long>(queueCounts[kLineWords * (b + 1)]));
+    const bool self = ((selfMask >> b) & 1ull) != 0ull;
+    if (self)
+    {
+        const unsigned long long rays = queueCounts[kLineWords * (b + 1)];
+        atomicAdd(&totals[3 * RenderStats::kMaxBounceStats + k], rays - shadowListCounts[kLineWords * b]);
+        atomicAdd(&counters->shadowRays, rays);
+    }
     if ((lookMask >> b) & 1ull)
     {
-        const unsigned long long rays = queueCounts[kLineWords * (b + 1)], answered = rays - listCounts[kLineWords * b];
+        const unsigned long long rays = self ? shadowListCounts[kLineWords * b] : queueCounts[kLineWords * (b + 1)], answered = rays - listCounts[kLineWords * b];
         atomicAdd(&totals[2 * RenderStats::kMaxBounceStats + k], answered);
         atomicAdd(&lookBatch[0], answered); // this batch alone: the host decides from it whether the first look pays (Impl::firstLookHoldOff)
         atomicAdd(&lookBatch[1], rays);

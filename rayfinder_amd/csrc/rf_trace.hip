@@ -1424,13 +1424,16 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 // leaf and finds the same triangle, or has found another one before -- occluded either way.  Rays that are not class A (rf_wide.hpp: an
 // infinite 1/direction component, a non-finite origin), big leaves and cells without an entry are simply passed on.
 // ------------------------------------------------------------------------------------------------
+// `inList` (or nullptr = every position of the queue): the queue positions to look at -- what kShade's own-triangle test (kShadeSelfShadow) has not settled; `inCount`: how many.
 __global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
-                                                            const uint32_t* queueCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax, uint32_t firstBounce)
+                                                            const uint32_t* inList, const uint32_t* inCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax,
+                                                            uint32_t flags)
 {
     __shared__ uint32_t sScratch[8];
-    const uint32_t      count = *queueCount;
+    const uint32_t      count = *inCount;
+    const uint32_t      firstBounce = flags & kLookFirstBounce;
     const uint32_t      tiles = (count + kItems * kBlock - 1) / (kItems * kBlock);
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !(flags & kLookNoRayCount)) atomicAdd(&counters->shadowRays, static_cast<unsigned long long>(count));
     // (one entry after the other: staging the kItems entries of a thread -- four cells, then four triangle records in flight per lane -- takes 163
     // registers, three waves per SIMD instead of eight, and measured 17 % slower: profiles/r04_occluder/firstlook2.log)
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
@@ -1440,10 +1443,12 @@ __global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, Wi
 #pragma unroll
         for (int k = 0; k < kItems; ++k)
         {
-            const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
-            keep[k] = i < count;
+            const uint32_t j = (tile * kItems + k) * kBlock + threadIdx.x;
+            keep[k] = j < count;
+            entry[k] = j;
+            if (j >= count) continue;
+            const uint32_t i = inList != nullptr ? inList[j] : j;
             entry[k] = i;
-            if (i >= count) continue;
             const Vec3     o = load3(ps.rayO + i);
             uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(occluderCellIndex(wide, o.x, o.y, o.z));
             uint32_t        e[kOccSlots];

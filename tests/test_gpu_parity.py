@@ -466,6 +466,38 @@ def test_occluder_cache_is_invisible(atrium, duck_pt):
             r.close()
 
 
+def test_shadow_rays_stopped_by_the_triangle_they_start_on_are_settled_by_kshade(atrium, duck_pt):
+    """kShadeSelfShadow: the reference pushes a hit point off the surface along the GEOMETRIC normal whatever side the path came from (wgsl:511-519), so wherever the sun stands
+    behind that normal shadowRay (wgsl:321-368) is stopped by the surface itself.  kShade tests exactly that -- the exact box of the triangle's leaf, then the triangle, both in
+    the shading record it holds -- and only the other hits are queued for the any-hit launches.  Same image bit for bit with the option off (cache on and off, first look from
+    bounce 1 / 2 / never), every shadow ray still counted, and the test really engages (more than a third of the atrium's shadow rays)."""
+    for pt, (W, H, spp, bounces) in ((atrium, (640, 360, 4, 6)), (duck_pt, (200, 150, 4, 4))):
+        imgs, stats = {}, {}
+        for name, opts in (("off", dict(shadow_self_test=0)), ("on", {}), ("on, cache off", dict(occluder_cache_bounces=0)), ("on, first look from 1", dict(shadow_first_look_from_bounce=1)),
+                           ("on, no first look", dict(shadow_first_look_from_bounce=0))):
+            r, _ = _renderer(pt, W, H, spp, bounces)
+            for k, v in opts.items():
+                r.set_option(k, v)
+            r.render(spp); r.synchronize()                               # cold grid
+            r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.5))
+            r.reset_stats()
+            r.render(spp)                                                # warm grid: kShadowFirstLook works through kShade's list
+            imgs[name], stats[name] = r.read_accumulation()[0], (r.stats(), r.bounce_stats())
+            r.close()
+        off = stats["off"][0]
+        assert off["shadow_rays_self_answered"] == 0
+        for name in imgs:
+            s, b = stats[name]
+            assert np.array_equal(bits(imgs[name]), bits(imgs["off"])), name
+            assert s["shadow_rays"] == off["shadow_rays"] and s["closest_rays"] == off["closest_rays"], name
+            assert np.array_equal(np.asarray(b["shadow_rays"]), np.asarray(stats["off"][1]["shadow_rays"])), name
+            if name != "off":
+                assert s["shadow_rays_self_answered"] == stats["on"][0]["shadow_rays_self_answered"], name     # (a property of the rays, not of the cache)
+                assert s["shadow_rays_self_answered"] + s["shadow_rays_hint_answered"] <= s["shadow_rays"], name
+        if pt is atrium:
+            assert stats["on"][0]["shadow_rays_self_answered"] > off["shadow_rays"] // 3
+
+
 def test_pinhole_primary_origin_as_a_kernel_argument_is_invisible(duck_pt, duck_oracle):
     """A pinhole camera's primary rays all start at camera.origin: kRaygen then writes no origins and the bounce-1 closest-hit launch takes the point as a kernel
     argument (kFlagConstOrigin).  Same image bit for bit with the option off; a camera with a lens, and a pinhole whose origin has a component that is exactly zero
@@ -493,6 +525,7 @@ def test_occluder_cache_engages_on_the_atrium(atrium):
     launches take clearly less time than with the cache off, and the per-bounce ray counts do not change (every shadow ray is still counted)."""
     W, H, spp, bounces = 1920, 1080, 16, 8                            # (33 M paths per batch: launches long enough for their time to mean something)
     r, _ = _renderer(atrium, W, H, spp, bounces)
+    r.set_option("shadow_self_test", 0)                              # (kShade's own-triangle test would settle six shadow rays in ten before the cache sees them: its own test below)
     r.render(spp); r.synchronize()                                   # first batch: fills the grid
     res = {}
     for name, n in (("on", 64), ("off", 0)):
@@ -888,6 +921,8 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
         if os.environ.get("RF_FUZZ_OCT"):
             r.set_option("quad_from_bounce", 1)
         r.set_option("oct_from_bounce", 1 if seed % 8 == 2 else 2 if seed % 8 == 6 else 1 + seed % 3)
+    if seed % 9 in (1, 5):                                      # kShade's own-triangle test of the shadow rays off (default: on)
+        r.set_option("shadow_self_test", 0)
     if seed % 2:                                                # one batch per sample: every batch after the first starts on a warm occluder grid
         for _ in range(spp):
             r.render(1)
