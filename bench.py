@@ -39,6 +39,9 @@ The JSON line also carries
                ray first visits the leaves that stopped the last rays from its cell of the scene): the rate and the shadow
                launches' time without it, the whole image compared bit for bit, and how many shadow rays the first look
                settled.  Every shadow ray is traced and counted in both; one unsharded GPU only (--no-occluder-ablation skips it).
+  self_shadow  the same for kShade's own-triangle test of the shadow rays (the reference offsets a hit point along the geometric normal whatever
+               the side, so a ray towards a sun behind that normal is stopped by the triangle it starts on): how many shadow rays kShade
+               settles, the rate and the shadow / shade times with the test off, image compared bit for bit.
 """
 import argparse
 import json
@@ -278,6 +281,7 @@ def run_regime(name, detail, scale, steps, sps, width, height, bounces, device, 
                ms_per_step=round(dt / steps * 1e3, 3),
                kernel_ms={k: round(st[k], 3) for k in ("ms_raygen", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")},
                value_with_cache_off=round((st_off["closest_rays"] + st_off["shadow_rays"]) / dt_off * 1e-6, 1),
+               shadow_rays_settled_by_kshade_fraction=round(st.get("shadow_rays_self_answered", 0) / max(st["shadow_rays"], 1), 4),
                cache_off_image_bit_identical=bool(np.array_equal(np.asarray(img_off).view(np.uint32), np.asarray(image).view(np.uint32))),
                record_layouts=layouts)
     if with_parity:
@@ -785,6 +789,29 @@ def main():
         log(f"[bench] occluder cache off: {occluder['value_with_cache_off']} Mrays/s, shadow launches {occluder['ms_shadow_with_cache_off']} ms against {occluder['ms_shadow']}, "
             f"image bit-identical: {occluder['image_bit_identical']}")
 
+    # ---- and once more with kShade's own-triangle test of the shadow rays off (untimed; one GPU): the reference offsets every hit point along the GEOMETRIC normal, so a
+    # shadow ray towards a sun that stands behind that normal is stopped by the triangle it starts on; kShade settles those itself (exact leaf box + triangle)
+    self_shadow = None
+    if occluder is not None:
+        r.set_option("shadow_self_test", 0)
+        r.set_render_parameters(rf.make_render_parameters(W, H, cam, spp, B, sky, 0.4375))
+        r.set_timing(True); r.reset_stats()
+        t0 = time.perf_counter(); r.render(spp); r.synchronize(); t_ns = time.perf_counter() - t0
+        s_ns = r.stats()
+        r.set_timing(False)
+        img_ns = r.read_accumulation()[0]
+        r.set_option("shadow_self_test", 1)
+        self_shadow = {"enabled": True, "shadow_rays_settled_by_kshade": int(s.get("shadow_rays_self_answered", 0)),
+                       "fraction_of_shadow_rays": round(s.get("shadow_rays_self_answered", 0) / max(s["shadow_rays"], 1), 4),
+                       "value_with_it_off": round((s_ns["closest_rays"] + s_ns["shadow_rays"]) / t_ns * 1e-6, 1),
+                       "ms_shadow": round(s["ms_shadow"], 3), "ms_shadow_with_it_off": round(s_ns["ms_shadow"], 3),
+                       "ms_shade": round(s["ms_shade"], 3), "ms_shade_with_it_off": round(s_ns["ms_shade"], 3),
+                       "same_rays": bool(s_ns["closest_rays"] == s["closest_rays"] and s_ns["shadow_rays"] == s["shadow_rays"]),
+                       "image_bit_identical": bool(np.array_equal(np.asarray(img_ns).view(np.uint32), np.asarray(image).view(np.uint32))),
+                       "note": "one untimed repeat of the same frames with shadow_self_test = 0 (occluder cache on); every shadow ray is counted in both"}
+        log(f"[bench] own-triangle test off: {self_shadow['value_with_it_off']} Mrays/s, shadow launches {self_shadow['ms_shadow_with_it_off']} ms against {self_shadow['ms_shadow']}, "
+            f"kShade settles {self_shadow['fraction_of_shadow_rays']} of the shadow rays, image bit-identical: {self_shadow['image_bit_identical']}")
+
     # ---- roofline of the dominant kernel (closest-hit traversal) + one-line entries for the shadow traversal and kShade
     live = None
     if rank == 0 and world == 1 and not multi and not args.no_live_counters and "ROCPROFILER_REGISTER_ROOT" not in os.environ and "ROCP_TOOL_LIBRARIES" not in os.environ:
@@ -838,6 +865,8 @@ def main():
             "per_bounce_rank0": per_bounce,
             "roofline": roofline,
         }
+        if self_shadow is not None:
+            out["self_shadow"] = self_shadow
         out["occluder_cache"] = occluder if occluder is not None else {"enabled": True, "value_with_cache_off": None,
                                                                          "note": "the untimed repeat with the cache off runs on one unsharded GPU only (and not with --no-counting)"}
         if not args.no_cpu_baseline and world == 1:
