@@ -865,8 +865,9 @@ def main():
             "per_bounce_rank0": per_bounce,
             "roofline": roofline,
         }
-        if self_shadow is not None:
-            out["self_shadow"] = self_shadow
+        out["self_shadow"] = self_shadow if self_shadow is not None else {"enabled": True, "shadow_rays_settled_by_kshade": int(s.get("shadow_rays_self_answered", 0)),
+                                                                          "fraction_of_shadow_rays": round(s.get("shadow_rays_self_answered", 0) / max(s["shadow_rays"], 1), 4),
+                                                                          "value_with_it_off": None, "note": "the repeat with the test off was not run (sharded / multi-rank / --no-occluder-ablation / --no-counting)"}
         out["occluder_cache"] = occluder if occluder is not None else {"enabled": True, "value_with_cache_off": None,
                                                                          "note": "the untimed repeat with the cache off runs on one unsharded GPU only (and not with --no-counting)"}
         if not args.no_cpu_baseline and world == 1:
