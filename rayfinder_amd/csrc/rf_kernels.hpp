@@ -191,7 +191,7 @@ constexpr int kItems = 4; // queue entries per thread in the per-entry kernels
 
 template<int ITEMS>
 __device__ __forceinline__ void blockAppend(const bool (&keep)[ITEMS], const uint32_t (&slot)[ITEMS], uint32_t* queue, uint32_t* count, uint32_t* sScratch,
-                                            uint32_t (*position)[ITEMS] = nullptr)
+                                            uint32_t (*position)[ITEMS] = nullptr, const uint32_t (*second)[ITEMS] = nullptr, uint32_t* queue2 = nullptr)
 {
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
     uint32_t       offs[ITEMS];
@@ -217,6 +217,7 @@ __device__ __forceinline__ void blockAppend(const bool (&keep)[ITEMS], const uin
     for (int k = 0; k < ITEMS; ++k)
     {
         if (keep[k]) queue[base + offs[k]] = slot[k];
+        if (second != nullptr && keep[k]) queue2[base + offs[k]] = (*second)[k]; // a second list with the same positions
         if (position) (*position)[k] = base + offs[k]; // where the entry went (meaningful where keep[k])
     }
     __syncthreads(); // sScratch may be reused by the next append
@@ -351,8 +352,8 @@ constexpr uint32_t kNodeDone = 0xFFFFFFFEu; // ray finished, result not yet writ
 using SamplePermutationKernel = void (*)(uint32_t firstFrame, uint32_t spp, uint32_t numSamples, uint32_t* perm, uint32_t* inv);
 using RaygenKernel = void (*)(FrameParams fp, DeviceScene scene, const uint32_t* tileIds, PathStreams ps, uint32_t* queue, uint32_t* queueCount, DeviceCounters* counters);
 using TraceClosestKernel = void (*)(DeviceScene scene, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, DeviceCounters* counters);
-using ShadeKernel = void (*)(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue, uint32_t* missCount, uint32_t* shadowList, uint32_t* shadowListCount, uint32_t bounceFlags, uint32_t sortScale);
-using SkyKernel = void (*)(SkyStateGpu sky, PathStreams ps, const uint32_t* queue, const uint32_t* missQueue, const uint32_t* missCount, uint32_t firstBounce);
+using ShadeKernel = void (*)(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue, uint32_t* missSlots, uint32_t* missCount, uint32_t* shadowList, uint32_t* shadowListCount, uint32_t bounceFlags, uint32_t sortScale);
+using SkyKernel = void (*)(SkyStateGpu sky, PathStreams ps, const uint32_t* missSlots, const uint32_t* missQueue, const uint32_t* missCount, uint32_t firstBounce);
 using TraceShadowKernel = void (*)(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, DeviceCounters* counters, uint32_t firstBounce);
 using TraceWideKernel = void (*)(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor, DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote, uint32_t chunkMax, float tMax, uint32_t flags);
 using ShadowFirstLookKernel = void (*)(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue, const uint32_t* inList, const uint32_t* inCount, uint32_t* list, uint32_t* listCount, DeviceCounters* counters, float tMax, uint32_t flags);

@@ -164,7 +164,7 @@ struct Renderer::Impl
     uint64_t                maxPaths = 0;
     DeviceBuffer<P3>        sRayO, sRayD, sRayD2, sThr, sThr2, sPending, sNoise, sNoise2; // queue-position arrays, packed xyz; rayD / thr / noise: double-buffered (PathStreams)
     DeviceBuffer<float4>    sRad, sHit;
-    DeviceBuffer<uint32_t>  queueA, queueB, missQueue, shadowList, queueCounts; // shadowList: kShade's list of the shadow rays its own-triangle test has not settled (kShadeSelfShadow)
+    DeviceBuffer<uint32_t>  queueA, queueB, missQueue, missSlots, shadowList, queueCounts; // shadowList: kShade's list of the shadow rays its own-triangle test has not settled (kShadeSelfShadow)
     DeviceBuffer<DeviceCounters> counters;
     DeviceBuffer<unsigned long long> bounceTotals; // 4 x kMaxBounceStats: closest-hit rays, shadow rays, shadow rays answered by kShadowFirstLook, shadow rays settled by kShade's own-triangle test
 
@@ -266,13 +266,13 @@ struct Renderer::Impl
     uint64_t allocatedPaths = 0;
     uint64_t effectivePaths = 0;       // batch depth the last render() call ended up with (<= maxPaths: less when less memory was free THEN)
 
-    // bytes of path state + queues per path slot (eight packed xyz streams, two float4 streams, three u32 queues)
-    static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 4 * sizeof(uint32_t);
+    // bytes of path state + queues per path slot (eight packed xyz streams, two float4 streams, four u32 queues / lists)
+    static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 5 * sizeof(uint32_t);
 
     void releasePathState()
     {
         sRayO.release(), sRayD.release(), sRayD2.release(), sThr.release(), sThr2.release(), sRad.release(), sHit.release();
-        sPending.release(), sNoise.release(), sNoise2.release(), queueA.release(), queueB.release(), missQueue.release(), shadowList.release();
+        sPending.release(), sNoise.release(), sNoise2.release(), queueA.release(), queueB.release(), missQueue.release(), missSlots.release(), shadowList.release();
         allocatedPaths = 0;
     }
 
@@ -300,7 +300,7 @@ struct Renderer::Impl
         };
         const bool ok = tryAlloc(sRayO, paths) && tryAlloc(sRayD, paths) && tryAlloc(sRayD2, paths) && tryAlloc(sThr, paths) && tryAlloc(sThr2, paths) &&
                         tryAlloc(sRad, paths) && tryAlloc(sHit, paths) && tryAlloc(sPending, paths) && tryAlloc(sNoise, paths) && tryAlloc(sNoise2, paths) &&
-                        tryAlloc(queueA, paths) && tryAlloc(queueB, paths) && tryAlloc(missQueue, paths) && tryAlloc(shadowList, paths);
+                        tryAlloc(queueA, paths) && tryAlloc(queueB, paths) && tryAlloc(missQueue, paths) && tryAlloc(missSlots, paths) && tryAlloc(shadowList, paths);
         if (!ok)
         {
             releasePathState();
@@ -554,8 +554,27 @@ struct Renderer::Impl
         }
         else
         {
+            // RF_DEBUG_QUERY_MS: the traversal launch alone between two events (tools/gpu_sort_potential.py: what would an order of the rays be worth?)
+            const bool timed = std::getenv("RF_DEBUG_QUERY_MS") != nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timed)
+            {
+                RF_HIP(hipEventCreate(&e0));
+                RF_HIP(hipEventCreate(&e1));
+                RF_HIP(hipEventRecord(e0, stream));
+            }
             launchClosestWide(layoutIfPresent(optQueryCompact), false, wide, wa, denseFlag);
+            if (timed) RF_HIP(hipEventRecord(e1, stream));
             hipLaunchKernelGGL(hitPointsKernel(), dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
+            if (timed)
+            {
+                RF_HIP(hipStreamSynchronize(stream));
+                float ms = 0.0f;
+                RF_HIP(hipEventElapsedTime(&ms, e0, e1));
+                std::fprintf(stderr, "[rf-query] closest-hit launch: %u rays, %.4f ms\n", count, ms);
+                RF_HIP(hipEventDestroy(e0));
+                RF_HIP(hipEventDestroy(e1));
+            }
         }
         RF_HIP(hipGetLastError());
         RF_HIP(hipStreamSynchronize(stream));
@@ -711,11 +730,13 @@ struct Renderer::Impl
                 const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u) | (selfShadow ? kShadeSelfShadow : 0u);
                 const dim3     shadeGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
                 if (optShadeSortFromBounce != 0u && bounce >= optShadeSortFromBounce)
-                    hipLaunchKernelGGL(shadeKernel(true), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, sortScale);
+                    hipLaunchKernelGGL(shadeKernel(true), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missSlots.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, sortScale);
                 else
-                    hipLaunchKernelGGL(shadeKernel(false), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, 0u);
-                // the paths that left the scene at this bounce, while its direction / throughput arrays and queue are intact
-                hipLaunchKernelGGL(skyKernel(), dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, qIn, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
+                    hipLaunchKernelGGL(shadeKernel(false), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missSlots.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, 0u);
+                // the paths that left the scene at this bounce, while its direction / throughput arrays are intact
+                // (its slot comes with the miss list: kSky reads nothing of the bounce's queue -- round 5: reading the slot through the queue position was a third
+                // dependent gather, and kShade + kSky went from 19.7 to 15.8 ms per 64 spp without it)
+                hipLaunchKernelGGL(skyKernel(), dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, missSlots.ptr, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
             });
             // occluder cache (kTraceWide, kFlagOccluderCache): the conservative-record any-hit launches of bounces 1..optOccluderCacheBounces; their rays are
             // short (a third of the steps), so the deep launches refill earlier

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
 #endif
 template<bool SORTED>
 __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
-                                                  const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue,
+                                                  const uint32_t* queueCount, uint32_t* hitQueue, uint32_t* hitCount, uint32_t* missQueue, uint32_t* missSlots,
                                                   uint32_t* missCount, uint32_t* shadowList, uint32_t* shadowListCount, uint32_t bounceFlags, uint32_t sortScale)
 {
     static_assert(kSortBins == kBlock, "one bin per thread");
@@ -132,17 +132,18 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     // knows its position in the next queue before it is shaded: what only the next two launches read (the NEE term) is
     // written there, densely, instead of at the path's slot (whose neighbours are mostly dead by bounce 3).
     bool       isHit[kItems], isMiss[kItems];
-    uint32_t   slots[kItems], missEntries[kItems], outPos[kItems], hitTri[kItems];
+    uint32_t   slots[kItems], missEntries[kItems], missSlot[kItems], outPos[kItems], hitTri[kItems];
 #pragma unroll
     for (int k = 0; k < kItems; ++k)
     {
         const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
         isHit[k] = isMiss[k] = false;
-        slots[k] = missEntries[k] = 0;
+        slots[k] = missEntries[k] = missSlot[k] = 0;
         hitTri[k] = kMiss;
         if (i >= count) continue;
-        slots[k] = queue[i];
-        missEntries[k] = i; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there
+        slots[k] = missSlot[k] = queue[i];
+        missEntries[k] = i; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there (and, in a second list, the path's slot:
+                            // kSky then needs nothing of the bounce's queue, which kShadowFirstLook reuses for its list while kSky may still be running)
         const Vec3     hitRec = SORTED ? load3(ps.hit + i) : vec3(ps.hit[i].x, 0.0f, 0.0f); // hit records sit at QUEUE positions (dense)
         const uint32_t tri = __float_as_uint(hitRec.x);
         hitTri[k] = tri;
@@ -223,7 +224,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     }
     else
         blockAppend<kItems>(isHit, slots, hitQueue, hitCount, sScratch, &outPos);
-    blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch);
+    blockAppend<kItems>(isMiss, missEntries, missQueue, missCount, sScratch, nullptr, &missSlot, missSlots);
 
     // Pass 2: shade the hits.  An entry is a chain of dependent gathers -- hit record -> shading record -> texture descriptor -> texel --
     // and four entries one after the other were four such chains end to end: the kernel waited.  Now the hit records of all
@@ -405,7 +406,7 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
 // after kShade, while the bounce's direction / throughput arrays and its queue are still intact.  All NEE terms of the path
 // have been added by then (the shadow launch of the previous bounce is complete).  Grid-stride: the list length is only
 // known on the device, and a worst-case grid of empty workgroups per bounce would cost more than the work.
-__global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, const uint32_t* queue, const uint32_t* missQueue, const uint32_t* missCount,
+__global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, const uint32_t* missSlots, const uint32_t* missQueue, const uint32_t* missCount,
                                                 uint32_t firstBounce)
 {
     const uint32_t n = *missCount;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, 
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
     {
         const uint32_t q = missQueue[i];
-        const uint32_t slot = queue[q];
+        const uint32_t slot = missSlots[i];
         const Vec3     v = load3(ps.rayD + q);
         const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + q);
         const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot);
