@@ -220,6 +220,15 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // shift-or for the address, and -- in the quad steps -- one bound check per step instead of one per push: closest-hit launches -1.5 % (round 4,
     // gpurun_out A/B in profiles/r04_lanes).  The any-hit launches measured +2.5 % with it and keep the plain depth, as do the counting builds
     // (they report it).
+    // ---- Eager leaves (closest-hit launches of scenes without long leaves; round 5).  A closest-hit ray's stack is full of leaves: the far child of a step near the bottom
+    // of the tree IS a leaf, and after a leaf phase a third of the lanes that were served hold the next leaf straight off their stack.  They used to sit through the next descend
+    // loop -- at least one trip, usually several -- before the next leaf phase took them.  Now (a) the leaf phase repeats while kLeafRepeat or more lanes stand at a leaf, and
+    // (b) a descend loop that fewer than `leafVote` lanes would enter is skipped when that many lanes wait at a leaf.  Scheduling only: every ray still visits its nodes and
+    // leaves in its own order.  Closest-hit launches -4.4 % on the plain atrium, neutral on the out-of-cache one (profiles/r05_leafrep); the dense (lane, triangle) leaf phase
+    // of the scenes with long leaves (DENSE_LEAVES) loses 6 % with it -- a phase of its kind wants many parked lanes -- and the any-hit launches stop at their first hit:
+    // both keep the plain schedule.  (As a run-time threshold in the launch flags the loop cost 4 % by its presence; a compile-time constant costs nothing.)
+    constexpr bool     kEagerLeaves = !ANY_HIT && !COUNT && !DENSE_LEAVES;
+    constexpr uint32_t kLeafRepeat = 8u;
     constexpr bool kPtrStack = !COUNT && !ANY_HIT;
     const int     spBase = kPtrStack ? static_cast<int>(threadIdx.x * sizeof(uint2)) : 0;
     constexpr int kSpStep = kPtrStack ? static_cast<int>(kBlock * sizeof(uint2)) : 1;
@@ -487,6 +496,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         }
 
         // ---- descend: one 64-byte record = both children of an accepted interior node
+        // (kEagerLeaves: when fewer than `leafVote` lanes would descend and kLeafRepeat or more already stand at a leaf -- off their stacks, or fresh from a refill of a
+        // one-leaf tree -- the leaf phase comes first: the thin descend trip that used to run in front of it is skipped)
+        if (!kEagerLeaves || !(__popcll(__ballot(static_cast<int32_t>(node) >= 0)) < leafVote &&
+                               __popcll(__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit)) >= kLeafRepeat))
         do
         {
             if (kPhase) ++wDescend;
@@ -1024,6 +1037,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull) ++phaseLeafWave;
 #endif
         uint32_t occluderWord = 0u; // kOccluderCache: the leaf in which this lane has just found an occluder
+        // kEagerLeaves: the leaf phase REPEATS while kLeafRepeat or more lanes stand at a leaf (see the declaration of kEagerLeaves)
+        do
+        {
         // ---- Leaf phase over dense (lane, triangle) pairs (round 5).  The loop further down tests triangle i of every parked lane's leaf in trip i: a phase lasts as
         // long as its LONGEST leaf, and on a scene whose leaves differ in length (the atrium with clutter: 1 ... 12 triangles, 7.2 tests per closest-hit ray) most trips
         // run for a handful of lanes.  When a parked lane's leaf holds kDenseMin triangles or more, the phase runs over PAIRS instead: the lanes' triangle counts are
@@ -1274,6 +1290,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             }
             else popNext();
         }
+        } while (kEagerLeaves && __popcll(__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit)) >= kLeafRepeat);
 
         // ---- write back finished rays
         if (kSpill && node == kNodeDone && !needScalar && !occluded)
