@@ -204,7 +204,7 @@ struct Renderer::Impl
     uint32_t maxLeafTriangles = 0; // of the scene (upload): scenes without a leaf as long as the threshold run the instantiations WITHOUT the dense block
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
-    uint32_t optRefillMinDeep = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 3; // closest-hit launches of bounce >= 3 refill at another count: 22 idle lanes on the 64-byte and the
+    uint32_t optRefillMinDeep = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 2; // closest-hit launches of bounce >= 2 (3 until the eager-leaves schedule: bounce 2 -2.6 % with it) refill at another count: 22 idle lanes on the 64-byte and the
                                                                                              // half-precision quad records (VALU bound: idle lanes cost most), 40 on the exact quad records (L1 bound: a refill is a wave-wide stall)
     // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
