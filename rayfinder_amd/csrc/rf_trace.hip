@@ -1035,9 +1035,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         // launches: parking pays; profiles/r05_leafrep/ab_leafearly.log)
 
         // ---- leaves
-#if defined(RF_EXP_PHASE)
-        if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull) ++phaseLeafWave;
-#endif
         uint32_t occluderWord = 0u; // kOccluderCache: the leaf in which this lane has just found an occluder
         // kEagerLeaves: the leaf phase REPEATS while kLeafRepeat or more lanes stand at a leaf (see the declaration of kEagerLeaves)
         do
@@ -1053,6 +1050,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         // The block is self-contained (its own leaf decode and exact box test) so that the loop below keeps its registers to itself: what it needs of a leaf's
         // first triangle record is live only inside its own branch.  And it is a template parameter (DENSE_LEAVES): its mere presence costs the closest-hit launches
         // of a scene that never uses it 2.5 % (profiles/r05_leaf/ab_presence.log), so scenes without long leaves run the instantiations without it.
+#if defined(RF_EXP_PHASE)
+        if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull) ++phaseLeafWave; // (every pass of a repeated leaf phase counts)
+#endif
         bool denseDone = false; // this lane's leaf has been dealt with by this block
         if constexpr (!COUNT && DENSE_LEAVES)
         {
