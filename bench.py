@@ -891,7 +891,7 @@ def main():
             except Exception as e:  # noqa: BLE001  (an extra: it must not take the headline down)
                 out["occluder_cache"]["value_cold_start"] = {"error": str(e)[:300]}
             regimes = {}
-            for (name, detail, scale, steps) in (("clutter", "clutter", 1, 4), ("out_of_cache_x8", "plain", 8, 2)):
+            for (name, detail, scale, steps) in (("clutter", "clutter", 1, 20), ("out_of_cache_x8", "plain", 8, 4)):   # (the step counts of their own full lines in profiles/: the whole driver command takes about a minute)
                 try:
                     regimes[name] = run_regime(name, detail, scale, steps, SPS, W, H, B, local_rank, with_parity=not args.no_cpu_baseline)
                 except Exception as e:  # noqa: BLE001

@@ -400,14 +400,16 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // at write-back, where every finishing lane gathered its own 12 bytes and the wave waited for them
                 if (ANY_HIT) pendingTerm = load3s(ps.pending + resultIndex);
                 // (a pinhole camera's primary rays: one origin, a kernel argument -- 12 of the 40 bytes a path costs kRaygen, and the read back here)
+                // (the direction is requested FIRST: behind the origin's wave-uniform branch the compiler waited for the origin before it asked for the direction -- two
+                // memory round trips per refill of a closest-hit launch instead of one)
+                Vec3 dir{};
+                if (!(ANY_HIT && !shadowDirFromStream)) dir = load3s(ps.rayD + resultIndex);
                 const Vec3 o = (!ANY_HIT && (flags & kFlagConstOrigin) != 0u) ? vec3(wide.constOriginX, wide.constOriginY, wide.constOriginZ) : load3s(ps.rayO + resultIndex);
-                Vec3       dir;
                 if (ANY_HIT && !shadowDirFromStream)
                 {
                     const Vec3 nz = load3s(ps.noiseOut + resultIndex);
                     dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
-                else dir = load3s(ps.rayD + resultIndex);
                 const RayPrep ray = prepareRay(o, dir);
                 pr = packRay(ray);
                 rayDir = dir;
@@ -1201,13 +1203,27 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // test its box, exactly, with its own formula, against the rayTMax of this moment -- happens here.  The leaf's box
                 // rides in the spare floats of its first triangle record (leafBoxesIntoTriangles): the same 64-byte line.
                 const float4* t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
-                firstA = t0[0], firstB = t0[1], firstC = t0[2];
                 float4 hi;
-                if constexpr (kOccluderCache) hi = t0[3]; // .w: what the occluder cache remembers for this leaf (leafBoxesIntoTriangles)
-                else
                 {
-                    const v3f h3 = *reinterpret_cast<const v3f*>(t0 + 3);
-                    hi = make_float4(h3.x, h3.y, h3.z, 0.0f);
+                    // FOUR loads for the 64-byte record, each pinned in its own register tuple: left alone, the compiler re-cuts the record to suit the packed arithmetic
+                    // below -- six loads (4 + 16, 8, 8, 16, 4, 16 bytes), six vector-L1 tag accesses per lane and leaf instead of four
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f* t4 = reinterpret_cast<const v4f*>(t0);
+                    // (ONE pin behind all four loads: the empty asm is a scheduling barrier that needs its operands, i.e. a wait for the loads in front of it)
+                    v4f        ra = t4[0], rb = t4[1], rc = t4[2];
+                    if constexpr (kOccluderCache)
+                    {
+                        v4f rd = t4[3]; // .w: what the occluder cache remembers for this leaf (leafBoxesIntoTriangles)
+                        asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc), "+v"(rd));
+                        hi = make_float4(rd.x, rd.y, rd.z, rd.w);
+                    }
+                    else
+                    {
+                        v3f h3 = *reinterpret_cast<const v3f*>(t0 + 3);
+                        asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc), "+v"(h3));
+                        hi = make_float4(h3.x, h3.y, h3.z, 0.0f);
+                    }
+                    firstA = make_float4(ra.x, ra.y, ra.z, ra.w), firstB = make_float4(rb.x, rb.y, rb.z, rb.w), firstC = make_float4(rc.x, rc.y, rc.z, rc.w);
                 }
                 if constexpr (kOccluderCache) leafHint = __float_as_uint(hi.w);
                 float     bn, bf;
@@ -1468,7 +1484,10 @@ __global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, Wi
             if (j >= count) continue;
             const uint32_t i = inList != nullptr ? inList[j] : j;
             entry[k] = i;
-            const Vec3     o = load3(ps.rayO + i);
+            // (one dwordx3, pinned: the compiler cuts the 12 bytes into two overlapping dwordx2 for the packed arithmetic further down otherwise)
+            v3fu           o3 = *reinterpret_cast<const v3fu*>(ps.rayO + i);
+            asm volatile("" : "+v"(o3));
+            const Vec3     o = vec3(o3.x, o3.y, o3.z);
             uint32_t* const cell = wide.occGrid + kOccSlots * static_cast<size_t>(occluderCellIndex(wide, o.x, o.y, o.z));
             uint32_t        e[kOccSlots];
             loadOccluderCell(cell, e);
@@ -1488,8 +1507,12 @@ __global__ __launch_bounds__(kBlock) void kShadowFirstLook(DeviceScene scene, Wi
                 if (at >= 0 || (w & kWideLeafBit) == 0u || ((w >> kWideIndexBits) & 7u) == 7u) continue;
                 const uint32_t first = w & ((1u << kWideIndexBits) - 1u), n = ((w >> kWideIndexBits) & 7u) + 1u;
                 const float4*  t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
-                const float4   a = t0[0], b = t0[1], c = t0[2];
-                const v3f      hi = *reinterpret_cast<const v3f*>(t0 + 3);
+                // (four loads, each pinned in its own register tuple: the compiler re-cuts the 64-byte record into six otherwise -- see the leaf phase of kTraceWide)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f*     t4 = reinterpret_cast<const v4f*>(t0);
+                v4f            a = t4[0], b = t4[1], c = t4[2];
+                v3f            hi = *reinterpret_cast<const v3f*>(t0 + 3);
+                asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(hi));
                 float          bn, bf;
                 bool           boxNaN;
                 slabSingleBounds(pr, a.w, b.w, c.w, hi.x, hi.y, hi.z, bn, bf, boxNaN);

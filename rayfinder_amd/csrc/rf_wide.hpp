@@ -971,6 +971,9 @@ __device__ __forceinline__ void slabSingleBounds(const PackedRay& r, float loX, 
     const v2f c = (v2f{loZ, hiZ} - oZZ) * iZZ;     // t(lo.z), t(hi.z)
     near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a.x, b.x), __builtin_fminf(a.y, b.y)), __builtin_fminf(c.x, c.y));
     far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a.x, b.x), __builtin_fmaxf(a.y, b.y)), __builtin_fmaxf(c.x, c.y));
+    // (pinned here so that the min / max chains stay in the basic block of their products: sunk behind the callers' rare class-B branch, the compiler no longer knows the
+    // products to be canonical and spends six v_max x,x on quieting them -- as in slabStep, rf_trace.hip)
+    asm volatile("" : "+v"(near), "+v"(far));
     hasNaN = __builtin_isunordered(a.x, a.y) || __builtin_isunordered(b.x, b.y) || __builtin_isunordered(c.x, c.y);
 }
 
