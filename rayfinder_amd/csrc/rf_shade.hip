@@ -133,35 +133,55 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     // written there, densely, instead of at the path's slot (whose neighbours are mostly dead by bounce 3).
     bool       isHit[kItems], isMiss[kItems];
     uint32_t   slots[kItems], missEntries[kItems], missSlot[kItems], outPos[kItems], hitTri[kItems];
+    // (round 5: the loads of all kItems entries are ASKED FOR before any of them is looked at -- first the queue entries and hit records, then, for the hits, throughput and
+    // blue-noise triple.  As one loop with its `continue` and `if (hit)` the compiler waited for each entry's loads inside that entry's own blocks: eight memory round trips one
+    // after the other at three waves per SIMD.  An entry that has nothing to load reads element 0 of the stream: one line for the whole wave, and a valid address)
+    Vec3       hitRecs[kItems];
 #pragma unroll
     for (int k = 0; k < kItems; ++k)
     {
         const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
-        isHit[k] = isMiss[k] = false;
-        slots[k] = missEntries[k] = missSlot[k] = 0;
-        hitTri[k] = kMiss;
-        if (i >= count) continue;
-        slots[k] = missSlot[k] = queue[i];
-        missEntries[k] = i; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there (and, in a second list, the path's slot:
-                            // kSky then needs nothing of the bounce's queue, which kShadowFirstLook reuses for its list while kSky may still be running)
-        const Vec3     hitRec = SORTED ? load3(ps.hit + i) : vec3(ps.hit[i].x, 0.0f, 0.0f); // hit records sit at QUEUE positions (dense)
-        const uint32_t tri = __float_as_uint(hitRec.x);
+        const uint32_t iL = i < count ? i : 0u;
+        slots[k] = queue[iL];
+        hitRecs[k] = SORTED ? load3(ps.hit + iL) : vec3(ps.hit[iL].x, 0.0f, 0.0f); // hit records sit at QUEUE positions (dense)
+    }
+#pragma unroll
+    for (int k = 0; k < kItems; ++k)
+    {
+        const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
+        const bool     valid = i < count;
+        const uint32_t tri = valid ? __float_as_uint(hitRecs[k].x) : kMiss;
+        slots[k] = valid ? slots[k] : 0u;
+        missSlot[k] = slots[k];
+        missEntries[k] = valid ? i : 0u; // the miss list holds QUEUE positions: kSky finds the ray's direction and throughput there (and, in a second list, the path's slot:
+                                         // kSky then needs nothing of the bounce's queue, which kShadowFirstLook reuses for its list while kSky may still be running)
         hitTri[k] = tri;
-        isMiss[k] = tri == kMiss; // the path ends in the sky: evaluated densely by this bounce's kSky launch
-        isHit[k] = tri != kMiss;
-        if constexpr (SORTED)
+        isMiss[k] = valid && tri == kMiss; // the path ends in the sky: evaluated densely by this bounce's kSky launch
+        isHit[k] = valid && tri != kMiss;
+    }
+    if constexpr (SORTED)
+    {
+        // what pass 2 needs of the hits, read here in INPUT order (coalesced) and handed over in LDS: pass 2 works in the
+        // tile's sorted order, where the 64 lanes of a wave would gather from ~57 different lines per stream
+        Vec3 thrIn[kItems], noiseIn[kItems];
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
         {
-            if (isHit[k])
-            {
-                // what pass 2 needs of this entry, read here in INPUT order (coalesced) and handed over in LDS: pass 2 works in the
-                // tile's sorted order, where the 64 lanes of a wave would gather from ~57 different lines per stream
-                const uint32_t l = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
-                const Vec3     t = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3nt(ps.thr + i), z = load3nt(ps.noise + i);
-                sIn[l] = t.x, sIn[kTile + l] = t.y, sIn[2 * kTile + l] = t.z;
-                sIn[3 * kTile + l] = z.x, sIn[4 * kTile + l] = z.y, sIn[5 * kTile + l] = z.z;
-                sIn[6 * kTile + l] = hitRec.x, sIn[7 * kTile + l] = hitRec.y, sIn[8 * kTile + l] = hitRec.z;
-                sIn[9 * kTile + l] = __uint_as_float(slots[k]);
-            }
+            const uint32_t i = (tile * kItems + k) * kBlock + threadIdx.x;
+            const uint32_t iL = isHit[k] ? i : 0u;
+            thrIn[k] = isFirstBounce ? vec3(1.0f, 1.0f, 1.0f) : load3nt(ps.thr + iL);
+            noiseIn[k] = load3nt(ps.noise + iL);
+        }
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+        {
+            if (!isHit[k]) continue;
+            const uint32_t l = static_cast<uint32_t>(k) * kBlock + threadIdx.x;
+            const Vec3     t = thrIn[k], z = noiseIn[k], hitRec = hitRecs[k];
+            sIn[l] = t.x, sIn[kTile + l] = t.y, sIn[2 * kTile + l] = t.z;
+            sIn[3 * kTile + l] = z.x, sIn[4 * kTile + l] = z.y, sIn[5 * kTile + l] = z.z;
+            sIn[6 * kTile + l] = hitRec.x, sIn[7 * kTile + l] = hitRec.y, sIn[8 * kTile + l] = hitRec.z;
+            sIn[9 * kTile + l] = __uint_as_float(slots[k]);
         }
     }
     uint32_t sortedHits = 0, sortedBase = 0; // SORTED: hits of the tile, and where its run starts in the next queue
@@ -255,6 +275,9 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
 #if defined(RF_EXP_SHADE_ABLATE) && RF_EXP_SHADE_ABLATE >= 3
         if constexpr (SORTED) rec = scene.shadeRecords + 8 * static_cast<size_t>(tri & 63u); // ablation (timing only): 64 records, all L1 hits
 #endif
+        // (round 5 measured the same fetch as straight-line code -- eight loads, no branch, every lane fetching A record -- so that entry k + 1's record really is in flight
+        // while entry k is shaded (as written here the compiler waits for each group of four loads on the spot): `kShade` +3.5 %.  The kernel is bound by what the fabric
+        // delivers, not by the latency of its requests; profiles/r05_shademlp)
         if (selfShadow)
         {
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
