@@ -438,9 +438,12 @@ __global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, 
     {
         const uint32_t q = missQueue[i];
         const uint32_t slot = missSlots[i];
+        // (all three asked for at once: behind the wave-uniform `first` the compiler waited for the direction before it asked for the other two.  At bounce 1 the two
+        // arrays hold nothing yet -- allocated memory, values not used)
         const Vec3     v = load3(ps.rayD + q);
-        const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : load3(ps.thr + q);
-        const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : load3(ps.rad + slot);
+        const Vec3     thrIn = load3(ps.thr + q), radIn = load3(ps.rad + slot);
+        const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : thrIn;
+        const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : radIn;
         const Vec3     s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
         const float    theta = wAcos(v.y);
         const float    gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));

@@ -650,7 +650,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                         }
                         else
                         {
-                            const uint4* n = wide.quadLocal + 4 * static_cast<size_t>(node);
+                            const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wide.quadLocal) + (node << 6)); // (32-bit byte offset: see the half-precision records)
                             v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3];
                         }
                         // A = scale / d (exact: a power of two times 1/d), B = (anchor - o) / d - 1024 A (one FMA)
@@ -691,7 +691,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                         }
                         else
                         {
-                            const uint4* n = wide.quadHalf + 4 * static_cast<size_t>(node);
+                            // (a 32-bit BYTE offset -- record indices stay below 2^26 (kWideIndexBits), 64 bytes each -- so that the four loads take the array's base from SGPRs and
+                            // the offset from one VGPR: one shift instead of a 64-bit shift and add per step)
+                            const uint4* n = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wide.quadHalf) + (node << 6));
                             const uint4  v0 = n[0], v1 = n[1], v2 = n[2], v3 = n[3];
                             halfEntryBounds<false>(v0.x, v0.y, v0.z, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq0, f0);
                             halfEntryBounds<false>(v0.w, v1.x, v1.y, rx, ry, rz, pr.iXY.x, pr.iXY.y, pr.iZ, bx, by, bz, tq1, f1);
@@ -1202,7 +1204,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // The half-precision / local-grid quad records let a SUPERSET of the reference's nodes through; what the reference does at a leaf --
                 // test its box, exactly, with its own formula, against the rayTMax of this moment -- happens here.  The leaf's box
                 // rides in the spare floats of its first triangle record (leafBoxesIntoTriangles): the same 64-byte line.
-                const float4* t0 = scene.triangles + kTriStride * static_cast<size_t>(first);
+                static_assert(kTriStride * sizeof(float4) == 64, "the leaf phase addresses triangle records by a 32-bit byte offset: 64 bytes each, indices below 2^26");
+                const float4* t0 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(scene.triangles) + (first << 6));
                 float4 hi;
                 {
                     // FOUR loads for the 64-byte record, each pinned in its own register tuple: left alone, the compiler re-cuts the record to suit the packed arithmetic
