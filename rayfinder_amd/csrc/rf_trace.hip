@@ -211,7 +211,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     float hbx = 0.0f, hby = 0.0f, hbz = 0.0f;
     uint32_t lselX = 0u, lselY = 0u, lselZ = 0u; // COMPACT == 5 (local-grid quad records): per-axis v_perm_b32 selectors (see localEntryBounds)
     uint32_t octKey = 0u; // COMPACT == 6 (oct records): bits 5..0 = 16 x the field of the record's order table this ray reads, bits 8.. = 0x7777 when its positions are flipped (WideBuild::oct)
-    uint32_t hrot = 0u; // ... and (1/d.x < 0) << 4 | (1/d.y < 0) << 12 | (1/d.z < 0) << 20: rotate amounts that bring a plane word's NEAR plane into its low half
+    uint32_t hrot = 0u, hrotY = 0u, hrotZ = 0u; // ... and (1/d.x < 0) << 4, (1/d.y < 0) << 4, (1/d.z < 0) << 4: rotate amounts that bring a plane word's NEAR plane into its low half
+                                                // (three registers, not three fields of one: the two shifts that took the fields apart ran in every step)
     PackedRay pr{};        // origin and 1/direction in the pairings of the record (rf_wide.hpp)
     Vec3      rayDir{};    // for the triangle tests
     uint32_t  negMask = 0; // bit a: 1/direction[a] < 0 (reference child order); bit 3: class B ray (rf_wide.hpp)
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     hbx = -(o.x * pr.iXY.x);
                     hby = -(o.y * pr.iXY.y);
                     hbz = -(o.z * pr.iZ);
-                    hrot = (ray.negX << 4) | (ray.negY << 12) | (ray.negZ << 20);
+                    hrot = ray.negX << 4, hrotY = ray.negY << 4, hrotZ = ray.negZ << 4;
                     lselX = ray.negX ? 0x00040005u : 0x00050004u, lselY = ray.negY ? 0x00040005u : 0x00050004u, lselZ = ray.negZ ? 0x00040005u : 0x00050004u;
                     const uint32_t signXY = ray.negX | (ray.negY << 1);
                     octKey = ray.negZ ? ((16u * (3u - signXY)) | (0x7777u << 8)) : 16u * signXY;
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                         // ---- half-precision quad records (rf_wide.hpp, WideBuild::quadHalf): the same four entries, planes as binary16,
                         // 64 bytes -- four loads.  CONSERVATIVE tests (a superset passes; the leaf phase applies the exact boxes).
                         const float    bx = hbx, by = hby, bz = hbz;
-                        const uint32_t rx = hrot, ry = hrot >> 8, rz = hrot >> 16;
+                        const uint32_t rx = hrot, ry = hrotY, rz = hrotZ;
                         float       f0, f1, f2, f3;
                         const uint32_t uNode = __builtin_amdgcn_readfirstlane(node);
                         if (uniformFetch && __ballot(node != uNode) == 0ull)
