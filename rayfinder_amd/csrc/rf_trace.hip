@@ -459,8 +459,16 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     const uint32_t signXY = ray.negX | (ray.negY << 1);
                     octKey = ray.negZ ? ((16u * (3u - signXY)) | (0x7777u << 8)) : 16u * signXY;
                 }
-                float      rootTMin;
-                const bool rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
+                // The root's own test (wgsl:379-382).  On the conservative records a class A ray (no infinite 1/d: no 0 * inf product anywhere) does without it: its first step
+                // tests the root's grandchildren -- supersets of boxes that lie inside the root's --, every leaf applies its exact box, and a ray that misses the root's box
+                // misses every box inside it (the slab arithmetic is monotone in the planes: rf_wide.hpp): one wasted step for such a ray, ~25 instructions less in every
+                // refill.  Class B rays keep the test: the reference's NaN rules at the ROOT's planes are not seen by any leaf.  The counting builds keep it too.
+                bool rootOk = true;
+                if (!(kConservative && !COUNT) || rayClass != kRayPlain)
+                {
+                    float rootTMin;
+                    rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
+                }
                 node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
                 if constexpr (kOccluderCache)
                 {
