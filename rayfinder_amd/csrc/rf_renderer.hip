@@ -1664,6 +1664,12 @@ uint32_t checkWideLayouts(std::span<const BvhNode> nodes, float* quadHalfAreaRat
                     for (int ax = 0; ax < 3; ++ax)
                     {
                         const uint32_t w = d[3 * (2 * k + j) + ax];
+                        if (d[12 + 2 * k + j] == kQuadEmpty)
+                        {
+                            // (an empty slot holds the inverted box that no ray passes: the traversal kernel does not test its word)
+                            if (w != kHalfEmptyPlanes) fail(r, "half-precision quad record: an empty slot does not hold the inverted box");
+                            continue;
+                        }
                         const uint16_t l16 = static_cast<uint16_t>(w & 0xFFFFu), h16 = static_cast<uint16_t>(w >> 16);
                         for (const uint16_t v : {l16, h16})
                             if (((v >> 10) & 0x1Fu) == 0x1Fu || (((v >> 10) & 0x1Fu) == 0u && (v & 0x3FFu) != 0u)) fail(r, "half-precision quad record: a plane is not a normal number or zero");

@@ -726,8 +726,11 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     // (an any-hit ray on the conservative layouts leaves `tmin < rayTMax` to the exact leaf test: its rayTMax is the constant
                     // tMax of the launch, which no box of a real scene lies beyond, and a superset is all these steps have to accept)
                     constexpr bool kSkipTMax = ANY_HIT && (COMPACT == 4 || COMPACT == 5);
-                    const bool     h0 = okq0 && (kSkipTMax || tq0 < rayTMax), h1 = okq1 && (kSkipTMax || tq1 < rayTMax) && w1 != kQuadEmpty,
-                                   h2 = okq2 && (kSkipTMax || tq2 < rayTMax), h3 = okq3 && (kSkipTMax || tq3 < rayTMax) && w3 != kQuadEmpty;
+                    // (an empty slot of a half-precision record holds an inverted box that fails `near <= far` for every ray: rf_wide.hpp, kHalfEmptyPlanes; the other
+                    // layouts' empty slots hold a degenerate box and are recognised by their word)
+                    constexpr bool kEmptyByBox = COMPACT == 4;
+                    const bool     h0 = okq0 && (kSkipTMax || tq0 < rayTMax), h1 = okq1 && (kSkipTMax || tq1 < rayTMax) && (kEmptyByBox || w1 != kQuadEmpty),
+                                   h2 = okq2 && (kSkipTMax || tq2 < rayTMax), h3 = okq3 && (kSkipTMax || tq3 < rayTMax) && (kEmptyByBox || w3 != kQuadEmpty);
                     constexpr uint32_t kAxisMask = ~(3u << kWideAxisShift);
                     // an entry that cannot be hit any more carries kQuadEmpty from here on
                     const uint32_t e0 = h0 ? (w0 & kAxisMask) : kQuadEmpty, e1 = h1 ? (w1 & kAxisMask) : kQuadEmpty, e2 = h2 ? w2 : kQuadEmpty, e3 = h3 ? (w3 & kAxisMask) : kQuadEmpty;

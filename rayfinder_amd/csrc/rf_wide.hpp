@@ -53,6 +53,7 @@ constexpr uint32_t kWideNone = 0xFFFFFFFFu; // scene.rootLeaf when the root is i
 // -> closest-hit: half-precision up to kQuadHalfMaxAreaRatio, local grid beyond; shadow: local grid up to kQuadLocalShadowMaxAreaRatio,
 //    exact quad records beyond.
 constexpr float    kQuadHalfMaxAreaRatio = 1.075f, kQuadLocalShadowMaxAreaRatio = 1.10f;
+constexpr uint32_t kHalfEmptyPlanes = 0x7BFFu | (0xFBFFu << 16); // half-precision quad records: the plane word {lower = +65504, upper = -65504} of an empty slot (an inverted box)
 constexpr uint32_t kQuadEmpty = 0xFFFFFFFFu; // quad records: an entry slot that holds no node (its child is a leaf and fills one slot only)
 #if defined(RF_EXP_WAVES)
 constexpr int      kWideWaves = RF_EXP_WAVES;                 // experiment builds: resident workgroups per CU of kTraceWide
@@ -498,6 +499,12 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
                         d[3 * (2 * k + j) + ax] = static_cast<uint32_t>(lower(lo[j][ax])) | (static_cast<uint32_t>(upper(hi[j][ax])) << 16);
             }
             d[12] = floatBits(q[6].x), d[13] = floatBits(q[6].y), d[14] = floatBits(q[6].z), d[15] = floatBits(q[6].w);
+            // an EMPTY slot (its child is a leaf and fills one slot only) holds an INVERTED box -- lower planes +65504, upper planes -65504 -- that no ray can pass: its
+            // near and far bounds are fma(+-65504, 1/d, b) with the same b, 131 008 |1/d| apart and the wrong way round, so `near <= far` fails whatever the origin.
+            // The step's hit test needs no `word != kQuadEmpty` for these records (kTraceWide, COMPACT == 4: two compares and two mask operations per step).
+            for (int e = 0; e < 4; ++e)
+                if (d[12 + e] == kQuadEmpty)
+                    for (int ax = 0; ax < 3; ++ax) d[3 * e + ax] = kHalfEmptyPlanes;
             for (int k = 0; k < 4; ++k) out.quadHalf[4 * r + k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
             for (int e = 0; e < 4 && ok; ++e)
             {
