@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
 #if defined(RF_EXP_SHADE_WAVES)
 #define RF_SHADE_BOUNDS __launch_bounds__(kBlock, RF_EXP_SHADE_WAVES)
 #else
-#define RF_SHADE_BOUNDS __launch_bounds__(kBlock) // (SORTED: 137 registers, three waves per SIMD; forced into 128 for four it is 2.5 % slower)
+#define RF_SHADE_BOUNDS __launch_bounds__(kBlock) // (SORTED: 154 registers -- 137 before the own-triangle test --, three waves per SIMD; forced into 128 for four it was 2.5 % slower)
 #endif
 template<bool SORTED>
 __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps, const uint32_t* queue,
