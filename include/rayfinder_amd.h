@@ -259,6 +259,13 @@ RF_API int  rf_comm_all_reduce_max(rf_comm* c, rf_renderer* r /* NULL: default s
 /* What RCCL reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice); any pointer may be NULL.
  * A scaling line that says N GPUs carries rccl_ranks == N from here. */
 RF_API int  rf_comm_info(const rf_comm* c, uint32_t* rccl_ranks, uint32_t* rccl_rank, int32_t* device_ordinal);
+/* *local_out = 1: the communicator runs on the LOCAL TEST TRANSPORT, not on RCCL.  With RF_COMM_TRANSPORT=local in the environment rf_comm_unique_id makes an
+ * id that rf_comm_create recognises: N communicators of ONE process (one host thread per rank, any number of them on one GPU) then execute the very plan
+ * rf_gather_plan lists -- same staging offsets, same un-tile kernel -- with each ncclSend / ncclRecv pair replaced by a device-to-device copy between the ranks'
+ * buffers.  It exists so that the multi-owner exchange runs on single-GPU boxes (RCCL refuses two ranks per device); rf_comm_info then reports the world the
+ * caller asked for, and THIS call is how a measurement proves it did not come from such a communicator.  No reference counterpart
+ * (single-device: reference_path_tracer.cpp:565-595). */
+RF_API int  rf_comm_transport(const rf_comm* c, uint32_t* local_out);
 /* Device time of this rank's LAST rf_renderer_gather_frame (HIP events on the handle's stream around the sends / receives and, on the root, the un-tile):
  * what the one exchange of the multi-GPU path costs once the rank's own frame has drained.  Waits for that exchange; -1 before the first.  (No reference
  * counterpart: the reference is single-device, reference_path_tracer.cpp:565-595.) */

@@ -391,6 +391,12 @@ class TileComm:
         check(lib.rf_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)))
         return dict(rccl_ranks=n.value, rccl_rank=r.value, device=d.value)
 
+    def local_transport(self):
+        """True: this communicator runs on the local TEST transport (RF_COMM_TRANSPORT=local when its id was made), not on RCCL."""
+        v = C.c_uint32(0)
+        check(lib.rf_comm_transport(self._h, C.byref(v)))
+        return bool(v.value)
+
     def last_exchange_ms(self):
         """Device time of this rank's last gather_frame (HIP events around the sends / receives + the root's un-tile); -1 before the first."""
         v = C.c_double(-1.0)

@@ -150,6 +150,7 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rf_build_bvh": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_int32)]),
     "rf_comm_last_exchange_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "rf_comm_transport": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_check_wide_layouts": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]),
     "rf_wide_layout_stats": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "rf_build_bvh_gpu": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -509,6 +509,15 @@ int rf_comm_info(const rf_comm* c, uint32_t* rccl_ranks, uint32_t* rccl_rank, in
     });
 }
 
+int rf_comm_transport(const rf_comm* c, uint32_t* local_out)
+{
+    return guarded([&] {
+        require(c && local_out, "null argument");
+        *local_out = c->impl->localTransport() ? 1u : 0u;
+        return RF_OK;
+    });
+}
+
 int rf_comm_last_exchange_ms(rf_comm* c, double* ms_out)
 {
     return guarded([&] {

@@ -6,10 +6,17 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <array>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <future>
+#include <map>
+#include <mutex>
+#include <random>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -118,6 +125,94 @@ std::vector<GatherOp> gatherPlan(const GatherLayout& g, uint32_t worldSize, uint
 
 namespace
 {
+// ------------------------------------------------------------------------------------------------
+// The LOCAL transport (round 6; a TEST transport, RF_COMM_TRANSPORT=local): the same exchange -- the same gatherPlan(), the same staging offsets, the same
+// kUntile -- with every ncclSend / ncclRecv pair replaced by a device-to-device copy between the buffers of N communicators that live in ONE process, one host
+// thread per rank.  RCCL refuses two ranks on one device, and the boxes this is developed on have one GPU: without this, TileComm::gatherFrame() and kUntile
+// had only ever executed with one owner (world 1: every tile `own`, or every tile staging in loop-back).  With it, worlds 2 / 3 / 4 / 8 run on one GPU: the
+// root's receives land at rankFirstTile[peer] of its staging area, kUntile picks own / staging per tile from tileOwner / tileSlot, and the image must equal
+// the single-rank one bit for bit (tests/test_gpu_parity.py: test_local_transport_gather_*).  What it does NOT exercise: RCCL itself and xGMI.
+//
+// Semantics mirror a group of point-to-point operations: a send is matched with the receive the peer posts for it, in posting order per (source,
+// destination); the receiver's stream waits for the sender's stream (an event recorded behind the sender's frame kernels), copies, and the sender's stream
+// waits for the copy before anything queued behind the exchange may touch the buffer again.  Host side a rank posts all its sends, then performs its
+// receives (each waits for its send to be posted), then waits until its sends have been taken -- dead-lock free for the gather (and for loop-back).  A
+// peer that never arrives is an error after RF_COMM_TIMEOUT_S, as with RCCL.
+// ------------------------------------------------------------------------------------------------
+constexpr char kLocalMagic[8] = {'R', 'F', 'L', 'O', 'C', 'A', 'L', '1'};
+
+struct LocalPost
+{
+    const void* src = nullptr;
+    size_t      bytes = 0;
+    int         srcDevice = 0;
+    hipEvent_t  ready = nullptr;    // recorded on the sender's stream behind everything queued before the exchange
+    hipEvent_t  consumed = nullptr; // recorded on the receiver's stream behind its copy (set when `taken`)
+    bool        taken = false;
+};
+
+struct LocalFabric
+{
+    uint32_t                world = 0;
+    std::mutex              mutex;
+    std::condition_variable cv;
+    std::map<std::pair<uint32_t, uint32_t>, std::deque<std::shared_ptr<LocalPost>>> mail; // (source, destination) -> sends not yet received, oldest first
+    std::vector<hipEvent_t> freeEvents, allEvents;
+    // allReduceMax: a generation barrier
+    uint64_t generation = 0;
+    uint32_t arrived = 0;
+    double   running = 0.0, result = 0.0;
+    uint32_t attached = 0;
+
+    hipEvent_t takeEvent() // (mutex held)
+    {
+        if (!freeEvents.empty())
+        {
+            hipEvent_t e = freeEvents.back();
+            freeEvents.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        allEvents.push_back(e);
+        return e;
+    }
+    ~LocalFabric()
+    {
+        for (hipEvent_t e : allEvents) (void)hipEventDestroy(e);
+    }
+};
+
+std::mutex                                                                    gFabricMutex;
+std::map<std::array<uint8_t, kCommIdBytes>, std::weak_ptr<LocalFabric>>        gFabrics;
+
+bool localTransportRequested()
+{
+    const char* v = std::getenv("RF_COMM_TRANSPORT");
+    return v != nullptr && std::strcmp(v, "local") == 0;
+}
+bool isLocalId(const uint8_t id[kCommIdBytes]) { return std::memcmp(id, kLocalMagic, sizeof kLocalMagic) == 0; }
+
+std::shared_ptr<LocalFabric> attachFabric(const uint8_t id[kCommIdBytes], uint32_t world)
+{
+    std::array<uint8_t, kCommIdBytes> key;
+    std::memcpy(key.data(), id, kCommIdBytes);
+    std::lock_guard<std::mutex> lock(gFabricMutex);
+    std::shared_ptr<LocalFabric> f = gFabrics[key].lock();
+    if (!f)
+    {
+        f = std::make_shared<LocalFabric>();
+        f->world = world;
+        gFabrics[key] = f;
+    }
+    if (f->world != world) throw std::runtime_error("local transport: the ranks of one id disagree about the world size");
+    for (auto it = gFabrics.begin(); it != gFabrics.end();) it = it->second.expired() ? gFabrics.erase(it) : std::next(it);
+    return f;
+}
+} // namespace
+
+namespace
+{
 // seconds a rank waits for its peers in ncclCommInitRank and in its FIRST gather before it gives up with an error
 // instead of hanging (a missing rank, a wrong id, a dead xGMI link); RF_COMM_TIMEOUT_S overrides, 0 = wait forever
 double commTimeoutSeconds()
@@ -130,6 +225,7 @@ double commTimeoutSeconds()
 struct TileComm::Impl
 {
     ncclComm_t comm = nullptr;
+    std::shared_ptr<LocalFabric> fabric; // the local (test) transport instead of RCCL: see LocalFabric
     uint32_t   rank = 0, world = 1;
     int        device = 0;
 
@@ -165,6 +261,14 @@ struct TileComm::Impl
 void TileComm::uniqueId(uint8_t out[kCommIdBytes])
 {
     static_assert(sizeof(ncclUniqueId) == kCommIdBytes);
+    if (localTransportRequested())
+    {
+        // the local transport's ids carry a magic prefix (TileComm's constructor recognises them whatever the environment says by then) + 120 random bytes
+        std::memcpy(out, kLocalMagic, sizeof kLocalMagic);
+        std::random_device rd;
+        for (uint32_t i = sizeof kLocalMagic; i < kCommIdBytes; ++i) out[i] = static_cast<uint8_t>(rd());
+        return;
+    }
     ncclUniqueId id;
     RF_NCCL(ncclGetUniqueId(&id));
     std::memcpy(out, &id, kCommIdBytes);
@@ -180,6 +284,11 @@ TileComm::TileComm(const uint8_t idBytes[kCommIdBytes], uint32_t rank, uint32_t 
     mImpl->world = worldSize;
     mImpl->device = deviceOrdinal;
     RF_HIP(hipSetDevice(deviceOrdinal));
+    if (isLocalId(idBytes))
+    {
+        mImpl->fabric = attachFabric(idBytes, worldSize); // (not collective: a rank's peers are waited for in the exchange itself)
+        return;
+    }
     ncclUniqueId id;
     std::memcpy(&id, idBytes, kCommIdBytes);
     // ncclCommInitRank blocks until every rank of the world has called it.  It runs on a helper thread so that a rank whose
@@ -222,8 +331,15 @@ uint32_t TileComm::rank() const { return mImpl->rank; }
 uint32_t TileComm::worldSize() const { return mImpl->world; }
 int      TileComm::deviceOrdinal() const { return mImpl->device; }
 
+bool TileComm::localTransport() const { return mImpl->fabric != nullptr; }
+
 void TileComm::rcclInfo(uint32_t& count, uint32_t& userRank, int& device) const
 {
+    if (mImpl->fabric)
+    {
+        count = mImpl->world, userRank = mImpl->rank, device = mImpl->device; // (no RCCL communicator behind it: localTransport() says so)
+        return;
+    }
     int c = 0, r = 0, d = 0;
     RF_NCCL(ncclCommCount(mImpl->comm, &c));
     RF_NCCL(ncclCommUserRank(mImpl->comm, &r));
@@ -234,7 +350,7 @@ void TileComm::rcclInfo(uint32_t& count, uint32_t& userRank, int& device) const
 const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uint32_t height, uint32_t root, void* streamHandle, bool loopback)
 {
     Impl& m = *mImpl;
-    if (m.comm == nullptr) throw std::runtime_error("the RCCL communicator was aborted");
+    if (m.comm == nullptr && !m.fabric) throw std::runtime_error("the RCCL communicator was aborted");
     if (root >= m.world) throw std::invalid_argument("gather root out of range");
     if (width == 0 || height == 0) throw std::invalid_argument("empty frame");
     hipStream_t stream = static_cast<hipStream_t>(streamHandle);
@@ -280,6 +396,79 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
     }
     m.exchangeTimed = false;
     RF_HIP(hipEventRecord(m.exchangeStart, stream));
+    if (m.fabric)
+    {
+        // ---- the local transport: the plan's operations as device-to-device copies between the ranks' buffers (see LocalFabric)
+        LocalFabric&  f = *m.fabric;
+        const double  timeout = commTimeoutSeconds();
+        const auto    waitFor = [&](std::unique_lock<std::mutex>& lock, auto&& ready, const char* what) {
+            if (timeout > 0.0)
+            {
+                if (!f.cv.wait_for(lock, std::chrono::duration<double>(timeout), ready))
+                    throw std::runtime_error(std::string("local transport: ") + what + " did not happen within " + std::to_string(static_cast<int>(timeout)) + " s on rank " +
+                                             std::to_string(m.rank) + " (a peer is missing or disagrees about frame size / root)");
+            }
+            else f.cv.wait(lock, ready);
+        };
+        std::vector<std::shared_ptr<LocalPost>> mine;
+        for (const GatherOp& op : plan) // 1. post every send
+        {
+            if (!op.isSend) continue;
+            auto post = std::make_shared<LocalPost>();
+            post->src = static_cast<const float*>(compactDevice) + op.offsetTiles * floatsPerTile;
+            post->bytes = op.countTiles * floatsPerTile * sizeof(float);
+            post->srcDevice = m.device;
+            {
+                std::lock_guard<std::mutex> lock(f.mutex);
+                post->ready = f.takeEvent();
+            }
+            RF_HIP(hipEventRecord(post->ready, stream));
+            {
+                std::lock_guard<std::mutex> lock(f.mutex);
+                f.mail[{m.rank, op.peer}].push_back(post);
+            }
+            f.cv.notify_all();
+            mine.push_back(post);
+        }
+        for (const GatherOp& op : plan) // 2. every receive: wait for the peer's send, copy behind it
+        {
+            if (op.isSend) continue;
+            std::shared_ptr<LocalPost> post;
+            {
+                std::unique_lock<std::mutex> lock(f.mutex);
+                auto&                        box = f.mail[{op.peer, m.rank}];
+                waitFor(lock, [&] { return !box.empty(); }, "a peer's send");
+                post = box.front();
+                box.pop_front();
+                post->consumed = f.takeEvent();
+            }
+            if (post->bytes != op.countTiles * floatsPerTile * sizeof(float))
+                throw std::runtime_error("local transport: rank " + std::to_string(op.peer) + " sends " + std::to_string(post->bytes) + " bytes, rank " + std::to_string(m.rank) + " expects " +
+                                         std::to_string(op.countTiles * floatsPerTile * sizeof(float)) + " (the ranks disagree about the frame)");
+            RF_HIP(hipStreamWaitEvent(stream, post->ready, 0));
+            RF_HIP(hipMemcpyAsync(m.staging.p + static_cast<size_t>(op.offsetTiles) * kTilePixels, post->src, post->bytes, hipMemcpyDeviceToDevice, stream));
+            RF_HIP(hipEventRecord(post->consumed, stream));
+            {
+                std::lock_guard<std::mutex> lock(f.mutex);
+                post->taken = true;
+            }
+            f.cv.notify_all();
+        }
+        for (const std::shared_ptr<LocalPost>& post : mine) // 3. my sends: the buffer is mine again once the receiver's copy has run
+        {
+            {
+                std::unique_lock<std::mutex> lock(f.mutex);
+                waitFor(lock, [&] { return post->taken; }, "the root's receive");
+            }
+            RF_HIP(hipStreamWaitEvent(stream, post->consumed, 0));
+            std::lock_guard<std::mutex> lock(f.mutex);
+            f.freeEvents.push_back(post->ready);
+            f.freeEvents.push_back(post->consumed);
+        }
+        m.firstGatherDone = true;
+    }
+    else
+    {
     RF_NCCL(ncclGroupStart());
     try
     {
@@ -350,6 +539,7 @@ const void* TileComm::gatherFrame(const void* compactDevice, uint32_t width, uin
         }
         m.firstGatherDone = true;
     }
+    } // (RCCL transport)
     if (!isRoot)
     {
         RF_HIP(hipEventRecord(m.exchangeStop, stream));
@@ -392,6 +582,31 @@ double TileComm::allReduceMax(double value, void* streamHandle)
     Impl&       m = *mImpl;
     hipStream_t stream = static_cast<hipStream_t>(streamHandle);
     RF_HIP(hipSetDevice(m.device));
+    if (m.fabric)
+    {
+        // local transport: a generation barrier over the fabric's ranks (host side; the caller's stream is drained first, as the RCCL path's read-back does)
+        RF_HIP(hipStreamSynchronize(stream));
+        LocalFabric&                 f = *m.fabric;
+        std::unique_lock<std::mutex> lock(f.mutex);
+        const uint64_t               gen = f.generation;
+        f.running = f.arrived == 0 ? value : std::max(f.running, value);
+        if (++f.arrived == f.world)
+        {
+            f.result = f.running;
+            f.arrived = 0;
+            ++f.generation;
+            f.cv.notify_all();
+            return f.result;
+        }
+        const double timeout = commTimeoutSeconds();
+        const auto   released = [&] { return f.generation != gen; };
+        if (timeout > 0.0)
+        {
+            if (!f.cv.wait_for(lock, std::chrono::duration<double>(timeout), released)) throw std::runtime_error("local transport: all-reduce timed out on rank " + std::to_string(m.rank));
+        }
+        else f.cv.wait(lock, released);
+        return f.result;
+    }
     m.scalar.ensure(2);
     RF_HIP(hipMemcpyAsync(m.scalar.p, &value, sizeof value, hipMemcpyHostToDevice, stream));
     RF_NCCL(ncclAllReduce(m.scalar.p, m.scalar.p + 1, 1, ncclDouble, ncclMax, m.comm, stream));

@@ -58,6 +58,9 @@ public:
     // What RCCL itself reports for this communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): proof of how
     // many ranks the exchange really spans.
     void rcclInfo(uint32_t& count, uint32_t& userRank, int& device) const;
+    // true: this communicator runs on the LOCAL test transport (RF_COMM_TRANSPORT=local when its id was made: N ranks in one process, one host thread each,
+    // ncclSend / ncclRecv replaced by device-to-device copies -- the same plan, staging offsets and un-tile; rf_comm.hip), not on RCCL
+    bool localTransport() const;
 
     // Frame-end exchange, enqueued on `stream` (a hipStream_t: the renderer's, so the exchange is ordered behind
     // the frame's kernels).  compactDevice: this rank's tile-major buffer (tilesForRank(...).size() * 1024 float4).

@@ -368,6 +368,17 @@ __device__ __forceinline__ float wPow15(float x)
 }
 __device__ __forceinline__ float wFract(float x) { return x - floorf(x); }
 
+// ---- round 6: the OPT-IN f32 evaluation of the same builtins (renderer option `transcendentals` = 1).  WGSL's own sin / cos / acos / exp / pow are f32 with
+// implementation-defined accuracy (wgsl:247-275,568-616 call them): the specified-f64 evaluation above is one documented choice that makes GPU == oracle
+// bit for bit, not the only legitimate one.  This mode calls the device math library's f32 functions (ocml: sinf / cosf within 2 ulp, acosf / expf within 1-2,
+// powf within 1 ulp -- "libm-grade", NOT the __sinf / __expf fast intrinsics) and is graded by SURVEY 8(d)'s stated tolerance against the oracle instead of
+// bit-identity (tests/test_gpu_parity.py: test_f32_transcendentals_mode_within_the_stated_tolerance).  The default stays the specified f64 evaluation.
+template<bool F32> __device__ __forceinline__ float tSin(float x) { if constexpr (F32) return sinf(x); else return wSin(x); }
+template<bool F32> __device__ __forceinline__ float tCos(float x) { if constexpr (F32) return cosf(x); else return wCos(x); }
+template<bool F32> __device__ __forceinline__ float tAcos(float x) { if constexpr (F32) return acosf(x); else return wAcos(x); }
+template<bool F32> __device__ __forceinline__ float tExp(float x) { if constexpr (F32) return expf(x); else return wExp(x); }
+template<bool F32> __device__ __forceinline__ float tPow15(float x) { if constexpr (F32) return powf(x, 1.5f); else return wPow15(x); }
+
 constexpr float kPi = 3.1415927f;       // wgsl:68
 constexpr float kFrac1Pi = 0.31830987f; // wgsl:69
 constexpr float kTMax = 10000.0f;       // wgsl:73
@@ -393,17 +404,18 @@ __device__ __forceinline__ Vec3 basisTimes(Vec3 c0, Vec3 c1, Vec3 c2, Vec3 v)
 
 // wgsl:247-275 (sky dome only; the solar disk is reached through next-event estimation).  cosTheta = |cos(theta)| and
 // cosGamma = cos(gamma) are the same for the three channels: the caller evaluates them once (identical values).
+template<bool F32 = false>
 __device__ __forceinline__ float skyRadiance(const SkyStateGpu& sky, float cosTheta, float gamma, float cosGamma, int channel)
 {
     const float  r = sky.skyRadiances[channel];
     const float* p = sky.params + 9 * channel;
     const float  cosGamma2 = cosGamma * cosGamma;
-    const float  expM = wExp(p[4] * gamma);
+    const float  expM = tExp<F32>(p[4] * gamma);
     const float  mieLhs = 1.0f + cosGamma2;
-    const float  mieRhs = wPow15(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma);
+    const float  mieRhs = tPow15<F32>(1.0f + p[8] * p[8] - 2.0f * p[8] * cosGamma);
     const float  mie = mieLhs / mieRhs;
     const float  zenith = rf_sqrt(cosTheta);
-    const float  lhs = 1.0f + p[0] * wExp(p[1] / (cosTheta + 0.01f));
+    const float  lhs = 1.0f + p[0] * tExp<F32>(p[1] / (cosTheta + 0.01f));
     const float  rhs = p[2] + p[3] * expM + p[5] * cosGamma2 + p[6] * mie + p[7] * zenith;
     return r * (lhs * rhs);
 }

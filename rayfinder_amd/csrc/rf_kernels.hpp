@@ -380,9 +380,9 @@ IntersectRaysKernel   intersectRaysKernel();
 OccludedRaysKernel    occludedRaysKernel();
 // rf_shade.hip
 SamplePermutationKernel samplePermutationKernel();
-RaygenKernel            raygenKernel();
+RaygenKernel            raygenKernel(bool f32Transcendentals);
 ShadeKernel             shadeKernel(bool sorted);
-SkyKernel               skyKernel();
+SkyKernel               skyKernel(bool f32Transcendentals);
 BounceTotalsKernel      bounceTotalsKernel();
 AccumulateKernel        accumulateKernel();
 AccumulateRunsKernel    accumulateRunsKernel();

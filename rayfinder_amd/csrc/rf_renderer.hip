@@ -210,6 +210,7 @@ struct Renderer::Impl
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
+    bool     optTranscendentalsF32 = false; // option `transcendentals`: kRaygen / kSky call the f32 math library instead of the specified f64 evaluation (opt-in)
     bool     optShadowSelfTest = true; // kShade tests every shadow ray against the triangle it starts on first (kShadeSelfShadow); needs selfShadowOk
     bool     selfShadowOk = false;     // the tree's boxes are nested and regular, and the shading records carry their triangles' leaf boxes
     bool     optConstPrimaryOrigin = true; // a pinhole camera's primary launch takes its one origin as a kernel argument (kFlagConstOrigin): kRaygen writes no origins
@@ -683,7 +684,7 @@ struct Renderer::Impl
             hipLaunchKernelGGL(samplePermutationKernel(), dim3((numSamples + 255) / 256), dim3(256), 0, stream, firstFrame, fp.samplesPerPixel, numSamples,
                                const_cast<uint32_t*>(fp.samplePerm), const_cast<uint32_t*>(fp.sampleInvPerm));
         launchTimed(0, [&] {
-            hipLaunchKernelGGL(raygenKernel(), dim3(itemBlocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
+            hipLaunchKernelGGL(raygenKernel(optTranscendentalsF32), dim3(itemBlocks), dim3(kBlock), 0, stream, fp, scene, tileIds.ptr, ps, qIn, queueCounts.ptr, counters.ptr);
         });
         const dim3 persistentGrid(std::min(blocks, wideBlocks));
         for (uint32_t bounce = 1; bounce <= numBounces; ++bounce)
@@ -736,7 +737,7 @@ struct Renderer::Impl
                 // the paths that left the scene at this bounce, while its direction / throughput arrays are intact
                 // (its slot comes with the miss list: kSky reads nothing of the bounce's queue -- round 5: reading the slot through the queue position was a third
                 // dependent gather, and kShade + kSky went from 19.7 to 15.8 ms per 64 spp without it)
-                hipLaunchKernelGGL(skyKernel(), dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, missSlots.ptr, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
+                hipLaunchKernelGGL(skyKernel(optTranscendentalsF32), dim3(std::min(blocks, skyBlocks)), dim3(kBlock), 0, stream, sky, ps, missSlots.ptr, missQueue.ptr, missCount, bounce == 1 ? 1u : 0u);
             });
             // occluder cache (kTraceWide, kFlagOccluderCache): the conservative-record any-hit launches of bounces 1..optOccluderCacheBounces; their rays are
             // short (a third of the steps), so the deep launches refill earlier
@@ -1431,6 +1432,9 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
     else if (name == "const_primary_origin") mImpl->optConstPrimaryOrigin = value != 0;
     else if (name == "shadow_self_test") mImpl->optShadowSelfTest = value != 0;
+    // 0 (default): sin / cos / acos / exp / pow as the f32 rounding of a specified f64 evaluation (bit-identical to the oracle); 1: the device math library's f32 functions
+    // (kRaygen's lens / cone angle, kSky's dome: rf_device.hpp tSin ...), graded by SURVEY 8(d)'s tolerance.  Set it before the first sample of an accumulation.
+    else if (name == "transcendentals") mImpl->optTranscendentalsF32 = value != 0;
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;

@@ -25,6 +25,8 @@ __global__ void kSamplePermutation(uint32_t firstFrame, uint32_t spp, uint32_t n
 }
 
 // ------------------------------------------------------------------------------------------------
+// F32: the opt-in f32 evaluation of sin / cos (renderer option `transcendentals`, rf_device.hpp: tSin / tCos); default: the specified f64 evaluation
+template<bool F32>
 __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene scene, const uint32_t* tileIds, PathStreams ps,
                                                    uint32_t* queue, uint32_t* queueCount, DeviceCounters* counters)
 {
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
         const float t = (1.0f - v) + ny / static_cast<float>(fp.height);
 
         const float phi = 2.0f * kPi * ny;
-        const float cosPhi = wCos(phi), sinPhi = wSin(phi);
+        const float cosPhi = tCos<F32>(phi), sinPhi = tSin<F32>(phi);
         const float r = rf_sqrt(nx);
         const float lensX = fp.camera.lensRadius * (r * cosPhi);
         const float lensY = fp.camera.lensRadius * (r * sinPhi);
@@ -429,6 +431,8 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
 // after kShade, while the bounce's direction / throughput arrays and its queue are still intact.  All NEE terms of the path
 // have been added by then (the shadow launch of the previous bounce is complete).  Grid-stride: the list length is only
 // known on the device, and a worst-case grid of empty workgroups per bounce would cost more than the work.
+// (F32: see kRaygen)
+template<bool F32>
 __global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, const uint32_t* missSlots, const uint32_t* missQueue, const uint32_t* missCount,
                                                 uint32_t firstBounce)
 {
@@ -445,11 +449,11 @@ __global__ __launch_bounds__(kBlock) void kSky(SkyStateGpu sky, PathStreams ps, 
         const Vec3     thr = first ? vec3(1.0f, 1.0f, 1.0f) : thrIn;
         const Vec3     rad = first ? vec3(0.0f, 0.0f, 0.0f) : radIn;
         const Vec3     s = vec3(sky.sunDirection[0], sky.sunDirection[1], sky.sunDirection[2]);
-        const float    theta = wAcos(v.y);
-        const float    gamma = wAcos(minf(maxf(dot(v, s), -1.0f), 1.0f));
+        const float    theta = tAcos<F32>(v.y);
+        const float    gamma = tAcos<F32>(minf(maxf(dot(v, s), -1.0f), 1.0f));
         // cos(gamma) and |cos(theta)| do not depend on the channel: evaluated once instead of three times (same values)
-        const float cosGamma = wCos(gamma), cosTheta = fabsf(wCos(theta));
-        const Vec3  dome = vec3(skyRadiance(sky, cosTheta, gamma, cosGamma, 0), skyRadiance(sky, cosTheta, gamma, cosGamma, 1), skyRadiance(sky, cosTheta, gamma, cosGamma, 2));
+        const float cosGamma = tCos<F32>(gamma), cosTheta = fabsf(tCos<F32>(theta));
+        const Vec3  dome = vec3(skyRadiance<F32>(sky, cosTheta, gamma, cosGamma, 0), skyRadiance<F32>(sky, cosTheta, gamma, cosGamma, 1), skyRadiance<F32>(sky, cosTheta, gamma, cosGamma, 2));
         const Vec3  radiance = rad + thr * dome;
         ps.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     }
@@ -732,9 +736,9 @@ __global__ __launch_bounds__(kBlock) void kDeferredLighting(DeviceScene scene, S
 namespace kern
 {
 SamplePermutationKernel samplePermutationKernel() { return kSamplePermutation; }
-RaygenKernel            raygenKernel() { return kRaygen; }
+RaygenKernel            raygenKernel(bool f32) { return f32 ? kRaygen<true> : kRaygen<false>; }
 ShadeKernel             shadeKernel(bool sorted) { return sorted ? kShade<true> : kShade<false>; }
-SkyKernel               skyKernel() { return kSky; }
+SkyKernel               skyKernel(bool f32) { return f32 ? kSky<true> : kSky<false>; }
 BounceTotalsKernel      bounceTotalsKernel() { return kBounceTotals; }
 AccumulateKernel        accumulateKernel() { return kAccumulate; }
 AccumulateRunsKernel    accumulateRunsKernel() { return kAccumulateRuns; }
