@@ -72,11 +72,11 @@ class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("closest_node_visits", C.c_uint64), ("closest_triangle_tests", C.c_uint64),
                 ("shadow_node_visits", C.c_uint64), ("shadow_triangle_tests", C.c_uint64), ("paths", C.c_uint64),
-                ("stack_high_water", C.c_uint32), ("reserved", C.c_uint32),
+                ("stack_high_water", C.c_uint32), ("batch_samples_used", C.c_uint32),
                 ("ms_raygen", C.c_double), ("ms_closest", C.c_double), ("ms_shade", C.c_double), ("ms_shadow", C.c_double),
                 ("ms_accumulate", C.c_double),
                 ("launches_raygen", C.c_uint32), ("launches_closest", C.c_uint32), ("launches_shade", C.c_uint32),
-                ("launches_shadow", C.c_uint32), ("launches_accumulate", C.c_uint32), ("reserved2", C.c_uint32),
+                ("launches_shadow", C.c_uint32), ("launches_accumulate", C.c_uint32), ("batches_traced", C.c_uint32),
                 ("closest_record_fetches", C.c_uint64), ("shadow_record_fetches", C.c_uint64),
                 ("abandoned_rays", C.c_uint64), ("scalar_redo_rays", C.c_uint64), ("shadow_rays_hint_answered", C.c_uint64), ("shadow_rays_self_answered", C.c_uint64)]
 

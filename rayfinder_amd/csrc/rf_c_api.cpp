@@ -308,6 +308,8 @@ int rf_renderer_get_stats(rf_renderer* r, rf_stats* out)
         out->shadow_triangle_tests = s.shadowTriangleTests;
         out->paths = s.paths;
         out->stack_high_water = s.stackHighWater;
+        out->batch_samples_used = s.batchSamplesUsed;
+        out->batches_traced = s.batchesTraced;
         out->ms_raygen = s.msRaygen;
         out->ms_closest = s.msClosest;
         out->ms_shade = s.msShade;

@@ -369,9 +369,9 @@ __device__ __forceinline__ float wPow15(float x)
 __device__ __forceinline__ float wFract(float x) { return x - floorf(x); }
 
 // ---- round 6: the OPT-IN f32 evaluation of the same builtins (renderer option `transcendentals` = 1).  WGSL's own sin / cos / acos / exp / pow are f32 with
-// implementation-defined accuracy (wgsl:247-275,568-616 call them): the specified-f64 evaluation above is one documented choice that makes GPU == oracle
+// implementation-defined accuracy (wgsl:247-275,568-616 call them): the specified-f64 evaluation above is one documented choice that makes GPU == test oracle
 // bit for bit, not the only legitimate one.  This mode calls the device math library's f32 functions (ocml: sinf / cosf within 2 ulp, acosf / expf within 1-2,
-// powf within 1 ulp -- "libm-grade", NOT the __sinf / __expf fast intrinsics) and is graded by SURVEY 8(d)'s stated tolerance against the oracle instead of
+// powf within 1 ulp -- "libm-grade", NOT the __sinf / __expf fast intrinsics) and is graded by SURVEY 8(d)'s stated tolerance against the test oracle instead of
 // bit-identity (tests/test_gpu_parity.py: test_f32_transcendentals_mode_within_the_stated_tolerance).  The default stays the specified f64 evaluation.
 template<bool F32> __device__ __forceinline__ float tSin(float x) { if constexpr (F32) return sinf(x); else return wSin(x); }
 template<bool F32> __device__ __forceinline__ float tCos(float x) { if constexpr (F32) return cosf(x); else return wCos(x); }

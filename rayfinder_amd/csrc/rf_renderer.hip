@@ -162,6 +162,7 @@ struct Renderer::Impl
     uint64_t                validPixels = 0;     // pixels of this rank's tiles that lie inside the frame
     unsigned long long      primaryRaysHost = 0; // samples traced x validPixels since the last resetStats()
     uint64_t                maxPaths = 0;
+    DeviceBuffer<P3>        sRayInv; // round 6, option `inv_stream`: 1 / direction of the bounce rays by queue position (PathStreams::rayInv); allocated with the rest of the path state
     DeviceBuffer<P3>        sRayO, sRayD, sRayD2, sThr, sThr2, sPending, sNoise, sNoise2; // queue-position arrays, packed xyz; rayD / thr / noise: double-buffered (PathStreams)
     DeviceBuffer<float4>    sRad, sHit;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, missSlots, shadowList, queueCounts; // shadowList: kShade's list of the shadow rays its own-triangle test has not settled (kShadeSelfShadow)
@@ -204,12 +205,14 @@ struct Renderer::Impl
     uint32_t maxLeafTriangles = 0; // of the scene (upload): scenes without a leaf as long as the threshold run the instantiations WITHOUT the dense block
     uint32_t optShadeSortFromBounce = 2, sortScale = 0;         // kShade of bounce >= this appends its tile's hits in triangle order (0: never)
     uint32_t optChunkEarly = 256, optChunkEarlyBounces = 2;      // queue entries per cursor claim at bounces 1-2
-    uint32_t optRefillMinDeep = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 2; // closest-hit launches of bounce >= 2 (3 until the eager-leaves schedule: bounce 2 -2.6 % with it) refill at another count: 22 idle lanes on the 64-byte and the
+    uint32_t optRefillMinDeep = 12, optRefillMinDeepDense = 22, optRefillMinDeepQuad = 40, optRefillDeepFromBounce = 2; // closest-hit launches of bounce >= 2 (3 until the eager-leaves schedule: bounce 2 -2.6 % with it) refill at another count: 12 idle lanes (22 until round 6: with the
+                                                                                             // refill trip's claim logic on the scalar unit and its one-test classification, 16 ... 4 measure the same and 1.3 % under 22: profiles/r06_lanes) on the 64-byte and the
                                                                                              // half-precision quad records (VALU bound: idle lanes cost most), 40 on the exact quad records (L1 bound: a refill is a wave-wide stall)
     // kShade grid cap (0: one workgroup per tile of 1024 entries, the default: workgroups then append to the hit queue in
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
+    bool     optInvStream = false; // kShade writes 1 / direction of the bounce rays, the closest-hit refill reads it instead of dividing (PathStreams::rayInv)
     bool     optTranscendentalsF32 = false; // option `transcendentals`: kRaygen / kSky call the f32 math library instead of the specified f64 evaluation (opt-in)
     bool     optShadowSelfTest = true; // kShade tests every shadow ray against the triangle it starts on first (kShadeSelfShadow); needs selfShadowOk
     bool     selfShadowOk = false;     // the tree's boxes are nested and regular, and the shading records carry their triangles' leaf boxes
@@ -267,12 +270,13 @@ struct Renderer::Impl
     uint64_t allocatedPaths = 0;
     uint64_t effectivePaths = 0;       // batch depth the last render() call ended up with (<= maxPaths: less when less memory was free THEN)
 
-    // bytes of path state + queues per path slot (eight packed xyz streams, two float4 streams, four u32 queues / lists)
-    static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 5 * sizeof(uint32_t);
+    // bytes of path state + queues per path slot (nine packed xyz streams, two float4 streams, five u32 queues / lists): 160
+    static constexpr uint64_t kBytesPerPath = 9 * sizeof(P3) + 2 * sizeof(float4) + 5 * sizeof(uint32_t);
 
     void releasePathState()
     {
         sRayO.release(), sRayD.release(), sRayD2.release(), sThr.release(), sThr2.release(), sRad.release(), sHit.release();
+        sRayInv.release();
         sPending.release(), sNoise.release(), sNoise2.release(), queueA.release(), queueB.release(), missQueue.release(), missSlots.release(), shadowList.release();
         allocatedPaths = 0;
     }
@@ -300,7 +304,7 @@ struct Renderer::Impl
             return true;
         };
         const bool ok = tryAlloc(sRayO, paths) && tryAlloc(sRayD, paths) && tryAlloc(sRayD2, paths) && tryAlloc(sThr, paths) && tryAlloc(sThr2, paths) &&
-                        tryAlloc(sRad, paths) && tryAlloc(sHit, paths) && tryAlloc(sPending, paths) && tryAlloc(sNoise, paths) && tryAlloc(sNoise2, paths) &&
+                        tryAlloc(sRad, paths) && tryAlloc(sHit, paths) && tryAlloc(sPending, paths) && tryAlloc(sNoise, paths) && tryAlloc(sNoise2, paths) && tryAlloc(sRayInv, paths) &&
                         tryAlloc(queueA, paths) && tryAlloc(queueB, paths) && tryAlloc(missQueue, paths) && tryAlloc(missSlots, paths) && tryAlloc(shadowList, paths);
         if (!ok)
         {
@@ -539,7 +543,7 @@ struct Renderer::Impl
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
         const uint32_t count = static_cast<uint32_t>(n);
         RF_HIP(hipMemcpyAsync(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice, stream));
-        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
+        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr, nullptr};
         const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
         const WideArgs wa{ps, queueA.ptr, queueCounts.ptr, queueCounts.ptr + kLineWords, optRefillMin, optChunk, tMax, grid, 0u};
         if (shadow)
@@ -555,6 +559,20 @@ struct Renderer::Impl
         }
         else
         {
+            // RF_DEBUG_QUERY_LIST=<file of n u32>: (read and uploaded BEFORE the timed span) the launch visits the rays in the order of that list (queue POSITIONS, as the any-hit launches behind kShadowFirstLook do) while
+            // the rays stay where they are -- what a global order of a bounce's rays costs when only an index list is sorted (tools/gpu_sort_potential.py --indirect)
+            WideScene wq = wide;
+            wq.rayList = nullptr;
+            if (const char* listPath = std::getenv("RF_DEBUG_QUERY_LIST"))
+            {
+                std::vector<uint32_t> list(n);
+                FILE* f = std::fopen(listPath, "rb");
+                if (f == nullptr || std::fread(list.data(), sizeof(uint32_t), n, f) != n) throw std::runtime_error("RF_DEBUG_QUERY_LIST: cannot read the ray list");
+                std::fclose(f);
+                RF_HIP(hipMemcpyAsync(queueB.ptr, list.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                RF_HIP(hipStreamSynchronize(stream));
+                wq.rayList = queueB.ptr;
+            }
             // RF_DEBUG_QUERY_MS: the traversal launch alone between two events (tools/gpu_sort_potential.py: what would an order of the rays be worth?)
             const bool timed = std::getenv("RF_DEBUG_QUERY_MS") != nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -564,7 +582,7 @@ struct Renderer::Impl
                 RF_HIP(hipEventCreate(&e1));
                 RF_HIP(hipEventRecord(e0, stream));
             }
-            launchClosestWide(layoutIfPresent(optQueryCompact), false, wide, wa, denseFlag);
+            launchClosestWide(layoutIfPresent(optQueryCompact), false, wq, wa, denseFlag);
             if (timed) RF_HIP(hipEventRecord(e1, stream));
             hipLaunchKernelGGL(hitPointsKernel(), dim3((count + 255) / 256), dim3(256), 0, stream, scene, sHit.ptr, sRayO.ptr, count);
             if (timed)
@@ -630,7 +648,7 @@ struct Renderer::Impl
         const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
         primaryRaysHost += static_cast<unsigned long long>(numSamples) * validPixels;
         // bounce b reads direction / throughput from buffer (b - 1) & 1 and kShade writes the next bounce's into the other one
-        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
+        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr, optInvStream ? sRayInv.ptr : nullptr};
         const uint32_t numBounces = fp.numBounces;
 
         wide.occGrid = nullptr;
@@ -702,8 +720,11 @@ struct Renderer::Impl
             const uint32_t chunkNow = bounce <= optChunkEarlyBounces ? optChunkEarly : optChunk;
             const int      layoutClosest = closestLayoutFor(bounce);
             const bool     conservativeClosest = layoutClosest == kLayoutOct || layoutClosest == kLayoutQuadHalf || layoutClosest == kLayoutQuadLocal;
-            const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (layoutClosest == kLayoutQuad ? optRefillMinDeepQuad : optRefillMinDeep) : optRefillMin;
+            // (scenes with long leaves -- the DENSE_LEAVES instantiations -- keep 22: a phase over dense (lane, triangle) pairs wants many parked lanes; clutter atrium +2.4 % at 12: profiles/r06_lanes)
+            const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (layoutClosest == kLayoutQuad ? optRefillMinDeepQuad : (denseWanted(uniformFlag) ? optRefillMinDeepDense : optRefillMinDeep)) : optRefillMin;
             (void)conservativeClosest;
+            // (option `inv_stream`) kShade of the bounce before wrote 1 / direction next to the direction: the wide closest-hit launches from bounce 2 on read it
+            const bool invFromStream = optInvStream && bounce >= 2u && !counting && layoutClosest != kLayoutScalar && layoutClosest != kLayoutPacket;
             launchTimed(1, [&] {
                 if (layoutClosest == kLayoutScalar)
                 {
@@ -718,17 +739,18 @@ struct Renderer::Impl
 #endif
                 else
                     launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds},
-                                      uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u));
+                                      uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u) | (invFromStream ? kFlagInvFromStream : 0u));
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
             // kShade's own-triangle test of the shadow rays (kShadeSelfShadow): wherever this bounce's any-hit launch is one that can work through a list of queue positions
             // (the kTraceWide instantiations with the occluder-cache code: quad / half / local-grid records) and nothing has to be counted node by node
             const int      layoutShadow = shadowLayoutFor(bounce);
-            const bool     selfShadow = optShadowSelfTest && selfShadowOk && !counting && (layoutShadow == kLayoutQuad || layoutShadow == kLayoutQuadHalf || layoutShadow == kLayoutQuadLocal);
+            // (bounce <= 64: kBounceTotals keeps one mask bit per bounce -- as for firstLook below; deeper bounces trace every shadow ray and count them in the launch: ADVICE r5)
+            const bool     selfShadow = optShadowSelfTest && selfShadowOk && !counting && bounce <= 64u && (layoutShadow == kLayoutQuad || layoutShadow == kLayoutQuadHalf || layoutShadow == kLayoutQuadLocal);
             uint32_t* const shadowListCount = shadowListCounts + kLine * (bounce - 1);
             if (selfShadow) selfMask |= 1ull << (bounce - 1);
             launchTimed(2, [&] {
-                const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u) | (selfShadow ? kShadeSelfShadow : 0u);
+                const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u) | (selfShadow ? kShadeSelfShadow : 0u) | (optInvStream && bounce < numBounces ? kShadeWriteInv : 0u);
                 const dim3     shadeGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
                 if (optShadeSortFromBounce != 0u && bounce >= optShadeSortFromBounce)
                     hipLaunchKernelGGL(shadeKernel(true), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missSlots.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, sortScale);
@@ -1194,6 +1216,7 @@ void Renderer::render(uint32_t numFrames)
             m.effectivePaths = depth;
         }
         m.traceBatch(m.frameCount, n);
+        m.hostStats.batchSamplesUsed = n, m.hostStats.batchPathsUsed = static_cast<uint64_t>(n) * pixelsPadded, ++m.hostStats.batchesTraced;
         m.frameCount += n;
         m.accumulated += n;
         remaining -= n;
@@ -1401,8 +1424,8 @@ void Renderer::setCounting(bool enabled) { mImpl->counting = enabled; }
 void Renderer::setOption(const std::string& name, int64_t value)
 {
     if (name == "traversal_variant") mImpl->traversalVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
-    else if (name == "refill_min") mImpl->optRefillMin = mImpl->optRefillMinDeep = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value); // (all: a sweep of one value covers every launch)
-    else if (name == "refill_min_deep") mImpl->optRefillMinDeep = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value);
+    else if (name == "refill_min") mImpl->optRefillMin = mImpl->optRefillMinDeep = mImpl->optRefillMinDeepDense = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value); // (all: a sweep of one value covers every launch)
+    else if (name == "refill_min_deep") mImpl->optRefillMinDeep = mImpl->optRefillMinDeepDense = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value);
     else if (name == "refill_deep_from_bounce") mImpl->optRefillDeepFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 1));
     else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
     else if (name == "dense_leaf_min") mImpl->optDenseLeafMin = static_cast<uint32_t>(std::clamp<int64_t>(value, 0, 15));
@@ -1432,9 +1455,10 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "shade_blocks") mImpl->optShadeBlocks = static_cast<uint32_t>(value);
     else if (name == "const_primary_origin") mImpl->optConstPrimaryOrigin = value != 0;
     else if (name == "shadow_self_test") mImpl->optShadowSelfTest = value != 0;
-    // 0 (default): sin / cos / acos / exp / pow as the f32 rounding of a specified f64 evaluation (bit-identical to the oracle); 1: the device math library's f32 functions
+    // 0 (default): sin / cos / acos / exp / pow as the f32 rounding of a specified f64 evaluation (bit-identical to the test oracle); 1: the device math library's f32 functions
     // (kRaygen's lens / cone angle, kSky's dome: rf_device.hpp tSin ...), graded by SURVEY 8(d)'s tolerance.  Set it before the first sample of an accumulation.
     else if (name == "transcendentals") mImpl->optTranscendentalsF32 = value != 0;
+    else if (name == "inv_stream") mImpl->optInvStream = value != 0;
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;

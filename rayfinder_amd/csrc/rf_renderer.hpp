@@ -73,6 +73,11 @@ struct RenderStats
     uint64_t shadowNodeVisits = 0, shadowTriangleTests = 0;
     uint64_t paths = 0;
     uint32_t stackHighWater = 0;
+    // batch depth actually used (round 6): samples of every pixel traced together in the MOST RECENT batch, paths in it, and batches traced since the last reset.  A render call
+    // that does not get the configured depth (device memory short: another handle, a co-tenant) traces the same samples in more, shallower batches -- same image, shorter
+    // launches: a loss of speed that used to be said on stderr only
+    uint32_t batchSamplesUsed = 0, batchesTraced = 0;
+    uint64_t batchPathsUsed = 0;
     uint64_t closestRecordFetches = 0, shadowRecordFetches = 0; // 64-B BVH records fetched (counting build)
     uint64_t abandonedRays = 0;  // rays whose traversal stack outgrew 96 entries (reference: undefined past 32); every build
     uint64_t scalarRedoRays = 0; // rays redone by the reference-ordered scalar traversal (irregular rays, LDS stack overflow); every build

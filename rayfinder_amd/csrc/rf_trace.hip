@@ -363,7 +363,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     const uint32_t shardBegin = shard * shardLen, shardEnd = min(shardBegin + shardLen, count);
                     uint32_t       base = 0;
                     if (lane == 0) base = shardBegin < count ? atomicAdd(cursor + shard * kLineWords, chunk) : shardLen;
-                    base = shardBegin + __shfl(base, 0);
+                    // (readfirstlane, not a shuffle: the claim state -- shard, chunkPos, chunkEnd, shardsTried, exhausted -- is wave-uniform, and the compiler can only
+                    // keep it in SGPRs and run these loops on the scalar unit if it can SEE that: behind a shuffle it held four VGPRs and ran exec-mask loops.  Every lane
+                    // is enabled here -- the refill's condition is wave-uniform -- so the first lane is lane 0.)
+                    base = shardBegin + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
                     if (base >= shardEnd)
                     {
                         shard = (shard + 1) % kShards;
@@ -386,6 +389,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // the ray's state sits at its QUEUE position: the lanes of a refill read consecutive elements (coalesced), and
                 // the closest-hit launch does not read the queue itself at all
                 resultIndex = myPos;
+                // (closest-hit launches: a list of queue positions to visit in ITS order -- today only the ray-query path's RF_DEBUG_QUERY_LIST, tools/gpu_sort_potential.py)
+                if (!ANY_HIT && wide.rayList != nullptr) resultIndex = wide.rayList[myPos];
                 bool triedCell = false;
                 if constexpr (kOccluderCache)
                 {
@@ -405,17 +410,26 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // memory round trips per refill of a closest-hit launch instead of one)
                 Vec3 dir{};
                 if (!(ANY_HIT && !shadowDirFromStream)) dir = load3s(ps.rayD + resultIndex);
+                // (round 6, kFlagInvFromStream: kShade wrote 1 / direction next to the direction -- the same three IEEE divides, issued where the lanes wait for memory
+                // instead of in this wave-wide trip: 33 of its VALU instructions)
+                const bool invFromStream = !ANY_HIT && (flags & kFlagInvFromStream) != 0u;
+                Vec3       invIn{};
+                if (invFromStream) invIn = load3s(ps.rayInv + resultIndex);
                 const Vec3 o = (!ANY_HIT && (flags & kFlagConstOrigin) != 0u) ? vec3(wide.constOriginX, wide.constOriginY, wide.constOriginZ) : load3s(ps.rayO + resultIndex);
                 if (ANY_HIT && !shadowDirFromStream)
                 {
                     const Vec3 nz = load3s(ps.noiseOut + resultIndex);
                     dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
-                const RayPrep ray = prepareRay(o, dir);
+                RayPrep ray;
+                if (invFromStream)
+                {
+                    ray.origin = o, ray.direction = dir, ray.invDir = invIn;
+                    ray.negX = invIn.x < 0.0f, ray.negY = invIn.y < 0.0f, ray.negZ = invIn.z < 0.0f;
+                }
+                else ray = prepareRay(o, dir);
                 pr = packRay(ray);
                 rayDir = dir;
-                const uint32_t rayClass = classifyRay(ray);
-                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u) | (triedCell ? 16u : 0u);
                 rayTMax = tMax;
                 stackSize = spBase;
 #if defined(RF_EXP_PHASE)
@@ -433,24 +447,56 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 rayNodes = 1; // the root visit (wgsl:379-382)
                 rayTris = 0;
                 rayStackHigh = 0;
-                needScalar = rayClass == kRayIrregular;
+                // ---- classification (rf_wide.hpp) and, on the conservative records, the preconditions of their margin proofs.  Round 6: ONE test first that nearly every ray
+                // passes -- all three 1 / d of ordinary magnitude (which excludes NaN, infinity, zero), the origin within the bound (which excludes NaN and, the bound being
+                // below 1e30, anything classifyRay() would call non-finite): such a ray is class A, needs no scalar traversal, no replacement of infinities and (below) no root
+                // test.  Only the others run the full classification -- the same decisions as before, moved off the path of the ordinary ray (nine compares instead of ~60
+                // instructions of every refill trip).
+                bool fastRay = false;
+                if constexpr (kConservative && !COUNT)
+                {
+                    const float ax = fabsf(ray.invDir.x), ay = fabsf(ray.invDir.y), az = fabsf(ray.invDir.z);
+                    fastRay = ax >= 1e-18f && ax <= 1e18f && ay >= 1e-18f && ay <= 1e18f && az >= 1e-18f && az <= 1e18f && fabsf(o.x) <= wide.originBound && fabsf(o.y) <= wide.originBound &&
+                              fabsf(o.z) <= wide.originBound && wide.originBound < 1e30f;
+                }
+                uint32_t rayClass = kRayPlain;
+                bool     rootOk = true;
+                needScalar = false;
+                if (__builtin_expect(!fastRay, 0))
+                {
+                    rayClass = classifyRay(ray);
+                    needScalar = rayClass == kRayIrregular;
+                    if constexpr (kConservative)
+                    {
+                        // the margin of the half-precision / local-grid planes covers origins within wide.originBound and 1/direction components of
+                        // ordinary magnitude (or +-inf: those axes drop out as NaNs): anything else takes the scalar traversal
+                        const auto ordinary = [](float inv) { const float a = fabsf(inv); return (a >= 1e-18f && a <= 1e18f) || a == __uint_as_float(0x7F800000u); };
+                        const bool inside = fabsf(o.x) <= wide.originBound && fabsf(o.y) <= wide.originBound && fabsf(o.z) <= wide.originBound;
+                        if (!(inside && ordinary(ray.invDir.x) && ordinary(ray.invDir.y) && ordinary(ray.invDir.z))) needScalar = true;
+                        // An infinite 1/d (axis-parallel ray, class B) is replaced by +-1e30 IN THE CONSERVATIVE TESTS: the margin argument
+                        // does not depend on the size of 1/d, so the ray is still accepted wherever the reference accepts it (strictly inside
+                        // the slab: [-huge, +huge]; within the margin of a plane: accepted as well) and rejected when it is outside the
+                        // conservative slab by more than rounding -- instead of being left unconstrained on that axis, which sent such rays
+                        // through whole slices of the scene (and over the 12-entry stack: 150 x the scalar redos).  The leaf phase puts the
+                        // infinity back for its exact test (a genuine |1/d| of 1e30 never gets here: see `ordinary`).
+                        const float inf = __uint_as_float(0x7F800000u);
+                        if (fabsf(pr.iXY.x) == inf) pr.iXY.x = __builtin_copysignf(1e30f, pr.iXY.x);
+                        if (fabsf(pr.iXY.y) == inf) pr.iXY.y = __builtin_copysignf(1e30f, pr.iXY.y);
+                        if (fabsf(pr.iZ) == inf) pr.iZ = __builtin_copysignf(1e30f, pr.iZ);
+                    }
+                    // The root's own test (wgsl:379-382).  On the conservative records a class A ray (no infinite 1/d: no 0 * inf product anywhere) does without it: its first step
+                    // tests the root's grandchildren -- supersets of boxes that lie inside the root's --, every leaf applies its exact box, and a ray that misses the root's box
+                    // misses every box inside it (the slab arithmetic is monotone in the planes: rf_wide.hpp): one wasted step for such a ray, ~25 instructions less in every
+                    // refill.  Class B rays keep the test: the reference's NaN rules at the ROOT's planes are not seen by any leaf.  The counting builds keep it too.
+                    if (!(kConservative && !COUNT) || rayClass != kRayPlain)
+                    {
+                        float rootTMin;
+                        rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
+                    }
+                }
+                negMask = ray.negX | (ray.negY << 1) | (ray.negZ << 2) | (rayClass == kRayHasInf ? 8u : 0u) | (triedCell ? 16u : 0u);
                 if constexpr (kConservative)
                 {
-                    // the margin of the half-precision / local-grid planes covers origins within wide.originBound and 1/direction components of
-                    // ordinary magnitude (or +-inf: those axes drop out as NaNs): anything else takes the scalar traversal
-                    const auto ordinary = [](float inv) { const float a = fabsf(inv); return (a >= 1e-18f && a <= 1e18f) || a == __uint_as_float(0x7F800000u); };
-                    const bool inside = fabsf(o.x) <= wide.originBound && fabsf(o.y) <= wide.originBound && fabsf(o.z) <= wide.originBound;
-                    if (!(inside && ordinary(ray.invDir.x) && ordinary(ray.invDir.y) && ordinary(ray.invDir.z))) needScalar = true;
-                    // An infinite 1/d (axis-parallel ray, class B) is replaced by +-1e30 IN THE CONSERVATIVE TESTS: the margin argument
-                    // does not depend on the size of 1/d, so the ray is still accepted wherever the reference accepts it (strictly inside
-                    // the slab: [-huge, +huge]; within the margin of a plane: accepted as well) and rejected when it is outside the
-                    // conservative slab by more than rounding -- instead of being left unconstrained on that axis, which sent such rays
-                    // through whole slices of the scene (and over the 12-entry stack: 150 x the scalar redos).  The leaf phase puts the
-                    // infinity back for its exact test (a genuine |1/d| of 1e30 never gets here: see `ordinary`).
-                    const float inf = __uint_as_float(0x7F800000u);
-                    if (fabsf(pr.iXY.x) == inf) pr.iXY.x = __builtin_copysignf(1e30f, pr.iXY.x);
-                    if (fabsf(pr.iXY.y) == inf) pr.iXY.y = __builtin_copysignf(1e30f, pr.iXY.y);
-                    if (fabsf(pr.iZ) == inf) pr.iZ = __builtin_copysignf(1e30f, pr.iZ);
                     hbx = -(o.x * pr.iXY.x);
                     hby = -(o.y * pr.iXY.y);
                     hbz = -(o.z * pr.iZ);
@@ -458,16 +504,6 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                     lselX = ray.negX ? 0x00040005u : 0x00050004u, lselY = ray.negY ? 0x00040005u : 0x00050004u, lselZ = ray.negZ ? 0x00040005u : 0x00050004u;
                     const uint32_t signXY = ray.negX | (ray.negY << 1);
                     octKey = ray.negZ ? ((16u * (3u - signXY)) | (0x7777u << 8)) : 16u * signXY;
-                }
-                // The root's own test (wgsl:379-382).  On the conservative records a class A ray (no infinite 1/d: no 0 * inf product anywhere) does without it: its first step
-                // tests the root's grandchildren -- supersets of boxes that lie inside the root's --, every leaf applies its exact box, and a ray that misses the root's box
-                // misses every box inside it (the slab arithmetic is monotone in the planes: rf_wide.hpp): one wasted step for such a ray, ~25 instructions less in every
-                // refill.  Class B rays keep the test: the reference's NaN rules at the ROOT's planes are not seen by any leaf.  The counting builds keep it too.
-                bool rootOk = true;
-                if (!(kConservative && !COUNT) || rayClass != kRayPlain)
-                {
-                    float rootTMin;
-                    rootOk = slabBounds(ray, wide.rootLo, wide.rootHi, rootTMin) && rootTMin < rayTMax;
                 }
                 node = (needScalar || !rootOk) ? kNodeDone : (wide.rootLeaf != kWideNone ? wide.rootLeaf : 0u);
                 if constexpr (kOccluderCache)

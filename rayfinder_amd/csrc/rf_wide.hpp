@@ -500,7 +500,12 @@ inline WideBuild buildWide(const BvhNode* nodes, size_t count)
             }
             d[12] = floatBits(q[6].x), d[13] = floatBits(q[6].y), d[14] = floatBits(q[6].z), d[15] = floatBits(q[6].w);
             // an EMPTY slot (its child is a leaf and fills one slot only) holds an INVERTED box -- lower planes +65504, upper planes -65504 -- that no ray can pass: its
-            // near and far bounds are fma(+-65504, 1/d, b) with the same b, 131 008 |1/d| apart and the wrong way round, so `near <= far` fails whatever the origin.
+            // near and far bounds are fma(+-65504, 1/d, b) with the same b, 131 008 |1/d| apart and the wrong way round, so `near <= far` fails -- FOR THE RAYS THAT REACH
+            // THESE RECORDS: kTraceWide sends every ray whose origin lies beyond wide.originBound (4 R + 1) or whose 1/d is not of ordinary magnitude (1e-18 ... 1e18) to the
+            // scalar traversal before its first step (the refill's `fastRay` / `ordinary` tests).  The invariant depends on that gate: with |o / d| beyond ~2^41 on all three
+            // axes both fma results would round to the same b, `near == far` would pass, and -- the step no longer testing the word -- kQuadEmpty & kAxisMask would be followed
+            // as a record index.  Under the gate |b| = |o / d| <= (4 R + 1) * 1e18 only where |1/d| itself is huge, and then 131 008 |1/d| >> ulp(b); the fuzz covers a
+            // far diagonal camera with these records forced (tests/test_gpu_parity.py: test_far_camera_on_the_half_precision_records).
             // The step's hit test needs no `word != kQuadEmpty` for these records (kTraceWide, COMPACT == 4: two compares and two mask operations per step).
             for (int e = 0; e < 4; ++e)
                 if (d[12 + e] == kQuadEmpty)

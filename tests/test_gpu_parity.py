@@ -153,6 +153,17 @@ def test_render_path_traversal_kernel_on_arbitrary_rays(duck_pt, duck_oracle, tm
         d[ax] = np.float32(rng.choice([1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3, 1e-12, -1e-12]))
         rays[4000 + i, :3] = o
         rays[4000 + i, 3:] = d
+    # far DIAGONAL origins: |o| from 1e3 to 1e20 on all three axes, aimed at the scene -- beyond the conservative records' origin bound, where fma(+-65504, 1/d, -o/d)
+    # of a half-precision record's EMPTY slot would collapse to near == far if such a ray ever reached a step (rf_wide.hpp, kHalfEmptyPlanes): the refill's gate must send
+    # every one of them to the scalar traversal, whatever layout the launch reads
+    centre = 0.5 * (lo + hi)
+    for i in range(600):
+        sgn = np.array([1.0 if (i >> k) & 1 else -1.0 for k in range(3)])
+        far = sgn * (10.0 ** (3 + (i % 18))) * rng.uniform(0.8, 1.25, 3)
+        target = rng.uniform(lo, hi)
+        rays[9000 + i, :3] = far.astype(np.float32)
+        d = target - far
+        rays[9000 + i, 3:] = (d / np.linalg.norm(d) if i % 2 else d * 1e-12).astype(np.float32)   # (unit, or tiny: 1/d around 1e-8 ... 1e9)
     r, _ = _renderer(duck_pt, 64, 64, 1, 1)
     r.set_option("query_variant", 2)
     with np.errstate(all="ignore"):
@@ -923,6 +934,9 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
         r.set_option("oct_from_bounce", 1 if seed % 8 == 2 else 2 if seed % 8 == 6 else 1 + seed % 3)
     if seed % 9 in (1, 5):                                      # kShade's own-triangle test of the shadow rays off (default: on)
         r.set_option("shadow_self_test", 0)
+    if seed % 3 == 0 or os.environ.get("RF_FUZZ_INV"):          # round 6: 1 / direction of the bounce rays written by kShade and read by the closest-hit refill (+ an early refill)
+        r.set_option("inv_stream", 1 if not os.environ.get("RF_FUZZ_INV_OFF") else 0)
+        r.set_option("refill_min_deep", 1 + seed % 9)
     if seed % 2:                                                # one batch per sample: every batch after the first starts on a warm occluder grid
         for _ in range(spp):
             r.render(1)
@@ -1144,6 +1158,23 @@ def test_f32_transcendentals_mode_within_the_stated_tolerance(duck_pt, duck_orac
         assert gr["nan_gpu"] == gr["nan_ref"], (name, gr)
     # ... and it IS another evaluation: the images are not bit-identical to the default mode's
     assert report["atrium_1080p_8spp_vs_default_mode"]["exact"] < 1.0
+
+
+def test_inv_stream_and_refill_threshold_are_invisible(atrium, duck_pt):
+    """Round 6: `inv_stream` (kShade writes 1 / direction of the bounce ray, the closest-hit refill reads it instead of issuing the three divides itself) and the refill
+    threshold are scheduling / data-path choices: same image bit for bit, whatever the threshold (1: a refill for every finished lane ... 63: almost never)."""
+    for pt, (W, H, spp, bounces) in ((atrium, (480, 270, 4, 8)), (duck_pt, (200, 150, 4, 4))):
+        r, _ = _renderer(pt, W, H, spp, bounces)
+        r.set_option("inv_stream", 0)
+        r.render(spp)
+        want = r.read_accumulation()[0]
+        for inv, refill in ((1, 22), (1, 1), (1, 8), (0, 1), (1, 63), (0, 40)):
+            r.set_option("inv_stream", inv)
+            r.set_option("refill_min_deep", refill)
+            r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.25 + 0.001 * refill + 0.0001 * inv))   # (exposure: restarts the accumulation)
+            r.render(spp)
+            assert np.array_equal(bits(r.read_accumulation()[0]), bits(want)), (inv, refill)
+        r.close()
 
 
 def _local_world_gather(pt, W, H, spp, bounces, world, root, loopback=False):

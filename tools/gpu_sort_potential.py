@@ -13,6 +13,10 @@ HIP events around the launch alone) on the SAME rays in several orders:
     morton+oct     30-bit Morton code of the origin, then direction octant
 
   RF_DEBUG_QUERY_MS=1 python tools/gpu_sort_potential.py [tiles = 128] [spp = 64] [scene detail = plain] [scene scale = 1]
+
+RF_SORT_INDIRECT=1 (round 6): the rays STAY in kShade's order (every run of 1 024 sorted by triangle: where the renderer's path state would sit) and only an index list is put into
+the order under test -- the launch visits ray list[i] at position i (RF_DEBUG_QUERY_LIST), gathering origin / direction from and scattering its hit record to the ray's own place:
+what a global order costs when nothing but a list of queue positions is sorted.
 """
 import os, sys, re, subprocess, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -34,7 +38,7 @@ if os.environ.get("RF_SORT_POTENTIAL_CHILD") != "1":
     base = {}
     for lab, ms in best.items():
         bounce, rays, order = lab.split("|")
-        if order == "natural": base[bounce] = ms
+        if order == "natural" or (order == "tile-sort" and bounce not in base): base[bounce] = ms
     for lab, ms in best.items():
         bounce, rays, order = lab.split("|")
         print(f"bounce {bounce}  {int(rays) / 1e6:6.2f} M rays  {order:14s} {ms:8.3f} ms  {int(rays) / ms / 1e6:7.2f} Grays/s   x{base[bounce] / ms:5.3f}")
@@ -81,12 +85,23 @@ o = np.broadcast_to(origin, d.shape).astype(np.float32)
 start_tri = np.zeros(n, np.uint32)
 
 
-def timed(o, d, label):
+INDIRECT = os.environ.get("RF_SORT_INDIRECT") == "1"
+LIST_PATH = f"/tmp/rf_sort_list_{os.getpid()}.bin"
+
+
+def timed(o, d, label, order=None):
+    """order (INDIRECT): the rays are passed as they are and visited in this order through an index list"""
     rays = np.ascontiguousarray(np.concatenate([o, d], 1), np.float32)
     out = None
-    for _ in range(2):
-        print(f"LABEL {label}", flush=True)
-        out = r.intersect_rays(rays, 10000.0)
+    if order is not None:
+        np.ascontiguousarray(order, np.uint32).tofile(LIST_PATH)
+        os.environ["RF_DEBUG_QUERY_LIST"] = LIST_PATH
+    try:
+        for _ in range(2):
+            print(f"LABEL {label}", flush=True)
+            out = r.intersect_rays(rays, 10000.0)
+    finally:
+        os.environ.pop("RF_DEBUG_QUERY_LIST", None)
     return out
 
 
@@ -118,13 +133,25 @@ for bounce in range(1, 6):
         q = np.clip((o - lo) / np.maximum(hi - lo, 1e-9) * 1023.0, 0, 1023).astype(np.uint32)
         orders["morton+oct"] = np.argsort((morton3(q) << 3) | octant, kind="stable")
         ref = None
-        for name, perm in orders.items():
+        if INDIRECT:
+            base = orders["tile-sort"]                       # where the path state sits: kShade's order
+            ob, db = o[base], d[base]
+            pos_of = np.empty(n, np.int64); pos_of[base] = np.arange(n)      # natural index -> position in the tile-sorted arrays
+            for name, perm in orders.items():
+                if name == "natural": continue
+                out = timed(ob, db, f"{bounce}|{n}|{name}", order=pos_of[perm])            # visit order `perm`, expressed in positions of the tile-sorted arrays
+                tri_nat = out["tri"][pos_of]
+                if ref is None: ref = tri_nat
+                elif not np.array_equal(ref, tri_nat): print("RESULT MISMATCH under order", name)
+            out = {k: (v[pos_of] if hasattr(v, "__len__") and len(v) == n else v) for k, v in out.items()}
+        else:
+          for name, perm in orders.items():
             out = timed(o[perm], d[perm], f"{bounce}|{n}|{name}")
             inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
             tri_nat = out["tri"][inv]
             if ref is None: ref = tri_nat
             elif not np.array_equal(ref, tri_nat): print("RESULT MISMATCH under order", name)
-        out = {k: (v[inv] if hasattr(v, "__len__") and len(v) == n else v) for k, v in out.items()}
+          out = {k: (v[inv] if hasattr(v, "__len__") and len(v) == n else v) for k, v in out.items()}
     else:
         out = timed(o, d, f"{bounce}|{n}|natural")
     hit = out["tri"] != 0xFFFFFFFF
