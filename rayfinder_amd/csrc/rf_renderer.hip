@@ -139,6 +139,9 @@ struct Renderer::Impl
     DeviceBuffer<float4>            shadeRecords; // 8 per triangle: kShade's 128-byte record
     DeviceBuffer<TextureDescriptor> textureDescriptors;
     DeviceBuffer<uint32_t>          texels;
+    DeviceBuffer<TiledTextureDescriptor> tiledDescriptors; // option `texel_tiles` (round 6): the texels once more in 8 x 8 tiles
+    DeviceBuffer<uint32_t>          tiledTexels;
+    bool                            optTexelTiles = false;
     DeviceBuffer<uint8_t>           blueNoise;
     DeviceBuffer<float>             albedoLut;
     DeviceScene                     scene{};
@@ -1047,6 +1050,32 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         if (descs.empty()) descs.push_back({1, 1, 0});
         m.textureDescriptors.upload(descs.data(), descs.size());
         m.texels.upload(blob.data(), blob.size());
+        // the same texels in 8 x 8 tiles (option `texel_tiles`; evalTexture).  Padding texels of partial tiles are never addressed (j < width && i < height on that path).
+        {
+            std::vector<TiledTextureDescriptor> td;
+            uint64_t                            total = 0;
+            for (const TextureDescriptor& d : descs)
+            {
+                if (total > 0xFFFFFFFFull) break;
+                td.push_back({d.width, d.height, d.offset, static_cast<uint32_t>(total)});
+                total += static_cast<uint64_t>((d.width + 7u) >> 3) * ((d.height + 7u) >> 3) * 64ull;
+            }
+            if (td.size() == descs.size() && total <= 0xFFFFFFFFull && !sceneView.baseColorTextures.empty())
+            {
+                std::vector<uint32_t> tiled(static_cast<size_t>(std::max<uint64_t>(total, 1)), 0u);
+                for (size_t k = 0; k < td.size(); ++k)
+                {
+                    const uint32_t w = td[k].width, h = td[k].height, tilesPerRow = (w + 7u) >> 3;
+                    const uint32_t* src = blob.data() + td[k].offset;
+                    uint32_t*       dst = tiled.data() + td[k].tiledOffset;
+                    for (uint32_t i = 0; i < h; ++i)
+                        for (uint32_t j = 0; j < w; ++j)
+                            dst[(static_cast<size_t>((i >> 3) * tilesPerRow + (j >> 3)) << 6) + ((i & 7u) << 3) + (j & 7u)] = src[static_cast<size_t>(i) * w + j];
+                }
+                m.tiledDescriptors.upload(td.data(), td.size());
+                m.tiledTexels.upload(tiled.data(), tiled.size());
+            }
+        }
     }
     {
         m.blueNoise.upload(blueNoiseTable(), 128 * 128 * 2);
@@ -1062,6 +1091,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.scene.textureDescriptors = m.textureDescriptors.ptr;
     m.scene.texels = m.texels.ptr;
     m.scene.numTexels = m.texels.count;
+    m.scene.tiledDescriptors = nullptr, m.scene.tiledTexels = nullptr; // (option `texel_tiles` switches them in)
     m.scene.blueNoise = m.blueNoise.ptr;
     m.scene.albedoLut = m.albedoLut.ptr;
 
@@ -1306,7 +1336,7 @@ void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, ui
     pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
     maxPathsPerBatch = m.effectivePaths ? std::min(m.effectivePaths, m.maxPaths) : m.maxPaths;
     sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.wideQuadLocal.count + m.wideOct.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
-                 m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2) + m.occluderGrid.count * sizeof(uint32_t); // (the occluder grid: allocated by the first batch)
+                 m.texels.count * sizeof(uint32_t) + m.tiledTexels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2) + m.occluderGrid.count * sizeof(uint32_t); // (the occluder grid: allocated by the first batch)
 }
 uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }
 
@@ -1459,6 +1489,14 @@ void Renderer::setOption(const std::string& name, int64_t value)
     // (kRaygen's lens / cone angle, kSky's dome: rf_device.hpp tSin ...), graded by SURVEY 8(d)'s tolerance.  Set it before the first sample of an accumulation.
     else if (name == "transcendentals") mImpl->optTranscendentalsF32 = value != 0;
     else if (name == "inv_stream") mImpl->optInvStream = value != 0;
+    else if (name == "texel_tiles")
+    {
+        // (wgsl:546-565's texel (i, j) from an 8 x 8-tiled copy of the blob: another address, the same texel; scenes whose tiled blob would pass 2^32 texels keep the rows)
+        mImpl->optTexelTiles = value != 0 && mImpl->tiledTexels.ptr != nullptr;
+        synchronize();
+        mImpl->scene.tiledDescriptors = mImpl->optTexelTiles ? mImpl->tiledDescriptors.ptr : nullptr;
+        mImpl->scene.tiledTexels = mImpl->optTexelTiles ? mImpl->tiledTexels.ptr : nullptr;
+    }
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;

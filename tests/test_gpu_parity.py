@@ -934,6 +934,8 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
         r.set_option("oct_from_bounce", 1 if seed % 8 == 2 else 2 if seed % 8 == 6 else 1 + seed % 3)
     if seed % 9 in (1, 5):                                      # kShade's own-triangle test of the shadow rays off (default: on)
         r.set_option("shadow_self_test", 0)
+    if seed % 4 == 1 or os.environ.get("RF_FUZZ_TILES"):        # round 6: texels fetched from the 8 x 8-tiled copy of the blob (textures of 1 ... 8 texels a side, uvs in -2 ... 3: partial tiles, wrapped and out-of-range lookups)
+        r.set_option("texel_tiles", 1)
     if seed % 3 == 0 or os.environ.get("RF_FUZZ_INV"):          # round 6: 1 / direction of the bounce rays written by kShade and read by the closest-hit refill (+ an early refill)
         r.set_option("inv_stream", 1 if not os.environ.get("RF_FUZZ_INV_OFF") else 0)
         r.set_option("refill_min_deep", 1 + seed % 9)
@@ -1158,6 +1160,20 @@ def test_f32_transcendentals_mode_within_the_stated_tolerance(duck_pt, duck_orac
         assert gr["nan_gpu"] == gr["nan_ref"], (name, gr)
     # ... and it IS another evaluation: the images are not bit-identical to the default mode's
     assert report["atrium_1080p_8spp_vs_default_mode"]["exact"] < 1.0
+
+
+def test_texel_tiles_are_invisible(atrium, duck_pt):
+    """Round 6: `texel_tiles` reads wgsl:546-565's texel (i, j) from a copy of the blob stored in 8 x 8 tiles -- another address, the same texel: the image
+    keeps its bits (25 textures of the atrium incl. sizes that are no multiple of 8; Duck's 512 x 512 palette image; the fuzz adds textures of 1 ... 8 texels a side)."""
+    for pt, (W, H, spp, bounces) in ((atrium, (480, 270, 4, 8)), (duck_pt, (200, 150, 4, 4))):
+        r, _ = _renderer(pt, W, H, spp, bounces)
+        r.render(spp)
+        want = r.read_accumulation()[0]
+        r.set_option("texel_tiles", 1)
+        r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.3))
+        r.render(spp)
+        assert np.array_equal(bits(r.read_accumulation()[0]), bits(want))
+        r.close()
 
 
 def test_inv_stream_and_refill_threshold_are_invisible(atrium, duck_pt):
