@@ -102,7 +102,7 @@ typedef struct rf_renderer_descriptor
     int32_t              device_ordinal;
     uint64_t             max_paths_in_flight;   /* batch depth; 0 = default (1 Gi paths).  Default or chosen, a render() call whose batches do not fit the device memory
                                                    free at that moment traces the same samples in shallower batches (same image; said on stderr; the configured depth is
-                                                   used again once the memory is back).  Path state is allocated on demand: samples x pixels x 160 B */
+                                                   used again once the memory is back).  Path state is allocated on demand: samples x pixels x 148 B */
 } rf_renderer_descriptor;
 
 typedef struct rf_stats
@@ -273,7 +273,7 @@ RF_API int  rf_comm_transport(const rf_comm* c, uint32_t* local_out);
  * what the one exchange of the multi-GPU path costs once the rank's own frame has drained.  Waits for that exchange; -1 before the first.  (No reference
  * counterpart: the reference is single-device, reference_path_tracer.cpp:565-595.) */
 RF_API int  rf_comm_last_exchange_ms(rf_comm* c, double* ms_out);
-/* Device memory held by a handle: path state + queues (160 B per path slot: nine packed xyz streams, two float4 streams, five u32 queues / lists; allocated on demand for the largest batch traced),
+/* Device memory held by a handle: path state + queues (148 B per path slot: eight packed xyz streams, two float4 streams, five u32 queues / lists; allocated on demand for the largest batch traced),
  * the batch depth in use (lowered automatically when the device has less free memory than the default wants: same image,
  * more batches) and the resident scene.  Any pointer may be NULL. */
 RF_API int  rf_renderer_memory_info(const rf_renderer* r, uint64_t* path_state_bytes, uint64_t* paths_allocated, uint64_t* max_paths_per_batch, uint64_t* scene_bytes);

@@ -41,8 +41,6 @@ struct DeviceScene
     const TextureDescriptor* textureDescriptors;
     const uint32_t*          texels;
     uint64_t                 numTexels;
-    const TiledTextureDescriptor* tiledDescriptors; // option `texel_tiles`: the texels once more in 8 x 8 tiles (nullptr: off); texels / numTexels stay for the out-of-range cases
-    const uint32_t*               tiledTexels;
     const uint8_t*           blueNoise; // 128*128*2
     const float*             albedoLut; // 256 entries: pow(i/255, 2.2)
 };
@@ -427,36 +425,16 @@ __device__ __forceinline__ float skyRadiance(const SkyStateGpu& sky, float cosTh
 // `lut`: the 256-entry sRGB -> linear table, in LDS in kShade (three look-ups per hit that then bypass the vector L1)
 __device__ __forceinline__ Vec3 evalTexture(const DeviceScene& scene, const float* lut, uint32_t descriptorIdx, float uvx, float uvy)
 {
-    uint32_t width, height, offset, tiledOffset = 0u;
-    if (scene.tiledDescriptors != nullptr)
-    {
-        const TiledTextureDescriptor t = scene.tiledDescriptors[descriptorIdx];
-        width = t.width, height = t.height, offset = t.offset, tiledOffset = t.tiledOffset;
-    }
-    else
-    {
-        const TextureDescriptor d = scene.textureDescriptors[descriptorIdx];
-        width = d.width, height = d.height, offset = d.offset;
-    }
-    const float    u = wFract(uvx);
-    const float    v = wFract(uvy);
-    const uint32_t j = static_cast<uint32_t>(u * static_cast<float>(width));
-    const uint32_t i = static_cast<uint32_t>(v * static_cast<float>(height));
-    uint32_t       bgra;
-    if (scene.tiledDescriptors != nullptr && j < width && i < height)
-    {
-        // 8 x 8 tiles, row-major inside the tile and across the texture's tiles: same texel (i, j), another address
-        const uint32_t tilesPerRow = (width + 7u) >> 3;
-        bgra = scene.tiledTexels[static_cast<uint64_t>(tiledOffset) + (static_cast<uint64_t>((i >> 3) * tilesPerRow + (j >> 3)) << 6) + ((i & 7u) << 3) + (j & 7u)];
-    }
-    else
-    {
-        // (also the tiled path's way out for j == width / i == height -- fract() * w rounding up, fract() returning 1: the row-major index then names a texel of the next
-        // row or the next texture, which only the row-major blob can answer)
-        uint64_t idx = static_cast<uint64_t>(offset) + static_cast<uint64_t>(i * width + j);
-        if (idx >= scene.numTexels) idx = scene.numTexels - 1;
-        bgra = scene.texels[idx];
-    }
+    // (round 6 measured the same texels in 8 x 8 tiles -- four 64-byte lines of 8 x 2 texels instead of 16 x 1: kShade of bounce 1 -3.1 %, L1->L2 requests per hit 0.51 -> 0.46, the
+    // other bounces unchanged; below the 5 % it was to be adopted at: profiles/r06_texel)
+    const TextureDescriptor d = scene.textureDescriptors[descriptorIdx];
+    const float             u = wFract(uvx);
+    const float             v = wFract(uvy);
+    const uint32_t          j = static_cast<uint32_t>(u * static_cast<float>(d.width));
+    const uint32_t          i = static_cast<uint32_t>(v * static_cast<float>(d.height));
+    uint64_t                idx = static_cast<uint64_t>(d.offset) + static_cast<uint64_t>(i * d.width + j);
+    if (idx >= scene.numTexels) idx = scene.numTexels - 1;
+    const uint32_t bgra = scene.texels[idx];
     return vec3(lut[(bgra >> 16) & 0xffu], lut[(bgra >> 8) & 0xffu], lut[bgra & 0xffu]);
 }
 

@@ -62,10 +62,6 @@ struct PathStreams
     P3*     rayDOut; // [position in the NEXT queue] written by kShade
     P3*     thrOut;  // [position in the NEXT queue]
     P3*     noiseOut; // [position in the NEXT queue]: kShade copies the triple along; the shadow launch of the bounce reads it here
-    // round 6 (option `inv_stream`): [position in the NEXT queue] 1 / direction of the bounce ray, written by kShade (kShadeWriteInv) with the same IEEE divide the
-    // traversal's refill would issue -- three divides (33 VALU instructions) of a ~150-instruction wave-wide refill trip moved into a kernel that waits for memory.
-    // One buffer: the closest-hit launch that reads it has finished before kShade writes the next bounce's.  nullptr: the refill divides itself.
-    P3*     rayInv;
 };
 
 // 12-byte load of the xyz part of a float4 stream element (global_load_dwordx3): the L1 -> VGPR return path
@@ -307,7 +303,6 @@ constexpr uint32_t kShadeLastBounce = 1u, kShadeFirstBounce = 2u;
 // kShadeSelfShadow: kShade tests every hit's shadow ray against the hit triangle ITSELF (its leaf's exact box, then the triangle: both sit in the shading record it has in
 // registers) and writes the positions of the hits that this does not settle to `shadowList`; the bounce's any-hit launches work through that list only (see kShade)
 constexpr uint32_t kShadeSelfShadow = 4u;
-constexpr uint32_t kShadeWriteInv = 8u; // kShade also writes 1 / direction of the bounce ray (PathStreams::rayInv)
 constexpr uint32_t kLookFirstBounce = 1u, kLookNoRayCount = 2u; // kShadowFirstLook's flags
 
 
@@ -339,7 +334,6 @@ constexpr uint32_t kFlagOccluderCache = 16u;      // any-hit: a new ray first vi
 constexpr uint32_t kFlagOccluderNoTry = 32u;      // ... the launch runs behind kShadowFirstLook: its rays have had their first look, it only records what stopped them
 constexpr uint32_t kFlagNoRayCount = 64u;
 constexpr uint32_t kFlagConstOrigin = 128u;      // closest-hit, bounce 1: every ray starts at WideScene::constOrigin (a pinhole camera: kRaygen does not write the origins, the refill does not read them)
-constexpr uint32_t kFlagInvFromStream = 4096u;   // closest-hit: 1 / direction comes from ps.rayInv (written by kShade) instead of three divides in the refill
 constexpr uint32_t kFlagDenseLeafShift = 8u;       // bits 11..8: leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (0: never; see kTraceWide)         // the launch's rays are counted elsewhere (kShadowFirstLook counted the whole queue)
 #if defined(RF_EXP_OCC_SLOTS)
 constexpr int kOccSlots = RF_EXP_OCC_SLOTS;

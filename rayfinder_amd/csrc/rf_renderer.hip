@@ -139,9 +139,6 @@ struct Renderer::Impl
     DeviceBuffer<float4>            shadeRecords; // 8 per triangle: kShade's 128-byte record
     DeviceBuffer<TextureDescriptor> textureDescriptors;
     DeviceBuffer<uint32_t>          texels;
-    DeviceBuffer<TiledTextureDescriptor> tiledDescriptors; // option `texel_tiles` (round 6): the texels once more in 8 x 8 tiles
-    DeviceBuffer<uint32_t>          tiledTexels;
-    bool                            optTexelTiles = false;
     DeviceBuffer<uint8_t>           blueNoise;
     DeviceBuffer<float>             albedoLut;
     DeviceScene                     scene{};
@@ -165,7 +162,6 @@ struct Renderer::Impl
     uint64_t                validPixels = 0;     // pixels of this rank's tiles that lie inside the frame
     unsigned long long      primaryRaysHost = 0; // samples traced x validPixels since the last resetStats()
     uint64_t                maxPaths = 0;
-    DeviceBuffer<P3>        sRayInv; // round 6, option `inv_stream`: 1 / direction of the bounce rays by queue position (PathStreams::rayInv); allocated with the rest of the path state
     DeviceBuffer<P3>        sRayO, sRayD, sRayD2, sThr, sThr2, sPending, sNoise, sNoise2; // queue-position arrays, packed xyz; rayD / thr / noise: double-buffered (PathStreams)
     DeviceBuffer<float4>    sRad, sHit;
     DeviceBuffer<uint32_t>  queueA, queueB, missQueue, missSlots, shadowList, queueCounts; // shadowList: kShade's list of the shadow rays its own-triangle test has not settled (kShadeSelfShadow)
@@ -215,7 +211,6 @@ struct Renderer::Impl
     // roughly queue order, which keeps neighbouring pixels' rays together -- a capped, grid-striding kShade saved its empty
     // workgroups but cost the traversal kernels 2-5 %)
     uint32_t optShadeBlocks = 0;
-    bool     optInvStream = false; // kShade writes 1 / direction of the bounce rays, the closest-hit refill reads it instead of dividing (PathStreams::rayInv)
     bool     optTranscendentalsF32 = false; // option `transcendentals`: kRaygen / kSky call the f32 math library instead of the specified f64 evaluation (opt-in)
     bool     optShadowSelfTest = true; // kShade tests every shadow ray against the triangle it starts on first (kShadeSelfShadow); needs selfShadowOk
     bool     selfShadowOk = false;     // the tree's boxes are nested and regular, and the shading records carry their triangles' leaf boxes
@@ -273,13 +268,12 @@ struct Renderer::Impl
     uint64_t allocatedPaths = 0;
     uint64_t effectivePaths = 0;       // batch depth the last render() call ended up with (<= maxPaths: less when less memory was free THEN)
 
-    // bytes of path state + queues per path slot (nine packed xyz streams, two float4 streams, five u32 queues / lists): 160
-    static constexpr uint64_t kBytesPerPath = 9 * sizeof(P3) + 2 * sizeof(float4) + 5 * sizeof(uint32_t);
+    // bytes of path state + queues per path slot (eight packed xyz streams, two float4 streams, five u32 queues / lists): 148
+    static constexpr uint64_t kBytesPerPath = 8 * sizeof(P3) + 2 * sizeof(float4) + 5 * sizeof(uint32_t);
 
     void releasePathState()
     {
         sRayO.release(), sRayD.release(), sRayD2.release(), sThr.release(), sThr2.release(), sRad.release(), sHit.release();
-        sRayInv.release();
         sPending.release(), sNoise.release(), sNoise2.release(), queueA.release(), queueB.release(), missQueue.release(), missSlots.release(), shadowList.release();
         allocatedPaths = 0;
     }
@@ -307,7 +301,7 @@ struct Renderer::Impl
             return true;
         };
         const bool ok = tryAlloc(sRayO, paths) && tryAlloc(sRayD, paths) && tryAlloc(sRayD2, paths) && tryAlloc(sThr, paths) && tryAlloc(sThr2, paths) &&
-                        tryAlloc(sRad, paths) && tryAlloc(sHit, paths) && tryAlloc(sPending, paths) && tryAlloc(sNoise, paths) && tryAlloc(sNoise2, paths) && tryAlloc(sRayInv, paths) &&
+                        tryAlloc(sRad, paths) && tryAlloc(sHit, paths) && tryAlloc(sPending, paths) && tryAlloc(sNoise, paths) && tryAlloc(sNoise2, paths) &&
                         tryAlloc(queueA, paths) && tryAlloc(queueB, paths) && tryAlloc(missQueue, paths) && tryAlloc(missSlots, paths) && tryAlloc(shadowList, paths);
         if (!ok)
         {
@@ -546,7 +540,7 @@ struct Renderer::Impl
         RF_HIP(hipMemsetAsync(queueCounts.ptr, 0, queueCounts.count * sizeof(uint32_t), stream));
         const uint32_t count = static_cast<uint32_t>(n);
         RF_HIP(hipMemcpyAsync(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice, stream));
-        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr, nullptr};
+        PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
         const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
         const WideArgs wa{ps, queueA.ptr, queueCounts.ptr, queueCounts.ptr + kLineWords, optRefillMin, optChunk, tMax, grid, 0u};
         if (shadow)
@@ -651,7 +645,7 @@ struct Renderer::Impl
         const uint32_t blocks = static_cast<uint32_t>((paths + kBlock - 1) / kBlock);
         primaryRaysHost += static_cast<unsigned long long>(numSamples) * validPixels;
         // bounce b reads direction / throughput from buffer (b - 1) & 1 and kShade writes the next bounce's into the other one
-        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr, optInvStream ? sRayInv.ptr : nullptr};
+        PathStreams    ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
         const uint32_t numBounces = fp.numBounces;
 
         wide.occGrid = nullptr;
@@ -726,8 +720,6 @@ struct Renderer::Impl
             // (scenes with long leaves -- the DENSE_LEAVES instantiations -- keep 22: a phase over dense (lane, triangle) pairs wants many parked lanes; clutter atrium +2.4 % at 12: profiles/r06_lanes)
             const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (layoutClosest == kLayoutQuad ? optRefillMinDeepQuad : (denseWanted(uniformFlag) ? optRefillMinDeepDense : optRefillMinDeep)) : optRefillMin;
             (void)conservativeClosest;
-            // (option `inv_stream`) kShade of the bounce before wrote 1 / direction next to the direction: the wide closest-hit launches from bounce 2 on read it
-            const bool invFromStream = optInvStream && bounce >= 2u && !counting && layoutClosest != kLayoutScalar && layoutClosest != kLayoutPacket;
             launchTimed(1, [&] {
                 if (layoutClosest == kLayoutScalar)
                 {
@@ -742,7 +734,7 @@ struct Renderer::Impl
 #endif
                 else
                     launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds},
-                                      uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u) | (invFromStream ? kFlagInvFromStream : 0u));
+                                      uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u));
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
             // kShade's own-triangle test of the shadow rays (kShadeSelfShadow): wherever this bounce's any-hit launch is one that can work through a list of queue positions
@@ -753,7 +745,7 @@ struct Renderer::Impl
             uint32_t* const shadowListCount = shadowListCounts + kLine * (bounce - 1);
             if (selfShadow) selfMask |= 1ull << (bounce - 1);
             launchTimed(2, [&] {
-                const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u) | (selfShadow ? kShadeSelfShadow : 0u) | (optInvStream && bounce < numBounces ? kShadeWriteInv : 0u);
+                const uint32_t shadeFlags = (bounce == numBounces ? kShadeLastBounce : 0u) | (bounce == 1 ? kShadeFirstBounce : 0u) | (selfShadow ? kShadeSelfShadow : 0u);
                 const dim3     shadeGrid(optShadeBlocks ? std::min(itemBlocks, optShadeBlocks) : itemBlocks);
                 if (optShadeSortFromBounce != 0u && bounce >= optShadeSortFromBounce)
                     hipLaunchKernelGGL(shadeKernel(true), shadeGrid, dim3(kBlock), 0, stream, scene, sky, sunBasis, ps, qIn, countIn, qOut, countOut, missQueue.ptr, missSlots.ptr, missCount, shadowList.ptr, shadowListCount, shadeFlags, sortScale);
@@ -1050,32 +1042,6 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         if (descs.empty()) descs.push_back({1, 1, 0});
         m.textureDescriptors.upload(descs.data(), descs.size());
         m.texels.upload(blob.data(), blob.size());
-        // the same texels in 8 x 8 tiles (option `texel_tiles`; evalTexture).  Padding texels of partial tiles are never addressed (j < width && i < height on that path).
-        {
-            std::vector<TiledTextureDescriptor> td;
-            uint64_t                            total = 0;
-            for (const TextureDescriptor& d : descs)
-            {
-                if (total > 0xFFFFFFFFull) break;
-                td.push_back({d.width, d.height, d.offset, static_cast<uint32_t>(total)});
-                total += static_cast<uint64_t>((d.width + 7u) >> 3) * ((d.height + 7u) >> 3) * 64ull;
-            }
-            if (td.size() == descs.size() && total <= 0xFFFFFFFFull && !sceneView.baseColorTextures.empty())
-            {
-                std::vector<uint32_t> tiled(static_cast<size_t>(std::max<uint64_t>(total, 1)), 0u);
-                for (size_t k = 0; k < td.size(); ++k)
-                {
-                    const uint32_t w = td[k].width, h = td[k].height, tilesPerRow = (w + 7u) >> 3;
-                    const uint32_t* src = blob.data() + td[k].offset;
-                    uint32_t*       dst = tiled.data() + td[k].tiledOffset;
-                    for (uint32_t i = 0; i < h; ++i)
-                        for (uint32_t j = 0; j < w; ++j)
-                            dst[(static_cast<size_t>((i >> 3) * tilesPerRow + (j >> 3)) << 6) + ((i & 7u) << 3) + (j & 7u)] = src[static_cast<size_t>(i) * w + j];
-                }
-                m.tiledDescriptors.upload(td.data(), td.size());
-                m.tiledTexels.upload(tiled.data(), tiled.size());
-            }
-        }
     }
     {
         m.blueNoise.upload(blueNoiseTable(), 128 * 128 * 2);
@@ -1091,7 +1057,6 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
     m.scene.textureDescriptors = m.textureDescriptors.ptr;
     m.scene.texels = m.texels.ptr;
     m.scene.numTexels = m.texels.count;
-    m.scene.tiledDescriptors = nullptr, m.scene.tiledTexels = nullptr; // (option `texel_tiles` switches them in)
     m.scene.blueNoise = m.blueNoise.ptr;
     m.scene.albedoLut = m.albedoLut.ptr;
 
@@ -1336,7 +1301,7 @@ void Renderer::memoryInfo(uint64_t& pathStateBytes, uint64_t& pathsAllocated, ui
     pathStateBytes = m.allocatedPaths * Impl::kBytesPerPath;
     maxPathsPerBatch = m.effectivePaths ? std::min(m.effectivePaths, m.maxPaths) : m.maxPaths;
     sceneBytes = (m.nodes.count + m.triangles.count + m.wideNodes.count + m.wideCompact.count + m.wideHot.count + m.wideOwn.count + m.wideQuad.count + m.wideQuadHalf.count + m.wideQuadLocal.count + m.wideOct.count + m.attributes.count + m.shadeRecords.count) * sizeof(float4) +
-                 m.texels.count * sizeof(uint32_t) + m.tiledTexels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2) + m.occluderGrid.count * sizeof(uint32_t); // (the occluder grid: allocated by the first batch)
+                 m.texels.count * sizeof(uint32_t) + m.bigLeaves.count * sizeof(uint2) + m.occluderGrid.count * sizeof(uint32_t); // (the occluder grid: allocated by the first batch)
 }
 uint64_t Renderer::accumulationBytes() const { return static_cast<uint64_t>(mImpl->tiles.size()) * 1024 * sizeof(float4); }
 
@@ -1488,15 +1453,6 @@ void Renderer::setOption(const std::string& name, int64_t value)
     // 0 (default): sin / cos / acos / exp / pow as the f32 rounding of a specified f64 evaluation (bit-identical to the test oracle); 1: the device math library's f32 functions
     // (kRaygen's lens / cone angle, kSky's dome: rf_device.hpp tSin ...), graded by SURVEY 8(d)'s tolerance.  Set it before the first sample of an accumulation.
     else if (name == "transcendentals") mImpl->optTranscendentalsF32 = value != 0;
-    else if (name == "inv_stream") mImpl->optInvStream = value != 0;
-    else if (name == "texel_tiles")
-    {
-        // (wgsl:546-565's texel (i, j) from an 8 x 8-tiled copy of the blob: another address, the same texel; scenes whose tiled blob would pass 2^32 texels keep the rows)
-        mImpl->optTexelTiles = value != 0 && mImpl->tiledTexels.ptr != nullptr;
-        synchronize();
-        mImpl->scene.tiledDescriptors = mImpl->optTexelTiles ? mImpl->tiledDescriptors.ptr : nullptr;
-        mImpl->scene.tiledTexels = mImpl->optTexelTiles ? mImpl->tiledTexels.ptr : nullptr;
-    }
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;

@@ -128,7 +128,6 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
     // Occluded either way.  A ray the test does NOT stop proves nothing and is traced as before.  (Trees whose boxes are not nested, triangles that sit in two leaves or in
     // none, rays that are not class A: no shortcut -- the record's flag is 0 / the ray goes onto the list.)
     const bool selfShadow = (bounceFlags & kShadeSelfShadow) != 0u;
-    const bool writeInv = (bounceFlags & kShadeWriteInv) != 0u;
   for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x)
   {
     // Pass 1: which entries hit, which left the scene -> both output queues are appended FIRST, so that every surviving path
@@ -387,8 +386,6 @@ __global__ RF_SHADE_BOUNDS void kShade(DeviceScene scene, SkyStateGpu sky, SunBa
             const Vec3 t2 = throughput * albedo;
             store3nt(ps.rayDOut + out, wi);
             store3nt(ps.thrOut + out, t2);
-            // (kShadeWriteInv: what prepareRay() would compute in the next closest-hit launch's refill -- the same correctly rounded divides, here where the lanes wait for memory)
-            if (writeInv) store3nt(ps.rayInv + out, vec3(1.0f / wi.x, 1.0f / wi.y, 1.0f / wi.z));
         }
         return !settled;
     };

@@ -410,24 +410,15 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                 // memory round trips per refill of a closest-hit launch instead of one)
                 Vec3 dir{};
                 if (!(ANY_HIT && !shadowDirFromStream)) dir = load3s(ps.rayD + resultIndex);
-                // (round 6, kFlagInvFromStream: kShade wrote 1 / direction next to the direction -- the same three IEEE divides, issued where the lanes wait for memory
-                // instead of in this wave-wide trip: 33 of its VALU instructions)
-                const bool invFromStream = !ANY_HIT && (flags & kFlagInvFromStream) != 0u;
-                Vec3       invIn{};
-                if (invFromStream) invIn = load3s(ps.rayInv + resultIndex);
                 const Vec3 o = (!ANY_HIT && (flags & kFlagConstOrigin) != 0u) ? vec3(wide.constOriginX, wide.constOriginY, wide.constOriginZ) : load3s(ps.rayO + resultIndex);
                 if (ANY_HIT && !shadowDirFromStream)
                 {
                     const Vec3 nz = load3s(ps.noiseOut + resultIndex);
                     dir = sunSample(sky, sunBasis, nz.x, nz.y, nz.z);
                 }
-                RayPrep ray;
-                if (invFromStream)
-                {
-                    ray.origin = o, ray.direction = dir, ray.invDir = invIn;
-                    ray.negX = invIn.x < 0.0f, ray.negY = invIn.y < 0.0f, ray.negZ = invIn.z < 0.0f;
-                }
-                else ray = prepareRay(o, dir);
+                // (round 6 measured 1 / direction written by kShade next to the direction and read here instead of the three divides: closest-hit launches +1 %, kShade +4 % --
+                // the refill is not short of VALU slots, it waits for its loads: profiles/r06_lanes/README.md)
+                const RayPrep ray = prepareRay(o, dir);
                 pr = packRay(ray);
                 rayDir = dir;
                 rayTMax = tMax;

@@ -97,13 +97,6 @@ struct TextureDescriptor
     uint32_t width, height, offset;
 };
 static_assert(sizeof(TextureDescriptor) == 12);
-// round 6 (option `texel_tiles`): the same texels stored in 8 x 8 tiles (256 B: four 64-byte lines of 8 x 2 texels instead of 16 x 1) -- the address map of wgsl:546-565's
-// (i, j) changes, the texel returned does not.  One 16-byte descriptor per texture: the reference's three words + where the texture's tiles start in the tiled blob.
-struct TiledTextureDescriptor
-{
-    uint32_t width, height, offset, tiledOffset;
-};
-static_assert(sizeof(TiledTextureDescriptor) == 16);
 
 // AlignedSkyState (src/pt/aligned_sky_state.hpp:34-41): 40 floats / 160 B.
 struct SkyStateGpu

@@ -934,10 +934,7 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
         r.set_option("oct_from_bounce", 1 if seed % 8 == 2 else 2 if seed % 8 == 6 else 1 + seed % 3)
     if seed % 9 in (1, 5):                                      # kShade's own-triangle test of the shadow rays off (default: on)
         r.set_option("shadow_self_test", 0)
-    if seed % 4 == 1 or os.environ.get("RF_FUZZ_TILES"):        # round 6: texels fetched from the 8 x 8-tiled copy of the blob (textures of 1 ... 8 texels a side, uvs in -2 ... 3: partial tiles, wrapped and out-of-range lookups)
-        r.set_option("texel_tiles", 1)
-    if seed % 3 == 0 or os.environ.get("RF_FUZZ_INV"):          # round 6: 1 / direction of the bounce rays written by kShade and read by the closest-hit refill (+ an early refill)
-        r.set_option("inv_stream", 1 if not os.environ.get("RF_FUZZ_INV_OFF") else 0)
+    if seed % 3 == 0:                                           # round 6: the closest-hit launches' deep refill threshold, from "a refill for every finished lane" up
         r.set_option("refill_min_deep", 1 + seed % 9)
     if seed % 2:                                                # one batch per sample: every batch after the first starts on a warm occluder grid
         for _ in range(spp):
@@ -1162,34 +1159,17 @@ def test_f32_transcendentals_mode_within_the_stated_tolerance(duck_pt, duck_orac
     assert report["atrium_1080p_8spp_vs_default_mode"]["exact"] < 1.0
 
 
-def test_texel_tiles_are_invisible(atrium, duck_pt):
-    """Round 6: `texel_tiles` reads wgsl:546-565's texel (i, j) from a copy of the blob stored in 8 x 8 tiles -- another address, the same texel: the image
-    keeps its bits (25 textures of the atrium incl. sizes that are no multiple of 8; Duck's 512 x 512 palette image; the fuzz adds textures of 1 ... 8 texels a side)."""
+def test_refill_threshold_is_invisible(atrium, duck_pt):
+    """The refill threshold of the closest-hit launches is a scheduling choice: same image bit for bit from "a refill for every finished lane" (1) to "almost never" (63)."""
     for pt, (W, H, spp, bounces) in ((atrium, (480, 270, 4, 8)), (duck_pt, (200, 150, 4, 4))):
         r, _ = _renderer(pt, W, H, spp, bounces)
         r.render(spp)
         want = r.read_accumulation()[0]
-        r.set_option("texel_tiles", 1)
-        r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.3))
-        r.render(spp)
-        assert np.array_equal(bits(r.read_accumulation()[0]), bits(want))
-        r.close()
-
-
-def test_inv_stream_and_refill_threshold_are_invisible(atrium, duck_pt):
-    """Round 6: `inv_stream` (kShade writes 1 / direction of the bounce ray, the closest-hit refill reads it instead of issuing the three divides itself) and the refill
-    threshold are scheduling / data-path choices: same image bit for bit, whatever the threshold (1: a refill for every finished lane ... 63: almost never)."""
-    for pt, (W, H, spp, bounces) in ((atrium, (480, 270, 4, 8)), (duck_pt, (200, 150, 4, 4))):
-        r, _ = _renderer(pt, W, H, spp, bounces)
-        r.set_option("inv_stream", 0)
-        r.render(spp)
-        want = r.read_accumulation()[0]
-        for inv, refill in ((1, 22), (1, 1), (1, 8), (0, 1), (1, 63), (0, 40)):
-            r.set_option("inv_stream", inv)
+        for refill in (22, 1, 8, 63, 40):
             r.set_option("refill_min_deep", refill)
-            r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.25 + 0.001 * refill + 0.0001 * inv))   # (exposure: restarts the accumulation)
+            r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.25 + 0.001 * refill))   # (exposure: restarts the accumulation)
             r.render(spp)
-            assert np.array_equal(bits(r.read_accumulation()[0]), bits(want)), (inv, refill)
+            assert np.array_equal(bits(r.read_accumulation()[0]), bits(want)), refill
         r.close()
 
 
