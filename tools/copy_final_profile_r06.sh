@@ -1,0 +1,16 @@
+#!/bin/bash
+# After `gpurun -- bash tools/final_profile_r06.sh`: copy what was merged into gpurun_out/ into the tracked profiles/ directories (container side).
+set -e
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+cd $REPO
+F=gpurun_out/r06_final; P=profiles/r06_final
+mkdir -p $P profiles/r06_hbm
+cp $F/roofline/*.txt $F/roofline/*.csv $F/roofline/*.json $F/roofline/*.jsonl $F/roofline/trace.log $P/
+cp $F/bench_*.json $F/shard_emulation.log $F/fuzz20000.log $P/
+grep -h "passed\|failed\|error" $F/pytest_gpu.log | tail -3 > $P/pytest_gpu.txt
+cp $F/pmc_per_ray.json profiles/pmc_per_ray.json
+cp $F/pmc_per_ray_x8.json profiles/pmc_per_ray_x8.json
+for f in $(ls gpurun_out/r06_hbm | grep -v bench.err); do cp gpurun_out/r06_hbm/$f profiles/r06_hbm/$f; done
+sed -i 's/"profile": "roofline"/"profile": "r06_final"/' profiles/pmc_per_ray.json $P/pmc_per_ray.json $P/per_bounce.json
+sed -i 's/"profile": "r06_hbm"/"profile": "r06_hbm"/' profiles/pmc_per_ray_x8.json 2>/dev/null || true
+git status --short profiles | wc -l
