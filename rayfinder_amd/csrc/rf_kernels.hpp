@@ -121,6 +121,9 @@ struct DeviceCounters
     unsigned long long scalarRedo[2]; // rays redone by the scalar traversal (irregular or stack overflow), all builds
     unsigned long long abandonedRays; // rays whose traversal stack outgrew 96 entries (result = what was found until then), all builds
     unsigned long long occluderTried, occluderHit, occludedRays; // RF_EXP_PHASE builds: the any-hit launches' occluder cache
+    // RF_EXP_PHASE builds (round 6): what the lanes that do NOT take a step in a descend trip are doing -- parked at a leaf (waiting for the leaf phase) or without a ray
+    // (finished / never filled: waiting for the refill); and, in the leaf passes, lanes that still stand at an interior node / lanes without a ray.  Lane-trips, [closest, shadow]
+    unsigned long long descendParked[2], descendIdle[2], leafInterior[2], leafIdle[2];
 };
 
 struct FrameParams

@@ -1536,6 +1536,9 @@ RenderStats Renderer::stats()
                          k ? "shadow " : "closest", rays, steps / rays, c.leafTrips[k] / rays, c.popLaneTrips[k] / rays, c.outerTrips[k] * 64.0 / rays,
                          c.descendTrips[k] * 64.0 / rays, c.leafPhases[k] * 64.0 / rays, c.refillTrips[k] * 64.0 / rays, steps / (64.0 * c.descendTrips[k]),
                          c.leafTrips[k] / (64.0 * c.leafPhases[k]));
+            std::fprintf(stderr, "[rf-phase] %s: lanes of a descend trip: stepping %.3f, parked at a leaf %.3f, without a ray %.3f | lanes of a leaf pass: at a leaf %.3f, at an interior node %.3f, without a ray %.3f\n",
+                         k ? "shadow " : "closest", steps / (64.0 * c.descendTrips[k]), c.descendParked[k] / (64.0 * c.descendTrips[k]), c.descendIdle[k] / (64.0 * c.descendTrips[k]),
+                         c.leafTrips[k] / (64.0 * c.leafPhases[k]), c.leafInterior[k] / (64.0 * c.leafPhases[k]), c.leafIdle[k] / (64.0 * c.leafPhases[k]));
         }
         std::fprintf(stderr, "[rf-phase] occluder cache: shadow rays %llu, occluded %llu, cache tried %llu, answered at the cached leaf %llu\n", c.shadowRays, c.occludedRays, c.occluderTried, c.occluderHit);
     }

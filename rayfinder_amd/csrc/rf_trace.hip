@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
 #if defined(RF_EXP_PHASE)
     constexpr bool kPhase = true; // experiment build: the wave-trip / lane-trip counters of the COUNT build in EVERY kTraceWide (RF_DEBUG_COUNTERS prints them)
     uint32_t       phaseTris = 0, phaseLeafWave = 0, phaseOccTried = 0, phaseOccHit = 0, phaseOccluded = 0;
+    uint32_t       phaseParked = 0, phaseIdle = 0, phaseLeafInterior = 0, phaseLeafIdle = 0;
     bool           phaseFromCache = false;
 #else
     constexpr bool kPhase = COUNT;
@@ -541,6 +542,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         do
         {
             if (kPhase) ++wDescend;
+#if defined(RF_EXP_PHASE)
+            if (node >= kNodeDone) ++phaseIdle;                       // no ray (finished, or never filled)
+            else if (static_cast<int32_t>(node) < 0) ++phaseParked;   // stands at a leaf
+#endif
             if (static_cast<int32_t>(node) >= 0)
             {
                 if (kPhase) ++recordFetches;
@@ -1094,7 +1099,12 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         // first triangle record is live only inside its own branch.  And it is a template parameter (DENSE_LEAVES): its mere presence costs the closest-hit launches
         // of a scene that never uses it 2.5 % (profiles/r05_leaf/ab_presence.log), so scenes without long leaves run the instantiations without it.
 #if defined(RF_EXP_PHASE)
-        if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull) ++phaseLeafWave; // (every pass of a repeated leaf phase counts)
+        if (__ballot(node - kWideLeafBit < kNodeDone - kWideLeafBit) != 0ull)
+        {
+            ++phaseLeafWave; // (every pass of a repeated leaf phase counts)
+            if (node >= kNodeDone) ++phaseLeafIdle;
+            else if (static_cast<int32_t>(node) >= 0) ++phaseLeafInterior;
+        }
 #endif
         bool denseDone = false; // this lane's leaf has been dealt with by this block
         if constexpr (!COUNT && DENSE_LEAVES)
@@ -1478,6 +1488,8 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             atomicAdd(&counters->refillTrips[k], static_cast<unsigned long long>(r));
             atomicAdd(&counters->outerTrips[k], static_cast<unsigned long long>(o));
         }
+        const unsigned long long pk = waveSum(phaseParked), pi = waveSum(phaseIdle), li = waveSum(phaseLeafInterior), ld = waveSum(phaseLeafIdle);
+        if (lane == 0) atomicAdd(&counters->descendParked[k], pk), atomicAdd(&counters->descendIdle[k], pi), atomicAdd(&counters->leafInterior[k], li), atomicAdd(&counters->leafIdle[k], ld);
         const unsigned long long ot = waveSum(phaseOccTried), oh = waveSum(phaseOccHit), oc = waveSum(phaseOccluded);
         if (lane == 0 && ANY_HIT) atomicAdd(&counters->occluderTried, ot), atomicAdd(&counters->occluderHit, oh), atomicAdd(&counters->occludedRays, oc);
     }
