@@ -210,6 +210,14 @@ RF_API int rf_renderer_set_timing(rf_renderer* r, int enabled);
  *                                      scene (default 1024); occluder_grid_log2_cells n: table of 2^n cells x 16 bytes (default 22);
  *                                      shadow_first_look_from_bounce b: from this bounce on that first look is a dense pass of its own
  *                                      (kShadowFirstLook; default 2, 0: never).  Same image with any setting.
+ *   transcendentals 0 | 1              THE ONE OPTION THAT CHANGES RESULTS (round 6; default 0).  0: sin / cos / acos / exp / pow(x, 1.5) of ray generation and the sky dome are
+ *                                      the f32 rounding of a specified f64 evaluation (GPU == test oracle bit for bit); 1: the device math library's f32 functions (libm-grade) --
+ *                                      WGSL's own builtins are f32 with implementation-defined ulps (wgsl:247-275,568-616).  Within SURVEY 8(d)'s tolerance of the default
+ *                                      (>= 99.97 % of the pixels within 1e-3 |ref| + 1e-4 spp, image mean 5e-8), +0.2 % rays/s: off.  Set it before an accumulation's first sample.
+ *   refill_min, refill_min_deep, refill_deep_from_bounce, leaf_vote, chunk, chunk_early ...
+ *                                      scheduling of the persistent traversal kernel (idle lanes at which a wave refills: 40 at bounce 1 and in the any-hit
+ *                                      launches, 12 from bounce 2 on -- 22 in scenes with leaves of 5 triangles or more; lanes that must still descend for the
+ *                                      descend loop to go on; queue entries per cursor claim).  Same image with any setting.
  *   slot_group_shift, sample_sort, accumulate_runs, shade_blocks, reserve_samples, persistent_blocks, extra_lds
  *                                      path-slot order, accumulation kernel, grid sizes, occupancy experiments
  *   query_variant 0 | 2, query_compact 0 .. 5       kernels / record layout behind rf_renderer_intersect_rays / _occluded_rays (tests) */
