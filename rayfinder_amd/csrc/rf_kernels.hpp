@@ -149,7 +149,21 @@ struct FrameParams
     const uint32_t* sampleInvPerm;
     uint32_t tilesX;
     uint32_t skipOrigins; // a pinhole camera whose primary launch takes the origin as a constant (kFlagConstOrigin): kRaygen leaves ps.rayO alone
+    // Round 6: kRaygen's queue positions WITHOUT an atomic.  One device-scope counter serves ~88 returning atomics per microsecond (MI355X_MICROARCH.md, "dequeue"), and a 320-spp
+    // batch of a 1080p frame is 648 k blocks of 1 024 slots: 7.4 ms of the kernel's 7.6 were that one counter.  Which slots are pixels of the image is known in advance: the tiles'
+    // valid extents.  tileValidBefore[t] = valid pixels in the shard's tiles before tile t (numTiles + 1 entries, host: configureShard); the rank of a pixel inside its tile follows
+    // from the tile's valid width / height in closed form (validRankInTile).  Slot orders with samples of a pixel GROUP kept together (slotGroupShift 1 .. 10) keep the atomic append.
+    const uint32_t* tileValidBefore; // nullptr: append with the atomic
+    uint32_t        validPixels;     // of the shard
 };
+
+// rank of local pixel w (tile-major: 8x8 blocks of 64 lanes, localPixelToXY) among the VALID pixels of its tile -- the pixels with x < vw && y < vh in that order
+__device__ __forceinline__ uint32_t validRankInTile(uint32_t w, uint32_t vw, uint32_t vh)
+{
+    const uint32_t block = w >> 6, lane = w & 63u, bx = block & 3u, by = block >> 2, lx = lane & 7u, ly = lane >> 3;
+    const uint32_t ch = min(8u, vh - min(vh, 8u * by)), cw = min(8u, vw - min(vw, 8u * bx)); // valid rows / columns of this 8x8 block
+    return vw * min(vh, 8u * by) + ch * min(vw, 8u * bx) + cw * ly + lx;                     // block rows above + blocks to the left + rows above inside the block + pixels to the left
+}
 
 constexpr uint32_t kSlotSampleMajor = 31u;
 

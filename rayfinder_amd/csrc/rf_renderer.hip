@@ -154,6 +154,8 @@ struct Renderer::Impl
 
     std::vector<uint32_t>   tiles;
     DeviceBuffer<uint32_t>  tileIds;
+    DeviceBuffer<uint32_t>  tileValidBefore; // prefix sum of the valid pixels of the shard's tiles (numTiles + 1): kRaygen's queue positions without an atomic (FrameParams)
+    bool                    optDenseRaygen = true;
     DeviceBuffer<float4>    ownedImage;
     float4*                 image = nullptr; // compact tile-major accumulation buffer
     uint64_t                imageBytes = 0;
@@ -330,11 +332,16 @@ struct Renderer::Impl
         {
             const uint32_t tilesX = (params.width + kTileSize - 1) / kTileSize;
             validPixels = 0;
+            std::vector<uint32_t> before;
+            before.reserve(tiles.size() + 1);
             for (const uint32_t t : tiles)
             {
                 const uint32_t x0 = (t % tilesX) * kTileSize, y0 = (t / tilesX) * kTileSize;
+                before.push_back(static_cast<uint32_t>(validPixels));
                 validPixels += static_cast<uint64_t>(std::min(kTileSize, params.width - x0)) * std::min(kTileSize, params.height - y0);
             }
+            before.push_back(static_cast<uint32_t>(validPixels));
+            tileValidBefore.upload(before.data(), before.size());
         }
         if (image == nullptr || image == ownedImage.ptr)
         {
@@ -639,6 +646,10 @@ struct Renderer::Impl
         const bool    constOrigin = optConstPrimaryOrigin && camNow.lensRadius == 0.0f && camNow.origin.x != 0.0f && camNow.origin.y != 0.0f && camNow.origin.z != 0.0f &&
                                  finite3(camNow.origin) && finite3(camNow.right) && finite3(camNow.up) && primaryLayout != kLayoutScalar && primaryLayout != kLayoutPacket;
         fp.skipOrigins = constOrigin ? 1u : 0u;
+        // (kRaygen computes its queue positions instead of appending with one atomic per 1 024 slots, where the slot order allows it: FrameParams::tileValidBefore)
+        const bool denseRaygen = optDenseRaygen && (fp.slotGroupShift == 0u || fp.slotGroupShift == kSlotSampleMajor) && static_cast<uint64_t>(validPixels) * numSamples <= 0xFFFFFFFFull;
+        fp.tileValidBefore = denseRaygen ? tileValidBefore.ptr : nullptr;
+        fp.validPixels = static_cast<uint32_t>(validPixels);
         wide.constOriginX = camNow.origin.x, wide.constOriginY = camNow.origin.y, wide.constOriginZ = camNow.origin.z;
 
         const uint64_t paths = static_cast<uint64_t>(numSamples) * fp.pixelsPadded;
@@ -1453,6 +1464,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     // 0 (default): sin / cos / acos / exp / pow as the f32 rounding of a specified f64 evaluation (bit-identical to the test oracle); 1: the device math library's f32 functions
     // (kRaygen's lens / cone angle, kSky's dome: rf_device.hpp tSin ...), graded by SURVEY 8(d)'s tolerance.  Set it before the first sample of an accumulation.
     else if (name == "transcendentals") mImpl->optTranscendentalsF32 = value != 0;
+    else if (name == "dense_raygen") mImpl->optDenseRaygen = value != 0; // 0: kRaygen appends to the first queue with one atomic per 1 024 slots (until round 6)
     else if (name == "slot_group_shift") mImpl->optSlotGroupShift = value < 0 || value > 10 ? kSlotSampleMajor : static_cast<uint32_t>(value); // -1: sample-major
     else if (name == "shadow_nearest_first") mImpl->shadowNearestFirst = value != 0;
     else if (name == "shadow_sign_order" || name == "shadow_record_order") mImpl->optShadowSignOrder = value != 0;

@@ -47,7 +47,26 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
         slots[k] = slot;
         px[k] = x, py[k] = y, sample[k] = sampleIdx;
     }
-    blockAppend<kItems>(keep, slots, queue, queueCount, sScratch, &pos);
+    if (fp.tileValidBefore != nullptr)
+    {
+        // (round 6) positions in closed form, no atomic: the valid pixels of the shard in local-pixel order, a pixel's samples next to each other (slot order: the queue is the
+        // slot array with the pixels outside the image squeezed out) -- or, sample-major, sample k's pixels in one run
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+        {
+            if (!keep[k]) continue;
+            uint32_t sampleIdx, lp;
+            slotToSamplePixel(fp, slots[k], sampleIdx, lp);
+            const uint32_t tile = tileIds[lp >> 10];
+            const uint32_t x0 = (tile % fp.tilesX) * kTileSize, y0 = (tile / fp.tilesX) * kTileSize;
+            const uint32_t rank = fp.tileValidBefore[lp >> 10] + validRankInTile(lp & 1023u, min(kTileSize, fp.width - x0), min(kTileSize, fp.height - y0));
+            pos[k] = fp.slotGroupShift == kSlotSampleMajor ? sampleIdx * fp.validPixels + rank : rank * fp.numSamples + sampleIdx;
+            queue[pos[k]] = slots[k];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *queueCount = fp.validPixels * fp.numSamples;
+    }
+    else
+        blockAppend<kItems>(keep, slots, queue, queueCount, sScratch, &pos);
     // pass 2: the rays, written at their queue positions
 #pragma unroll
     for (int k = 0; k < kItems; ++k)

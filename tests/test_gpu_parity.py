@@ -1159,6 +1159,28 @@ def test_f32_transcendentals_mode_within_the_stated_tolerance(duck_pt, duck_orac
     assert report["atrium_1080p_8spp_vs_default_mode"]["exact"] < 1.0
 
 
+@pytest.mark.parametrize("shape", [(333, 217, 5, 0), (200, 150, 7, -1), (65, 33, 3, 0), (96, 64, 2, 3)])
+def test_raygen_queue_positions_without_the_atomic_are_invisible(duck_pt, shape):
+    """Round 6: kRaygen computes the first queue's positions in closed form (the valid pixels of the shard's tiles in local-pixel order: `validRankInTile`) instead of appending with
+    one atomic per 1 024 slots.  Same rays, same image, same ray counts on ragged frames (right / bottom tiles partly outside), sample-major slots (-1) and -- where the slot order
+    keeps pixel groups together (3) and the atomic append stays -- with the option on or off; shards included."""
+    W, H, spp, g = shape
+    out = []
+    for dense in (0, 1):
+        for (rank, world) in ((0, 1), (1, 3)):
+            r, _ = _renderer(duck_pt, W, H, spp, 4)
+            r.set_option("dense_raygen", dense)
+            r.set_option("slot_group_shift", g)
+            r.set_tile_shard(rank, world)
+            r.render(spp)
+            s = r.stats()
+            out.append((dense, rank, world, r.read_accumulation()[0], s["primary_rays"], s["closest_rays"], s["shadow_rays"]))
+            r.close()
+    for a, b in ((out[0], out[2]), (out[1], out[3])):
+        assert np.array_equal(bits(a[3]), bits(b[3])) and a[4:] == b[4:], (shape, a[1], a[2])
+    assert out[0][4] == W * H * spp
+
+
 def test_refill_threshold_is_invisible(atrium, duck_pt):
     """The refill threshold of the closest-hit launches is a scheduling choice: same image bit for bit from "a refill for every finished lane" (1) to "almost never" (63)."""
     for pt, (W, H, spp, bounces) in ((atrium, (480, 270, 4, 8)), (duck_pt, (200, 150, 4, 4))):
