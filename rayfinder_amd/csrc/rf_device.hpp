@@ -439,17 +439,20 @@ __device__ __forceinline__ Vec3 evalTexture(const DeviceScene& scene, const floa
 }
 
 // wgsl:602-616; table texel = u8 / 255.0f (reference_path_tracer.cpp:174-178)
-__device__ __forceinline__ void animatedBlueNoise(const uint8_t* table, uint32_t x, uint32_t y, uint32_t frameIdx,
-                                                  uint32_t totalSampleCount, float& nx, float& ny)
+// (n = frameIdx % totalSampleCount, wgsl:608, computed by the caller: kRaygen has it without a software division, rf_kernels.hpp FastDiv)
+__device__ __forceinline__ void animatedBlueNoiseN(const uint8_t* table, uint32_t x, uint32_t y, uint32_t n, float& nx, float& ny)
 {
     const uint32_t idx = (y % 128u) * 128u + (x % 128u);
     const float    bx = static_cast<float>(table[2 * idx]) / 255.0f;
     const float    by = static_cast<float>(table[2 * idx + 1]) / 255.0f;
-    const uint32_t n = frameIdx % totalSampleCount;
     const float    a1 = 0.7548776662466927f;
     const float    a2 = 0.5698402909980532f;
     nx = wFract(bx + wFract(a1 * static_cast<float>(n)));
     ny = wFract(by + wFract(a2 * static_cast<float>(n)));
+}
+__device__ __forceinline__ void animatedBlueNoise(const uint8_t* table, uint32_t x, uint32_t y, uint32_t frameIdx, uint32_t totalSampleCount, float& nx, float& ny)
+{
+    animatedBlueNoiseN(table, x, y, frameIdx % totalSampleCount, nx, ny);
 }
 #endif // __HIPCC__
 } // namespace rf

@@ -126,6 +126,38 @@ struct DeviceCounters
     unsigned long long descendParked[2], descendIdle[2], leafInterior[2], leafIdle[2];
 };
 
+// Division of a 32-bit unsigned by a divisor that is a RUN-TIME value but the same for a whole launch (samples per batch, tiles per row, samples per pixel): the exact quotient from
+// one multiply-high, an add and two shifts (Granlund & Montgomery's round-up method) instead of the ~30-instruction software division the compiler emits for `n / d` -- kRaygen is
+// VALU bound and divided three times per path (round 6).  Host: FastDiv::make(d); device: div(n) == n / d for every n < 2^32, d >= 1.
+struct FastDiv
+{
+    uint32_t mul, shift1, shift2, divisor;
+    static FastDiv make(uint32_t d)
+    {
+        FastDiv f{0u, 0u, 0u, d ? d : 1u};
+        uint32_t l = 0;
+        while ((1ull << l) < f.divisor) ++l; // ceil(log2 d)
+        f.mul = static_cast<uint32_t>(((1ull << 32) * ((1ull << l) - f.divisor)) / f.divisor + 1ull);
+        f.shift1 = l < 1u ? l : 1u;
+        f.shift2 = l > 1u ? l - 1u : 0u;
+        return f;
+    }
+    __host__ __device__ __forceinline__ uint32_t div(uint32_t n) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t t = __umulhi(mul, n);
+#else
+        const uint32_t t = static_cast<uint32_t>((static_cast<uint64_t>(mul) * n) >> 32);
+#endif
+        return (t + ((n - t) >> shift1)) >> shift2;
+    }
+    __host__ __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const
+    {
+        q = div(n);
+        r = n - q * divisor;
+    }
+};
+
 struct FrameParams
 {
     uint32_t width, height;
@@ -155,6 +187,7 @@ struct FrameParams
     // from the tile's valid width / height in closed form (validRankInTile).  Slot orders with samples of a pixel GROUP kept together (slotGroupShift 1 .. 10) keep the atomic append.
     const uint32_t* tileValidBefore; // nullptr: append with the atomic
     uint32_t        validPixels;     // of the shard
+    FastDiv         divNumSamples, divPixelsPadded, divTilesX, divSamplesPerPixel; // the launch-invariant divisors of the slot / pixel / frame arithmetic (host: traceBatch)
 };
 
 // rank of local pixel w (tile-major: 8x8 blocks of 64 lanes, localPixelToXY) among the VALID pixels of its tile -- the pixels with x < vw && y < vh in that order
@@ -169,16 +202,13 @@ constexpr uint32_t kSlotSampleMajor = 31u;
 
 __device__ __forceinline__ void slotToSamplePixel(const FrameParams& fp, uint32_t slot, uint32_t& k, uint32_t& lp)
 {
-    if (fp.slotGroupShift == kSlotSampleMajor)
-    {
-        k = slot / fp.pixelsPadded;
-        lp = slot % fp.pixelsPadded;
-    }
+    if (fp.slotGroupShift == kSlotSampleMajor) fp.divPixelsPadded.divmod(slot, k, lp);
     else
     {
         const uint32_t g = fp.slotGroupShift, chunk = slot >> g;
-        k = chunk % fp.numSamples;
-        lp = ((chunk / fp.numSamples) << g) + (slot & ((1u << g) - 1u));
+        uint32_t       group;
+        fp.divNumSamples.divmod(chunk, group, k);
+        lp = (group << g) + (slot & ((1u << g) - 1u));
     }
 }
 __device__ __forceinline__ size_t samplePixelToSlot(const FrameParams& fp, uint32_t k, uint32_t lp)
@@ -194,8 +224,10 @@ __device__ __forceinline__ bool localPixelToXY(const FrameParams& fp, const uint
     const uint32_t tile = tileIds[lp >> 10];
     const uint32_t w = lp & 1023u;
     const uint32_t block = w >> 6, lane = w & 63u;
-    x = (tile % fp.tilesX) * kTileSize + (block & 3u) * 8u + (lane & 7u);
-    y = (tile / fp.tilesX) * kTileSize + (block >> 2) * 8u + (lane >> 3);
+    uint32_t       tileX, tileY;
+    fp.divTilesX.divmod(tile, tileY, tileX);
+    x = tileX * kTileSize + (block & 3u) * 8u + (lane & 7u);
+    y = tileY * kTileSize + (block >> 2) * 8u + (lane >> 3);
     return x < fp.width && y < fp.height;
 }
 

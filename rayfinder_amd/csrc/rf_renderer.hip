@@ -637,6 +637,8 @@ struct Renderer::Impl
         }
         fp.tilesX = (params.width + kTileSize - 1) / kTileSize;
         if (fp.numTiles == 0) return;
+        fp.divNumSamples = FastDiv::make(fp.numSamples), fp.divPixelsPadded = FastDiv::make(fp.pixelsPadded), fp.divTilesX = FastDiv::make(fp.tilesX);
+        fp.divSamplesPerPixel = FastDiv::make(fp.samplesPerPixel);
         // Pinhole camera (lensRadius == 0): kRaygen's origin = camera.origin + (0 * right + 0 * up) is camera.origin itself for every path, bit for bit, as long as no
         // component of camera.origin is a zero (whose sign the +-0 addend could flip) and right / up are finite (0 * inf = NaN).  The primary launch then takes it as a kernel
         // argument and kRaygen writes 28 instead of 40 bytes per path.  Only the wide traversal kernels know the flag (the scalar kernels read ps.rayO).

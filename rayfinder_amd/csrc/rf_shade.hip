@@ -58,7 +58,9 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
             uint32_t sampleIdx, lp;
             slotToSamplePixel(fp, slots[k], sampleIdx, lp);
             const uint32_t tile = tileIds[lp >> 10];
-            const uint32_t x0 = (tile % fp.tilesX) * kTileSize, y0 = (tile / fp.tilesX) * kTileSize;
+            uint32_t       tileX, tileY;
+            fp.divTilesX.divmod(tile, tileY, tileX);
+            const uint32_t x0 = tileX * kTileSize, y0 = tileY * kTileSize;
             const uint32_t rank = fp.tileValidBefore[lp >> 10] + validRankInTile(lp & 1023u, min(kTileSize, fp.width - x0), min(kTileSize, fp.height - y0));
             pos[k] = fp.slotGroupShift == kSlotSampleMajor ? sampleIdx * fp.validPixels + rank : rank * fp.numSamples + sampleIdx;
             queue[pos[k]] = slots[k];
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void kRaygen(FrameParams fp, DeviceScene sc
         const uint32_t x = px[k], y = py[k];
         const uint32_t frame = fp.firstFrame + (fp.samplePerm ? fp.samplePerm[sample[k]] : sample[k]);
         float          nx, ny;
-        animatedBlueNoise(scene.blueNoise, x, y, frame, fp.samplesPerPixel, nx, ny);
+        animatedBlueNoiseN(scene.blueNoise, x, y, frame - fp.divSamplesPerPixel.div(frame) * fp.samplesPerPixel, nx, ny); // (n = frame % spp, wgsl:608, without the software division: FastDiv)
 
         // fragment centre (wgsl:36-43); v runs down the image
         const float u = (static_cast<float>(x) + 0.5f) / static_cast<float>(fp.width);
