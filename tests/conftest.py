@@ -13,6 +13,7 @@ DUCK = os.path.join(GOLDEN, "Duck.glb")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: timing assertions on a real MI355X (python -m pytest tests -m perf, no -x; never part of the parity runs)")
 
 
 def pytest_collection_modifyitems(config, items):
