@@ -201,6 +201,9 @@ struct Renderer::Impl
     uint32_t optOccluderCacheBounces = 64; // the any-hit launches of bounces 1..n first visit the leaves their ray's cell of the occluder grid names (kFlagOccluderCache)
     bool     optShadowSignOrder = true; // the half-precision / local-grid shadow launches (VALU bound) visit entries in record order: a cheaper step beats the shorter walks of nearest-first there
     uint32_t optRefillMin = kRefillMin, optLeafVote = kLeafVote, optChunk = kChunk;
+    // closest-hit launches of scenes without long leaves whose tree stays cache resident leave the descend loop later (round 6: 14 instead of 20 lanes still descending; plain atrium
+    // closest-hit -1.5 %, Duck -1.4 %; the dense-leaf instantiations +4.7 % and the out-of-cache scene +1 % with it: they keep 20 -- profiles/r06_lanes/ab_leaf_vote*.log)
+    uint32_t optLeafVoteClosest = 14;
     // leaf phases in which a parked lane holds this many triangles or more run over dense (lane, triangle) pairs (kTraceWide; 0: never), from this bounce on
     uint32_t optDenseLeafMin = 5, optDenseLeafFromBounce = 1; // (5: the plain atrium's leaves of up to 4 triangles keep the loop -- 3 measured +1 % there; the clutter scene gains the same with 2 .. 5)
     uint32_t maxLeafTriangles = 0; // of the scene (upload): scenes without a leaf as long as the threshold run the instantiations WITHOUT the dense block
@@ -422,6 +425,7 @@ struct Renderer::Impl
         const uint32_t* count;
         uint32_t*       cursor;
         uint32_t        refillMin, chunk;
+        uint32_t        leafVote; // 0: optLeafVote
         float           tMax;
         dim3            grid;
         uint32_t        extraLds;
@@ -433,7 +437,7 @@ struct Renderer::Impl
         TraceWideKernel k = traceWideKernel(anyHit, count, nearest, compact, dense);
         if (k == nullptr && dense) k = traceWideKernel(anyHit, count, nearest, compact, false);
         if (k == nullptr) throw std::logic_error("kTraceWide: record layout " + std::to_string(compact) + " is not compiled into this build");
-        hipLaunchKernelGGL(k, a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr, a.refillMin, optLeafVote, a.chunk, a.tMax, flags);
+        hipLaunchKernelGGL(k, a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr, a.refillMin, a.leafVote ? a.leafVote : optLeafVote, a.chunk, a.tMax, flags);
     }
     // the layout a test asks for, if this scene has it (else the binary records)
     int layoutIfPresent(int want) const
@@ -549,7 +553,7 @@ struct Renderer::Impl
         RF_HIP(hipMemcpyAsync(queueCounts.ptr, &count, sizeof count, hipMemcpyHostToDevice, stream));
         PathStreams ps{sRayO.ptr, sRayD.ptr, sThr.ptr, sRad.ptr, sHit.ptr, sPending.ptr, sNoise.ptr, sRayD2.ptr, sThr2.ptr, sNoise2.ptr};
         const dim3  grid(std::min<uint32_t>(static_cast<uint32_t>((n + kBlock - 1) / kBlock), wideBlocks));
-        const WideArgs wa{ps, queueA.ptr, queueCounts.ptr, queueCounts.ptr + kLineWords, optRefillMin, optChunk, tMax, grid, 0u};
+        const WideArgs wa{ps, queueA.ptr, queueCounts.ptr, queueCounts.ptr + kLineWords, optRefillMin, optChunk, 0u, tMax, grid, 0u};
         if (shadow)
         {
             // rad = 0, pending = 1: rad.x becomes visibility * SOLAR_INV_PDF
@@ -733,6 +737,8 @@ struct Renderer::Impl
             // (scenes with long leaves -- the DENSE_LEAVES instantiations -- keep 22: a phase over dense (lane, triangle) pairs wants many parked lanes; clutter atrium +2.4 % at 12: profiles/r06_lanes)
             const uint32_t refillClosest = bounce >= optRefillDeepFromBounce ? (layoutClosest == kLayoutQuad ? optRefillMinDeepQuad : (denseWanted(uniformFlag) ? optRefillMinDeepDense : optRefillMinDeep)) : optRefillMin;
             (void)conservativeClosest;
+            // (kInfinityCacheBytes: the scene's records + triangles against the 256-MB Infinity Cache, as the layout selector's own test)
+            const uint32_t leafVoteClosest = (!counting && !denseWanted(uniformFlag) && treeBytes <= (192ull << 20)) ? optLeafVoteClosest : 0u;
             launchTimed(1, [&] {
                 if (layoutClosest == kLayoutScalar)
                 {
@@ -746,7 +752,7 @@ struct Renderer::Impl
                     hipLaunchKernelGGL(tracePacketKernel(false), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
 #endif
                 else
-                    launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds},
+                    launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, leafVoteClosest, kTMax, persistentGrid, counting ? 0u : optExtraLds},
                                       uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u));
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
@@ -806,7 +812,7 @@ struct Renderer::Impl
                     // the conservative layouts (VALU bound) visit a record's entries in record order unless asked otherwise; the exact and binary records nearest-first
                     const bool conservative = layoutShadow == kLayoutQuadLocal || layoutShadow == kLayoutQuadHalf;
                     const bool nearest = shadowNearestFirst && !(conservative && optShadowSignOrder);
-                    launchShadowWide(layoutShadow, nearest, counting, wide, WideArgs{ps, qOut, countShadow, cursorShadow, optRefillMin, chunkNow, kTMax, persistentGrid, counting ? 0u : optExtraLds}, shadowFlags);
+                    launchShadowWide(layoutShadow, nearest, counting, wide, WideArgs{ps, qOut, countShadow, cursorShadow, optRefillMin, chunkNow, 0u, kTMax, persistentGrid, counting ? 0u : optExtraLds}, shadowFlags);
                 }
             }, bounce - 1);
             std::swap(qIn, qOut);
@@ -1435,7 +1441,7 @@ void Renderer::setOption(const std::string& name, int64_t value)
     else if (name == "refill_min") mImpl->optRefillMin = mImpl->optRefillMinDeep = mImpl->optRefillMinDeepDense = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value); // (all: a sweep of one value covers every launch)
     else if (name == "refill_min_deep") mImpl->optRefillMinDeep = mImpl->optRefillMinDeepDense = mImpl->optRefillMinDeepQuad = static_cast<uint32_t>(value);
     else if (name == "refill_deep_from_bounce") mImpl->optRefillDeepFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 1));
-    else if (name == "leaf_vote") mImpl->optLeafVote = static_cast<uint32_t>(value);
+    else if (name == "leaf_vote") mImpl->optLeafVote = mImpl->optLeafVoteClosest = static_cast<uint32_t>(value);
     else if (name == "dense_leaf_min") mImpl->optDenseLeafMin = static_cast<uint32_t>(std::clamp<int64_t>(value, 0, 15));
     else if (name == "dense_leaf_from_bounce") mImpl->optDenseLeafFromBounce = static_cast<uint32_t>(std::max<int64_t>(value, 1));
     else if (name == "chunk") mImpl->optChunk = mImpl->optChunkEarly = static_cast<uint32_t>(std::clamp<int64_t>(value, 1, 1 << 20)); // (both, as refill_min)

@@ -934,8 +934,9 @@ def test_random_scenes_cameras_and_skies_bit_identical_to_oracle(seed):
         r.set_option("oct_from_bounce", 1 if seed % 8 == 2 else 2 if seed % 8 == 6 else 1 + seed % 3)
     if seed % 9 in (1, 5):                                      # kShade's own-triangle test of the shadow rays off (default: on)
         r.set_option("shadow_self_test", 0)
-    if seed % 3 == 0:                                           # round 6: the closest-hit launches' deep refill threshold, from "a refill for every finished lane" up
+    if seed % 3 == 0:                                           # round 6: the closest-hit launches' deep refill threshold, from "a refill for every finished lane" up, ...
         r.set_option("refill_min_deep", 1 + seed % 9)
+        r.set_option("leaf_vote", 1 + (seed % 7) * 9)           # ... and the number of lanes that must still descend for the descend loop to go on (1 ... 55)
     if seed % 2:                                                # one batch per sample: every batch after the first starts on a warm occluder grid
         for _ in range(spp):
             r.render(1)
@@ -1189,6 +1190,7 @@ def test_refill_threshold_is_invisible(atrium, duck_pt):
         want = r.read_accumulation()[0]
         for refill in (22, 1, 8, 63, 40):
             r.set_option("refill_min_deep", refill)
+            r.set_option("leaf_vote", {22: 20, 1: 64, 8: 1, 63: 14, 40: 33}[refill])     # (and the descend loop's exit vote: scheduling only)
             r.set_render_parameters(rf.make_render_parameters(W, H, rf.fly_camera(W, H), spp, bounces, rf.make_sky(), 0.25 + 0.001 * refill))   # (exposure: restarts the accumulation)
             r.render(spp)
             assert np.array_equal(bits(r.read_accumulation()[0]), bits(want)), refill
