@@ -23,6 +23,8 @@
 // device memory, so a whole batch is enqueued without any host round trip.
 #include "rf_kernels.hpp"
 
+#include <map>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -178,6 +180,9 @@ struct Renderer::Impl
     bool counting = false, timing = false;
     int      traversalVariant = 2; // 0 = one ray per thread over 32-B nodes (A/B baseline), 2 = persistent waves over 64-B wide nodes
     uint32_t wideBlocks = 0;
+    bool     wideBlocksForced = false; // option persistent_blocks: every persistent launch takes that grid
+    uint32_t multiProcessors = 0;
+    std::map<std::pair<const void*, uint32_t>, uint32_t> residentCache; // kernel, extra LDS -> workgroups the device holds at once
     uint32_t skyBlocks = 2048; // grid of the per-bounce kSky launches (grid-stride; set from the CU count)
     bool     wideUsable = true;
     int      queryVariant = 0; // 2: rf_renderer_intersect_rays / _occluded_rays run through kTraceWide (test hook; no per-ray counters)
@@ -429,15 +434,31 @@ struct Renderer::Impl
         float           tMax;
         dim3            grid;
         uint32_t        extraLds;
+        uint32_t        blocksWanted = 0; // != 0: the launch's worst-case workgroup count; the grid becomes min(this, what the device holds of the kernel launched)
     };
     // One kTraceWide launch: the instantiation named by (any-hit, counting build, nearest-first, record layout, dense leaf phase) from rf_trace.hip's table; a
     // combination the table does not hold falls back to the same one without the dense leaf phase (options can ask for it on a layout it is not built for)
+    // Workgroups of THIS instantiation the device holds at once.  The persistent grid used to be sized once, from the closest-hit kernel (6 per CU: 80 VGPRs, 24 KB of LDS); the
+    // any-hit instantiations need 63 ... 72 VGPRs and -- round 6: their stack holds child words only, 4 bytes per entry -- 12 KB: most of them fit 7 per CU.
+    uint32_t residentBlocks(TraceWideKernel k, uint32_t extraLds)
+    {
+        const auto key = std::make_pair(reinterpret_cast<const void*>(k), extraLds);
+        const auto it = residentCache.find(key);
+        if (it != residentCache.end()) return it->second;
+        int perCu = 0;
+        RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(k), kBlock, extraLds));
+        const uint32_t n = static_cast<uint32_t>(std::max(perCu, 1)) * std::max(multiProcessors, 1u);
+        residentCache[key] = n;
+        return n;
+    }
     void launchWide(bool anyHit, bool count, bool nearest, int compact, bool dense, const WideScene& w, const WideArgs& a, uint32_t flags)
     {
         TraceWideKernel k = traceWideKernel(anyHit, count, nearest, compact, dense);
         if (k == nullptr && dense) k = traceWideKernel(anyHit, count, nearest, compact, false);
         if (k == nullptr) throw std::logic_error("kTraceWide: record layout " + std::to_string(compact) + " is not compiled into this build");
-        hipLaunchKernelGGL(k, a.grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr, a.refillMin, a.leafVote ? a.leafVote : optLeafVote, a.chunk, a.tMax, flags);
+        dim3 grid = a.grid;
+        if (a.blocksWanted != 0u && !wideBlocksForced && !count) grid = dim3(std::min(a.blocksWanted, residentBlocks(k, a.extraLds)));
+        hipLaunchKernelGGL(k, grid, dim3(kBlock), a.extraLds, stream, scene, w, sky, sunBasis, a.ps, a.queue, a.count, a.cursor, counters.ptr, a.refillMin, a.leafVote ? a.leafVote : optLeafVote, a.chunk, a.tMax, flags);
     }
     // the layout a test asks for, if this scene has it (else the binary records)
     int layoutIfPresent(int want) const
@@ -752,7 +773,7 @@ struct Renderer::Impl
                     hipLaunchKernelGGL(tracePacketKernel(false), persistentGrid, dim3(kBlock), 0, stream, scene, wide, sky, sunBasis, ps, qIn, countIn, counters.ptr, kTMax, 0u);
 #endif
                 else
-                    launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, leafVoteClosest, kTMax, persistentGrid, counting ? 0u : optExtraLds},
+                    launchClosestWide(layoutClosest, counting, wide, WideArgs{ps, qIn, countIn, cursorClosest, counting ? optRefillMin : refillClosest, chunkNow, leafVoteClosest, kTMax, persistentGrid, counting ? 0u : optExtraLds, blocks},
                                       uniformFlag | (bounce == 1 && constOrigin ? kFlagConstOrigin : 0u));
             }, bounce - 1);
             uint32_t* const missCount = missCounts + kLine * (bounce - 1);
@@ -812,7 +833,7 @@ struct Renderer::Impl
                     // the conservative layouts (VALU bound) visit a record's entries in record order unless asked otherwise; the exact and binary records nearest-first
                     const bool conservative = layoutShadow == kLayoutQuadLocal || layoutShadow == kLayoutQuadHalf;
                     const bool nearest = shadowNearestFirst && !(conservative && optShadowSignOrder);
-                    launchShadowWide(layoutShadow, nearest, counting, wide, WideArgs{ps, qOut, countShadow, cursorShadow, optRefillMin, chunkNow, 0u, kTMax, persistentGrid, counting ? 0u : optExtraLds}, shadowFlags);
+                    launchShadowWide(layoutShadow, nearest, counting, wide, WideArgs{ps, qOut, countShadow, cursorShadow, optRefillMin, chunkNow, 0u, kTMax, persistentGrid, counting ? 0u : optExtraLds, blocks}, shadowFlags);
                 }
             }, bounce - 1);
             std::swap(qIn, qOut);
@@ -1091,6 +1112,7 @@ Renderer::Renderer(const RendererDescriptor& desc, const SceneView& sceneView) :
         int perCu = 0;
         RF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(traceWideKernel(false, false, false, 0, false)), kBlock, 0));
         m.wideBlocks = static_cast<uint32_t>(std::max(perCu, 1)) * static_cast<uint32_t>(prop.multiProcessorCount);
+        m.multiProcessors = static_cast<uint32_t>(prop.multiProcessorCount);
         m.skyBlocks = 8u * static_cast<uint32_t>(prop.multiProcessorCount);
         if (const char* v = std::getenv("RF_TRAVERSAL_VARIANT")) m.traversalVariant = std::atoi(v);
         if (const char* v = std::getenv("RF_PACKET_BOUNCES")) m.optPacketBounces = static_cast<uint32_t>(std::max(std::atoi(v), 0)); // experiments: whole test suite through kTracePacket
@@ -1494,7 +1516,12 @@ void Renderer::setOption(const std::string& name, int64_t value)
         }
     }
     else if (name == "query_variant") mImpl->queryVariant = mImpl->wideUsable ? static_cast<int>(value) : 0;
-    else if (name == "persistent_blocks") mImpl->wideBlocks = static_cast<uint32_t>(value);
+    else if (name == "persistent_blocks")
+    {
+        // > 0: every persistent launch takes that grid; 0: back to what the device holds of the kernel launched (residentBlocks)
+        mImpl->wideBlocksForced = value > 0;
+        mImpl->wideBlocks = value > 0 ? static_cast<uint32_t>(value) : mImpl->residentBlocks(traceWideKernel(false, false, false, 0, false), mImpl->optExtraLds);
+    }
     else if (name == "extra_lds")
     {
         Impl& m = *mImpl;

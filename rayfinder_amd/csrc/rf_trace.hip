@@ -144,8 +144,14 @@ constexpr int wideStackDepth()
     return (COUNT && !NEAREST_FIRST) ? 28 : kWideLdsStack;
 }
 
+// (experiment builds, RF_EXP_ANYHIT_WAVES=n: the any-hit kernels -- whose stack holds child words only, 4 bytes per entry: half the LDS of the closest-hit kernels' -- at n waves per SIMD)
+#if defined(RF_EXP_ANYHIT_WAVES)
+constexpr int kWideWavesAnyHit = RF_EXP_ANYHIT_WAVES;
+#else
+constexpr int kWideWavesAnyHit = kWideWaves;
+#endif
 template<bool ANY_HIT, bool COUNT, bool NEAREST_FIRST = false, int COMPACT = 0, bool DENSE_LEAVES = false>
-__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
+__global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : ((ANY_HIT && !COUNT) ? kWideWavesAnyHit : kWideWaves)) void kTraceWide(DeviceScene scene, WideScene wide, SkyStateGpu sky, SunBasis sunBasis, PathStreams ps,
                                                                                         const uint32_t* queue, const uint32_t* queueCount, uint32_t* cursor,
                                                                                         DeviceCounters* counters, uint32_t refillMin, uint32_t leafVote,
                                                                                         uint32_t chunkMax, float tMax, uint32_t flags)
@@ -159,7 +165,9 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     static_assert(COMPACT != 1 && COMPACT != 2, "the compact-capable and the 32-byte records are experiment-build layouts (make EXP=RF_EXP_LEGACY_LAYOUTS)");
 #endif
     constexpr bool kConservative = COMPACT == 4 || COMPACT == 5 || COMPACT == 6; // interior tests accept a superset; every leaf's EXACT box is applied at the leaf
-    __shared__ uint2 sStack[kDepth * kBlock];
+    // (an any-hit kernel's entries are child words only -- kStackWordsOnly below --: 4 bytes each, 12 KB per workgroup instead of 24)
+    using StackEntry = std::conditional_t<ANY_HIT && !kRefCount, uint32_t, uint2>;
+    __shared__ StackEntry sStack[kDepth * kBlock];
     const uint32_t   count = *queueCount;
     const uint32_t   lane = __lane_id();
     const bool       shadowDirFromStream = flags & kFlagShadowDirFromStream;
@@ -229,14 +237,18 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // of the scenes with long leaves (DENSE_LEAVES) loses 6 % with it -- a phase of its kind wants many parked lanes -- and the any-hit launches stop at their first hit:
     // both keep the plain schedule.  (As a run-time threshold in the launch flags the loop cost 4 % by its presence; a compile-time constant costs nothing.)
     constexpr bool     kEagerLeaves = !ANY_HIT && !COUNT && !DENSE_LEAVES;
-    constexpr uint32_t kLeafRepeat = 8u; // (6 ... 12, and 2 ... 16 for the skipped descend loop alone, measure the same: profiles/r05_leafrep/ab_thresholds.log)
+#if defined(RF_EXP_LEAF_REPEAT)
+    constexpr uint32_t kLeafRepeat = RF_EXP_LEAF_REPEAT;
+#else
+    constexpr uint32_t kLeafRepeat = 8u;
+#endif // (6 ... 12, and 2 ... 16 for the skipped descend loop alone, measure the same: profiles/r05_leafrep/ab_thresholds.log)
     constexpr bool kPtrStack = !COUNT && !ANY_HIT;
     const int     spBase = kPtrStack ? static_cast<int>(threadIdx.x * sizeof(uint2)) : 0;
     constexpr int kSpStep = kPtrStack ? static_cast<int>(kBlock * sizeof(uint2)) : 1;
     constexpr int kSpLimit = kPtrStack ? kDepth * static_cast<int>(kBlock * sizeof(uint2)) : kDepth; // (depth == kDepth <=> offset >= this: lane * 8 < kBlock * 8)
     int       stackSize = spBase;
-    const auto stackAt = [&](int s) -> uint2& {
-        if constexpr (kPtrStack) return *reinterpret_cast<uint2*>(reinterpret_cast<char*>(sStack) + s);
+    const auto stackAt = [&](int s) -> StackEntry& {
+        if constexpr (kPtrStack) return *reinterpret_cast<StackEntry*>(reinterpret_cast<char*>(sStack) + s);
         else return sStack[s * kBlock + threadIdx.x];
     };
     bool      needScalar = false; // irregular ray or stack overflow: redo with the scalar traversal
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
     // kernel keeps only the words on its stack (no tmin to select, store and compare) -- except the reference-bookkeeping build, which
     // pushes missed children with tmin = +inf to count them.
     constexpr bool kStackWordsOnly = ANY_HIT && !kRefCount;
+    static_assert(std::is_same_v<StackEntry, uint32_t> == kStackWordsOnly, "the LDS stack's entry type follows kStackWordsOnly");
     // ---- Rays that need more than the LDS stack holds.  Until round 4 such a ray was redone whole by the scalar traversal (one lane, the
     // reference-ordered kernel over the 32-byte nodes): fine at 0.01 % of the rays (the plain atrium), a cliff at 2.6 % (the atrium with clutter, whose
     // long diagonal boxes keep many candidates alive: closest-hit launches 3.2 x longer than with the binary records, which push at most one entry per
@@ -262,13 +275,13 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         if (spilled + kEvict > static_cast<uint32_t>(kEvict * kSpillBlocks)) return false;
         for (int i = 0; i < kEvict; ++i)
         {
-            if constexpr (kStackWordsOnly) spillBuf[spilled + i] = stackAt(slotS(i)).x;
+            if constexpr (kStackWordsOnly) spillBuf[spilled + i] = stackAt(slotS(i));
             else spillBuf[spilled + i] = stackAt(slotS(i));
         }
         const int depth = kPtrStack ? (stackSize - spBase) / kSpStep : stackSize;
         for (int i = kEvict; i < depth; ++i)
         {
-            if constexpr (kStackWordsOnly) stackAt(slotS(i - kEvict)).x = stackAt(slotS(i)).x;
+            if constexpr (kStackWordsOnly) stackAt(slotS(i - kEvict)) = stackAt(slotS(i));
             else stackAt(slotS(i - kEvict)) = stackAt(slotS(i));
         }
         stackSize -= kEvict * kSpStep;
@@ -283,20 +296,20 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
         const uint32_t spilled = negMask >> 8;
         for (int i = 0; i < kEvict; ++i)
         {
-            if constexpr (kStackWordsOnly) stackAt(slotS(i)).x = spillBuf[spilled + i];
+            if constexpr (kStackWordsOnly) stackAt(slotS(i)) = spillBuf[spilled + i];
             else stackAt(slotS(i)) = spillBuf[spilled + i];
         }
         stackSize = slotS(kEvict);
     };
     auto      push = [&](uint32_t word, float tmin) -> bool {
         if (stackSize >= kSpLimit && !evict()) return false;
-        if constexpr (kStackWordsOnly) stackAt(stackSize).x = word;
+        if constexpr (kStackWordsOnly) stackAt(stackSize) = word;
         else stackAt(stackSize) = make_uint2(word, __float_as_uint(tmin));
         stackSize += kSpStep;
         return true;
     };
     auto      pushUnchecked = [&](uint32_t word, float tmin) {
-        if constexpr (kStackWordsOnly) stackAt(stackSize).x = word;
+        if constexpr (kStackWordsOnly) stackAt(stackSize) = word;
         else stackAt(stackSize) = make_uint2(word, __float_as_uint(tmin));
         stackSize += kSpStep;
     };
@@ -324,22 +337,25 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
             if (stackSize > spBase)
             {
                 stackSize -= kSpStep;
-                node = stackAt(stackSize).x;
+                node = stackAt(stackSize);
                 if (COUNT) ++wPop;
             }
             return;
         }
-        while (stackSize > spBase)
+        else
         {
-            stackSize -= kSpStep;
-            uint2 e = stackAt(stackSize);
-            asm volatile("" : "+v"(e.x), "+v"(e.y)); // one ds_read_b64 (not tmin first, word after the loop)
-            if (COUNT) ++wPop;
-            if (kRefCount) ++rayNodes;
-            if (__uint_as_float(e.y) < rayTMax)
+            while (stackSize > spBase)
             {
-                node = e.x;
-                break;
+                stackSize -= kSpStep;
+                uint2 e = stackAt(stackSize);
+                asm volatile("" : "+v"(e.x), "+v"(e.y)); // one ds_read_b64 (not tmin first, word after the loop)
+                if (COUNT) ++wPop;
+                if (kRefCount) ++rayNodes;
+                if (__uint_as_float(e.y) < rayTMax)
+                {
+                    node = e.x;
+                    break;
+                }
             }
         }
     };
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(kBlock, (COUNT && !NEAREST_FIRST) ? 2 : kWideWaves)
                                 if (!(__float_as_uint(gap[e]) >> 31))
                                 {
                                     const int rank = __popc(later >> pos[e]); // hit slots visited after this one: they lie below it
-                                    if constexpr (kStackWordsOnly) stackAt(stackSize + rank * kSpStep).x = words[e];
+                                    if constexpr (kStackWordsOnly) stackAt(stackSize + rank * kSpStep) = words[e];
                                     else stackAt(stackSize + rank * kSpStep) = make_uint2(words[e], __float_as_uint(tq[e]));
                                 }
                             stackSize += need * kSpStep;
