@@ -946,6 +946,10 @@ def main():
             "config": {"workload": f"{info['name']}{'' if scene_path else ' -- the real Sponza.glb is not in the reference mount'}, {W}x{H}, {B} bounces, "
                                    f"{SPS} spp per step x {K} steps = {spp} spp, default rayfinder camera + sky ({cfg_label}; tiled over {world} GPU(s))",
                        "spp_per_step": SPS, "spp": spp,
+                       # (the timed region's batches, from rf_stats of its median repeat on rank 0: a render call that does not get the configured depth -- device memory short --
+                       # traces shallower batches, same image, shorter launches; 148 B of path state per path in flight)
+                       "samples_per_batch": int(s["batch_samples_used"]), "batches": int(s["batches_traced"]), "paths_per_batch": int(s["batch_samples_used"]) * tiles_rank0 * 1024,
+                       "path_state_gb": round(int(s["batch_samples_used"]) * tiles_rank0 * 1024 * 148 / 1e9, 1),
                        "scene_triangles": info.get("triangles"), "scene_textures": info.get("textures"), "scene_digest": info.get("digest"),
                        "sharding": f"32x32 tiles along a Z-order curve dealt round-robin (rotated per block) over {world} rank(s), one exchange at frame end: {exchange}" if multi else "none"},
             "timed_region_s": round(elapsed, 4),
