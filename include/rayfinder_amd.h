@@ -252,6 +252,9 @@ RF_API int rf_renderer_bind_accumulation_buffer(rf_renderer* r, void* device_ptr
  * zero), and that includes a caller-owned buffer bound with rf_renderer_bind_accumulation_buffer (its first
  * rf_renderer_accumulation_device_buffer() bytes).  RF_GATHER_LOOPBACK: the root's own shard also
  * goes through ncclSend/ncclRecv instead of being read in place (self-test of the RCCL path at world size 1). */
+/* MI355X devices this process sees (hipGetDeviceCount; 0 without a GPU).  No reference counterpart (the reference asks Dawn for one adapter,
+ * gpu_context.cpp); what a host application sizes `--gpus N` against. */
+RF_API int rf_device_count(int32_t* count_out);
 typedef struct rf_comm rf_comm;
 #define RF_COMM_ID_BYTES 128
 #define RF_GATHER_LOOPBACK 1u

@@ -360,6 +360,13 @@ def gather_plan(width, height, world_size, rank, root=0, loopback=False):
     return ops
 
 
+def device_count():
+    """hipGetDeviceCount as the library sees it (0 without a GPU)."""
+    n = C.c_int32(0)
+    check(lib.rf_device_count(C.byref(n)))
+    return n.value
+
+
 def comm_unique_id():
     """ncclGetUniqueId: 128 bytes that rank 0 hands to the other ranks before TileComm(...)."""
     buf = np.zeros(128, np.uint8)

@@ -126,6 +126,7 @@ SIGNATURES = {
     "rf_renderer_shard_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "rf_renderer_accumulation_device_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "rf_renderer_bind_accumulation_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rf_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
     "rf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rf_comm_create": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]),
     "rf_comm_destroy": (None, [C.c_void_p]),

@@ -72,16 +72,20 @@ int main(int argc, char** argv)
     std::vector<float>              acc;
     if (!pfm.empty()) acc.resize(static_cast<size_t>(W) * H * 4);
     double       seconds = 0.0;
+    // rank r runs on device r -- modulo the devices there are: with more ranks than GPUs RCCL refuses the communicator (two ranks on one device), the local TEST transport
+    // (RF_COMM_TRANSPORT=local in the environment: rf_comm.hip) runs them all on what is there -- how the exchange is exercised with many owners on a single-GPU box
+    int32_t deviceCount = 0;
+    rfCheck(rf_device_count(&deviceCount), "device count");
     const auto   worker = [&](uint32_t rank) {
         rf_renderer_descriptor d = desc;
-        d.device_ordinal = static_cast<int32_t>(rank);
+        d.device_ordinal = static_cast<int32_t>(deviceCount > 0 ? rank % static_cast<uint32_t>(deviceCount) : rank);
         rf_renderer* renderer = nullptr;
         rfCheck(rf_renderer_create(&d, &scene, &renderer), "create renderer");
         rf_comm* comm = nullptr;
         if (gpus > 1)
         {
             rfCheck(rf_renderer_set_tile_shard(renderer, rank, gpus), "tile shard");
-            rfCheck(rf_comm_create(commId, rank, gpus, static_cast<int32_t>(rank), &comm), "RCCL communicator");
+            rfCheck(rf_comm_create(commId, rank, gpus, d.device_ordinal, &comm), "RCCL communicator");
         }
         const auto t0 = std::chrono::steady_clock::now();
         rfCheck(rf_renderer_render(renderer, spp), "render");

@@ -370,6 +370,15 @@ int rf_renderer_bind_accumulation_buffer(rf_renderer* r, void* device_ptr, uint6
     });
 }
 
+int rf_device_count(int32_t* count_out)
+{
+    return guarded([&] {
+        require(count_out, "null argument");
+        *count_out = rf::deviceCount();
+        return RF_OK;
+    });
+}
+
 int rf_comm_unique_id(uint8_t id_out[RF_COMM_ID_BYTES])
 {
     return guarded([&] {

@@ -258,6 +258,17 @@ struct TileComm::Impl
     }
 };
 
+int deviceCount()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
 void TileComm::uniqueId(uint8_t out[kCommIdBytes])
 {
     static_assert(sizeof(ncclUniqueId) == kCommIdBytes);

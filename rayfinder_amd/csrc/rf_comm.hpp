@@ -41,6 +41,9 @@ struct GatherOp
 };
 std::vector<GatherOp> gatherPlan(const GatherLayout& layout, uint32_t worldSize, uint32_t rank, uint32_t root, bool loopback);
 
+// HIP devices this process sees (0 without a GPU or a driver; never throws)
+int deviceCount();
+
 class TileComm
 {
 public:

@@ -1471,6 +1471,29 @@ def test_lockstep_packet_traversal_gives_identical_images(duck_pt, duck_oracle, 
     assert np.array_equal(bits(images[0]), bits(images[1]))
 
 
+def test_rf_render_cli_four_ranks_on_one_gpu_through_the_local_transport(duck_pt, tmp_path):
+    """`rf-render --gpus N` (one host thread per rank: renderer, tile shard, communicator, frame-end gather, the root's tonemap of the gathered image) had never run with N > 1: RCCL
+    refuses two ranks per device.  Under RF_COMM_TRANSPORT=local the same binary runs its 4 (and 3) ranks on the one GPU there is; PNG and PFM must equal the --gpus 1 files byte for byte."""
+    import subprocess
+    from conftest import ROOT
+    scene = tmp_path / "Duck.pt"
+    duck_pt.save(scene)
+    exe = os.path.join(ROOT, "rayfinder_amd", "bin", "rf-render")
+    W, H, spp, bounces = 200, 150, 4, 3                  # ragged right / bottom tiles
+    outs = {}
+    for gpus in (1, 4, 3):
+        png, pfm = tmp_path / f"g{gpus}.png", tmp_path / f"g{gpus}.pfm"
+        env = dict(os.environ, RF_COMM_TRANSPORT="local", RF_COMM_TIMEOUT_S="120")
+        txt = subprocess.check_output([exe, str(scene), "--width", str(W), "--height", str(H), "--spp", str(spp), "--bounces", str(bounces), "--out", str(png), "--pfm", str(pfm),
+                                       "--gpus", str(gpus)], env=env, timeout=300).decode()
+        assert f"on {gpus} GPU(s)" in txt
+        outs[gpus] = (open(png, "rb").read(), open(pfm, "rb").read(), txt.split("(")[-1])
+    for gpus in (4, 3):
+        assert outs[gpus][0] == outs[1][0], f"PNG of --gpus {gpus} differs"
+        assert outs[gpus][1] == outs[1][1], f"PFM of --gpus {gpus} differs"
+        assert outs[gpus][2] == outs[1][2], (outs[gpus][2], outs[1][2])            # the same rays in total
+
+
 def test_rf_render_cli_writes_the_tonemapped_image(duck_pt, tmp_path):
     """rf-render (the offline twin of the `pt` app, --gpus 1 path): its PNG holds exactly rf_renderer_read_tonemapped's texels."""
     import subprocess
