@@ -434,7 +434,7 @@ ShadeKernel             shadeKernel(bool sorted);
 SkyKernel               skyKernel(bool f32Transcendentals);
 BounceTotalsKernel      bounceTotalsKernel();
 AccumulateKernel        accumulateKernel();
-AccumulateRunsKernel    accumulateRunsKernel();
+AccumulateRunsKernel    accumulateRunsKernel(uint32_t pixelsPerWorkgroup); // 1, 2 or kAccPixels
 TonemapKernel           tonemapKernel();
 DeferredLightingKernel  deferredLightingKernel();
 } // namespace kern

@@ -851,8 +851,12 @@ struct Renderer::Impl
         if (wide.occGrid != nullptr) occluderGridWarm = true;
         launchTimed(4, [&] {
             if (fp.slotGroupShift == 0u && numSamples > 4u && numSamples <= kAccMaxSamples && optAccumulateRuns)
-                hipLaunchKernelGGL(accumulateRunsKernel(), dim3((fp.pixelsPadded + kAccPixels - 1) / kAccPixels), dim3(64), kAccPixels * 3u * (numSamples + 1u) * sizeof(float), stream, fp,
+            {
+                // (pixels per workgroup by the LDS their runs take: <= ~8 KB per workgroup keeps twenty of them resident per CU)
+                const uint32_t accPixels = numSamples > 640u ? 1u : (numSamples > 160u ? 2u : kAccPixels);
+                hipLaunchKernelGGL(accumulateRunsKernel(accPixels), dim3((fp.pixelsPadded + accPixels - 1) / accPixels), dim3(64), accPixels * 3u * (numSamples + 1u) * sizeof(float), stream, fp,
                                    tileIds.ptr, ps, image);
+            }
             else
                 hipLaunchKernelGGL(accumulateKernel(), dim3((fp.pixelsPadded + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, fp, tileIds.ptr, ps, image);
         });

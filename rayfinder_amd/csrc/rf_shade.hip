@@ -534,12 +534,15 @@ __global__ __launch_bounds__(kBlock) void kAccumulate(FrameParams fp, const uint
 // one lane per (pixel, channel) adds its samples in sample-index order -- the order is the result (f32, H15), so the
 // additions stay sequential; only the memory traffic changes.  Dynamic LDS: kAccPixels * (numSamples + 1) * 12 bytes (rows padded by one float: bank-conflict-free sums).
 
+// PIXELS per 64-lane workgroup: the runs of PIXELS pixels are staged in LDS (PIXELS x 3 x (S + 1) floats), so deep batches take fewer pixels per workgroup to keep workgroups
+// resident (round 6: 320 spp per batch: 4 pixels = 15 KB, ten workgroups per CU, 3.36 ms; 2 pixels: 2.24 ms; 64 spp: 4 pixels 0.37 ms, 2 pixels 0.43: profiles/r06_raygen)
+template<uint32_t PIXELS>
 __global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint32_t* tileIds, PathStreams ps, float4* image)
 {
     extern __shared__ float sRun[]; // [pixel][channel][sample], rows of S + 1 floats: the twelve lanes that sum walk twelve different banks
     const uint32_t S = fp.numSamples, R = S + 1u, lane = threadIdx.x;
-    const uint32_t lp0 = blockIdx.x * kAccPixels;
-    for (uint32_t px = 0; px < kAccPixels; ++px)
+    const uint32_t lp0 = blockIdx.x * PIXELS;
+    for (uint32_t px = 0; px < PIXELS; ++px)
     {
         const uint32_t lp = lp0 + px;
         if (lp >= fp.pixelsPadded) break;
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(64) void kAccumulateRuns(FrameParams fp, const uint
         }
     }
     __syncthreads();
-    if (lane >= kAccPixels * 3u) return;
+    if (lane >= PIXELS * 3u) return;
     const uint32_t px = lane / 3u, c = lane % 3u, lp = lp0 + px;
     if (lp >= fp.pixelsPadded) return;
     uint32_t x, y;
@@ -762,7 +765,7 @@ ShadeKernel             shadeKernel(bool sorted) { return sorted ? kShade<true> 
 SkyKernel               skyKernel(bool f32) { return f32 ? kSky<true> : kSky<false>; }
 BounceTotalsKernel      bounceTotalsKernel() { return kBounceTotals; }
 AccumulateKernel        accumulateKernel() { return kAccumulate; }
-AccumulateRunsKernel    accumulateRunsKernel() { return kAccumulateRuns; }
+AccumulateRunsKernel    accumulateRunsKernel(uint32_t pixels) { return pixels == 1u ? kAccumulateRuns<1> : pixels == 2u ? kAccumulateRuns<2> : kAccumulateRuns<kAccPixels>; }
 TonemapKernel           tonemapKernel() { return kTonemap; }
 DeferredLightingKernel  deferredLightingKernel() { return kDeferredLighting; }
 } // namespace kern

@@ -1182,6 +1182,22 @@ def test_raygen_queue_positions_without_the_atomic_are_invisible(duck_pt, shape)
     assert out[0][4] == W * H * spp
 
 
+@pytest.mark.parametrize("spp", [100, 300, 700])
+def test_accumulation_of_deep_batches_in_sample_order(duck_pt, duck_oracle, spp):
+    """kAccumulateRuns stages the runs of 4 / 2 / 1 pixels per workgroup in LDS depending on the samples per batch (round 6: <= 160 / <= 640 / more): the per-channel sums are the
+    reference's sequential f32 additions in sample order (wgsl:55-57) whichever instantiation runs -- one batch of 100 / 300 / 700 samples against the oracle, bit for bit."""
+    W, H, bounces = 40, 24, 2
+    r, params = _renderer(duck_pt, W, H, spp, bounces)
+    r.render(spp)
+    img, acc = r.read_accumulation()
+    s = r.stats()
+    r.close()
+    assert acc == spp and s["batch_samples_used"] == spp and s["batches_traced"] == 1
+    rp = orc.make_render_params(W, H, rf.camera_to_array(params.camera), spp, bounces, 0.25, rf.aligned_sky_state(params.sky))
+    ref, _ = orc.render(duck_oracle.scene, rp, 0, spp)
+    assert np.array_equal(bits(img[..., :3]), bits(ref[..., :3]))
+
+
 def test_refill_threshold_is_invisible(atrium, duck_pt):
     """The refill threshold of the closest-hit launches is a scheduling choice: same image bit for bit from "a refill for every finished lane" (1) to "almost never" (63)."""
     for pt, (W, H, spp, bounces) in ((atrium, (480, 270, 4, 8)), (duck_pt, (200, 150, 4, 4))):
